@@ -1,0 +1,788 @@
+// rau_cpu.cc -- CPU oracle for the RAU forward/backward path (float and double).
+//
+// TEST INFRASTRUCTURE ONLY; see rau_oracle.h for the rules and for the
+// "parity unpinned" statement.  Every function cites the reference lines it
+// restates (paths under /root/reference; "SS" =
+// experiments/Ours_SS/LstmAttCtrlGradNoiseDontSelect.lua).
+//
+// Torch7 `nn` semantics honoured here: Linear y=xW^T+b with
+// W[out,in]; 1x1 SpatialConvolution on NCHW = per-position Linear; Dropout v2
+// (inverted: keep/(1-p) in training, identity in evaluate); SoftMax over the
+// last dim; CrossEntropyCriterion = LogSoftMax + ClassNLL with sizeAverage;
+// torch.max returns the FIRST maximal index; gModule sums gradients at fan-out.
+#include "rau_oracle.h"
+
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+namespace {
+
+template <typename real>
+using vec = std::vector<real>;
+
+// ---------------------------------------------------------------- small BLAS
+// C[m,n] (+)= sum_k A[m,k] * B[n,k]     (Linear forward, W stored [out,in])
+template <typename real>
+void gemm_nt(int M, int N, int K, const real* A, int lda, const real* B, int ldb,
+             real* C, int ldc, bool acc) {
+#pragma omp parallel for schedule(static)
+  for (int m = 0; m < M; ++m) {
+    const real* a = A + (size_t)m * lda;
+    real* c = C + (size_t)m * ldc;
+    for (int n = 0; n < N; ++n) {
+      const real* b = B + (size_t)n * ldb;
+      real s = 0;
+      for (int k = 0; k < K; ++k) s += a[k] * b[k];
+      c[n] = acc ? c[n] + s : s;
+    }
+  }
+}
+// C[m,n] (+)= sum_k A[m,k] * B[k,n]     (dgrad: dx = dy W)
+template <typename real>
+void gemm_nn(int M, int N, int K, const real* A, int lda, const real* B, int ldb,
+             real* C, int ldc, bool acc) {
+#pragma omp parallel for schedule(static)
+  for (int m = 0; m < M; ++m) {
+    real* c = C + (size_t)m * ldc;
+    if (!acc)
+      for (int n = 0; n < N; ++n) c[n] = 0;
+    const real* a = A + (size_t)m * lda;
+    for (int k = 0; k < K; ++k) {
+      const real av = a[k];
+      const real* b = B + (size_t)k * ldb;
+      for (int n = 0; n < N; ++n) c[n] += av * b[n];
+    }
+  }
+}
+// C[m,n] += sum_k A[k,m] * B[k,n]       (wgrad: dW += dy^T x)
+template <typename real>
+void gemm_tn_acc(int M, int N, int K, const real* A, int lda, const real* B,
+                 int ldb, real* C, int ldc) {
+#pragma omp parallel for schedule(static)
+  for (int m = 0; m < M; ++m) {
+    real* c = C + (size_t)m * ldc;
+    for (int k = 0; k < K; ++k) {
+      const real av = A[(size_t)k * lda + m];
+      const real* b = B + (size_t)k * ldb;
+      for (int n = 0; n < N; ++n) c[n] += av * b[n];
+    }
+  }
+}
+// bias gradient: db[n] += sum_m dY[m,n]
+template <typename real>
+void colsum_acc(int M, int N, const real* dY, int ld, real* db) {
+  for (int m = 0; m < M; ++m)
+    for (int n = 0; n < N; ++n) db[n] += dY[(size_t)m * ld + n];
+}
+template <typename real>
+void add_bias(int M, int N, real* Y, int ld, const real* b) {
+  for (int m = 0; m < M; ++m)
+    for (int n = 0; n < N; ++n) Y[(size_t)m * ld + n] += b[n];
+}
+template <typename real>
+inline real sigm(real x) {
+  return real(1) / (real(1) + std::exp(-x));
+}
+
+// ------------------------------------------------------------ param layouts
+// A Linear layer inside a flat group: weight [out,in] then bias [out].
+template <typename real>
+struct Lin {
+  const real* W;
+  const real* b;
+  real* dW;
+  real* db;
+  int out, in;
+};
+template <typename real>
+struct Cursor {
+  const real* p;
+  real* g;
+  size_t off = 0;
+  Lin<real> take(int out, int in) {
+    Lin<real> l;
+    l.out = out;
+    l.in = in;
+    l.W = p + off;
+    l.dW = g ? g + off : nullptr;
+    off += (size_t)out * in;
+    l.b = p + off;
+    l.db = g ? g + off : nullptr;
+    off += (size_t)out;
+    return l;
+  }
+};
+
+// mult group (SS:229-307), order = BASELINE.md section 2.3
+template <typename real>
+struct MultP {
+  Lin<real> q_proj, h_proj, i_embed, att_q, att_i, att_score, att_mem,
+      feat_attprob, lstm_i2h, lstm_h2h, lstm_out, cls, do_pred;
+  size_t n;
+  MultP(const rau_oracle_cfg& c, const real* p, real* g) {
+    Cursor<real> cur{p, g};
+    const int Q = 4 * c.Rq;
+    q_proj = cur.take(c.M, Q);            // SS:233 Linear(rnnout_dim, multfeat_dim)
+    h_proj = cur.take(c.M, c.R);          // SS:234
+    i_embed = cur.take(c.M, c.D);         // SS:240 1x1 conv D->M
+    att_q = cur.take(c.A, c.M);           // SS:246 Linear(M, A)
+    att_i = cur.take(c.A, c.M);           // SS:247 1x1 conv M->A
+    att_score = cur.take(1, c.A);         // SS:251 1x1 conv A->1
+    att_mem = cur.take(c.S, c.R);         // SS:287 Linear(R, S)
+    feat_attprob = cur.take(c.M, c.S);    // SS:271 Linear(S, M)
+    lstm_i2h = cur.take(4 * c.R, c.M);    // ATTLSTM.lua:6
+    lstm_h2h = cur.take(4 * c.R, c.R);    // ATTLSTM.lua:7
+    lstm_out = cur.take(c.M, c.R);        // SS:279 Linear(R, M)
+    cls = cur.take(c.K, c.M);             // SS:280
+    do_pred = cur.take(1, c.M);           // SS:281
+    n = cur.off;
+  }
+};
+// rnn group (DeepLSTM.lua:42-43), two layers
+template <typename real>
+struct RnnP {
+  Lin<real> i2h[2], h2h[2];
+  size_t n;
+  RnnP(const rau_oracle_cfg& c, const real* p, real* g) {
+    Cursor<real> cur{p, g};
+    for (int L = 0; L < 2; ++L) {
+      i2h[L] = cur.take(4 * c.Rq, L == 0 ? c.E : c.Rq);
+      h2h[L] = cur.take(4 * c.Rq, c.Rq);
+    }
+    n = cur.off;
+  }
+};
+
+// Linear forward Y[B,out] (+)= X[B,in] W^T (+ b)
+template <typename real>
+void lin_fwd(const Lin<real>& l, int B, const real* X, int ldx, real* Y, int ldy,
+             bool acc) {
+  gemm_nt<real>(B, l.out, l.in, X, ldx, l.W, l.in, Y, ldy, acc);
+  add_bias<real>(B, l.out, Y, ldy, l.b);
+}
+// Linear backward: dX (+)= dY W ; dW += dY^T X ; db += colsum dY
+template <typename real>
+void lin_bwd(const Lin<real>& l, int B, const real* X, int ldx, const real* dY,
+             int ldy, real* dX, int lddx, bool acc_dx) {
+  if (dX) gemm_nn<real>(B, l.in, l.out, dY, ldy, l.W, l.in, dX, lddx, acc_dx);
+  gemm_tn_acc<real>(l.out, l.in, B, dY, ldy, X, ldx, l.dW, l.in);
+  colsum_acc<real>(B, l.out, dY, ldy, l.db);
+}
+
+// ------------------------------------------------------------- saved state
+template <typename real>
+struct HopSave {  // everything one hop's backward needs
+  vec<real> qd, qf, I, T, a, j, gi, gg, gf, go, c, tanhc, h, mf;
+};
+template <typename real>
+struct TokSave {
+  vec<real> we;          // [B,E] tanh(drop(E[x_t]))
+  vec<real> x2;          // [B,Rq] dropout(h1_t), layer-2 input
+  vec<real> gi[2], gf[2], go[2], gg[2], tanhc[2];
+  vec<real> state;       // [B,4Rq] packed [c1 h1 c2 h2] AFTER step t
+};
+
+template <typename real>
+int step(const rau_oracle_cfg& c, const real* embed, const real* rnn,
+         const real* mult, const real* feats, const int32_t* tokens,
+         const int32_t* lens, const int32_t* labels, const uint8_t* m_we,
+         const uint8_t* m_rnn, const uint8_t* m_q, const uint8_t* m_x,
+         const uint8_t* m_mf, const real* hop_w, real* losses, int32_t* argmax,
+         real* logits_out, real* dopred_out, real* att_out, real* q_out,
+         real* attc_out, real* atth_out, real* g_embed, real* g_rnn,
+         real* g_mult) {
+  const int B = c.B, T = c.T, E = c.E, Rq = c.Rq, D = c.D, S = c.S, M = c.M,
+            A = c.A, R = c.R, K = c.K, H = c.H;
+  const int Q = 4 * Rq;
+  const bool do_bwd = g_embed || g_rnn || g_mult;
+  if (do_bwd && !(g_embed && g_rnn && g_mult)) return -1;
+  for (int b = 0; b < B; ++b) {
+    if (lens[b] < 0 || lens[b] > T) return -2;
+    if (labels && (labels[b] < 1 || labels[b] > K)) return -3;
+  }
+  for (size_t i = 0; i < (size_t)T * B; ++i)
+    if (tokens[i] < 1 || tokens[i] > c.V) return -4;
+
+  MultP<real> mp(c, mult, g_mult);
+  RnnP<real> rp(c, rnn, g_rnn);
+  const real s_we = real(1) / (real(1) - real(c.p_we));
+  const real s_rnn = real(1) / (real(1) - real(c.p_rnn));
+  const real s_q = real(1) / (real(1) - real(c.p_q));
+  const real s_x = real(1) / (real(1) - real(c.p_x));
+  const real s_mf = real(1) / (real(1) - real(c.p_mf));
+
+  // ================================================= encoder forward, SS:443-462
+  int max_len = 0;
+  for (int b = 0; b < B; ++b) max_len = lens[b] > max_len ? lens[b] : max_len;
+  std::vector<TokSave<real>> toks(max_len + 1);
+  toks[0].state.assign((size_t)B * Q, 0);  // init_state zeros, SS:358
+  vec<real> q((size_t)B * Q, 0);           // rnn_out:zero(), SS:447
+  vec<real> sums((size_t)B * 4 * Rq);
+  for (int t = 1; t <= max_len; ++t) {
+    TokSave<real>& ts = toks[t];
+    const int32_t* xt = tokens + (size_t)(t - 1) * B;
+    // word_embed: LookupTable -> Dropout(0.5) -> Tanh, SS:203-206
+    ts.we.resize((size_t)B * E);
+    for (int b = 0; b < B; ++b)
+      for (int e = 0; e < E; ++e) {
+        real v = embed[(size_t)(xt[b] - 1) * E + e];
+        if (m_we)
+          v = m_we[((size_t)(t - 1) * B + b) * E + e] ? v * s_we : real(0);
+        ts.we[(size_t)b * E + e] = std::tanh(v);
+      }
+    const vec<real>& prev = toks[t - 1].state;
+    ts.state.resize((size_t)B * Q);
+    const real* xin = ts.we.data();
+    int xin_ld = E;
+    for (int L = 0; L < 2; ++L) {  // DeepLSTM.lua:29-65
+      const real* prev_c = prev.data() + 2 * L * Rq;       // Narrow, :24
+      const real* prev_h = prev.data() + (2 * L + 1) * Rq; // Narrow, :25
+      if (L == 1) {  // dropout between layers, DeepLSTM.lua:39
+        ts.x2.resize((size_t)B * Rq);
+        for (int b = 0; b < B; ++b)
+          for (int r = 0; r < Rq; ++r) {
+            real v = ts.state[(size_t)b * Q + Rq + r];  // h1 of this step
+            if (m_rnn)
+              v = m_rnn[((size_t)(t - 1) * B + b) * Rq + r] ? v * s_rnn : real(0);
+            ts.x2[(size_t)b * Rq + r] = v;
+          }
+        xin = ts.x2.data();
+        xin_ld = Rq;
+      }
+      lin_fwd<real>(rp.i2h[L], B, xin, xin_ld, sums.data(), 4 * Rq, false);
+      lin_fwd<real>(rp.h2h[L], B, prev_h, Q, sums.data(), 4 * Rq, true);
+      ts.gi[L].resize((size_t)B * Rq);
+      ts.gf[L].resize((size_t)B * Rq);
+      ts.go[L].resize((size_t)B * Rq);
+      ts.gg[L].resize((size_t)B * Rq);
+      ts.tanhc[L].resize((size_t)B * Rq);
+      for (int b = 0; b < B; ++b)
+        for (int r = 0; r < Rq; ++r) {
+          const real* sb = sums.data() + (size_t)b * 4 * Rq;
+          // sigmoid chunk = [in, forget, out], tanh chunk last; DeepLSTM.lua:46-54
+          const real gi = sigm(sb[r]), gf = sigm(sb[Rq + r]),
+                     go = sigm(sb[2 * Rq + r]), gg = std::tanh(sb[3 * Rq + r]);
+          const real cn = gf * prev_c[(size_t)b * Q + r] + gi * gg;  // :56-59
+          const real tc = std::tanh(cn);
+          const size_t o = (size_t)b * Rq + r;
+          ts.gi[L][o] = gi; ts.gf[L][o] = gf; ts.go[L][o] = go; ts.gg[L][o] = gg;
+          ts.tanhc[L][o] = tc;
+          ts.state[(size_t)b * Q + 2 * L * Rq + r] = cn;
+          ts.state[(size_t)b * Q + (2 * L + 1) * Rq + r] = go * tc;  // :61
+        }
+    }
+    // rnn_out[k] = lst[k] where x_len[k] == t, SS:455-461
+    for (int b = 0; b < B; ++b)
+      if (lens[b] == t)
+        std::memcpy(&q[(size_t)b * Q], &ts.state[(size_t)b * Q], sizeof(real) * Q);
+  }
+  if (q_out) std::memcpy(q_out, q.data(), sizeof(real) * B * Q);
+
+  // ================================================== RAU forward, SS:467-520
+  std::vector<HopSave<real>> hops(H);
+  vec<real> c_prev((size_t)B * R, 0), h_prev((size_t)B * R, 0);  // SS:362-365
+  std::vector<vec<real>> c_hist(H + 1), h_hist(H + 1);
+  c_hist[0] = c_prev;
+  h_hist[0] = h_prev;
+  vec<real> logits((size_t)B * K), u((size_t)B * A), z((size_t)B * S),
+      v((size_t)B * M), g4((size_t)B * 4 * R), pre((size_t)B * M);
+  std::vector<vec<real>> dlogits_all(H);
+  for (int h = 0; h < H; ++h) {
+    HopSave<real>& hs = hops[h];
+    const real* hp = h_hist[h].data();
+    const real* cp = c_hist[h].data();
+    // q_embed, SS:231-236
+    hs.qd.resize((size_t)B * Q);
+    for (size_t i = 0; i < (size_t)B * Q; ++i) {
+      real val = q[i];
+      if (m_q) val = m_q[(size_t)h * B * Q + i] ? val * s_q : real(0);
+      hs.qd[i] = val;
+    }
+    hs.qf.resize((size_t)B * M);
+    lin_fwd<real>(mp.q_proj, B, hs.qd.data(), Q, hs.qf.data(), M, false);
+    lin_fwd<real>(mp.h_proj, B, hp, R, hs.qf.data(), M, true);
+    for (auto& x : hs.qf) x = std::tanh(x);
+    // i_embed, SS:238-242: I[b,m,s] = tanh(sum_d Wi[m,d] * drop(X)[b,d,s] + bi[m])
+    hs.I.assign((size_t)B * M * S, 0);
+#pragma omp parallel for schedule(static)
+    for (int b = 0; b < B; ++b) {
+      real* Ib = hs.I.data() + (size_t)b * M * S;
+      const real* Xb = feats + (size_t)b * D * S;
+      const uint8_t* mb = m_x ? m_x + ((size_t)h * B + b) * D * S : nullptr;
+      vec<real> xd((size_t)D * S);
+      for (size_t i = 0; i < (size_t)D * S; ++i)
+        xd[i] = mb ? (mb[i] ? Xb[i] * s_x : real(0)) : Xb[i];
+      for (int m = 0; m < M; ++m) {
+        real* row = Ib + (size_t)m * S;
+        const real* w = mp.i_embed.W + (size_t)m * D;
+        for (int d = 0; d < D; ++d) {
+          const real wv = w[d];
+          const real* xr = xd.data() + (size_t)d * S;
+          for (int s = 0; s < S; ++s) row[s] += wv * xr[s];
+        }
+        for (int s = 0; s < S; ++s) row[s] = std::tanh(row[s] + mp.i_embed.b[m]);
+      }
+    }
+    // attbycontent, SS:244-252
+    lin_fwd<real>(mp.att_q, B, hs.qf.data(), M, u.data(), A, false);
+    hs.T.assign((size_t)B * A * S, 0);
+    vec<real> e((size_t)B * S);
+#pragma omp parallel for schedule(static)
+    for (int b = 0; b < B; ++b) {
+      const real* Ib = hs.I.data() + (size_t)b * M * S;
+      real* Tb = hs.T.data() + (size_t)b * A * S;
+      for (int k = 0; k < A; ++k) {
+        real* row = Tb + (size_t)k * S;
+        const real* w = mp.att_i.W + (size_t)k * M;
+        for (int m = 0; m < M; ++m) {
+          const real wv = w[m];
+          const real* ir = Ib + (size_t)m * S;
+          for (int s = 0; s < S; ++s) row[s] += wv * ir[s];
+        }
+        const real add = mp.att_i.b[k] + u[(size_t)b * A + k];
+        for (int s = 0; s < S; ++s) row[s] = std::tanh(row[s] + add);
+      }
+      for (int s = 0; s < S; ++s) {
+        real acc = 0;
+        for (int k = 0; k < A; ++k) acc += mp.att_score.W[k] * Tb[(size_t)k * S + s];
+        e[(size_t)b * S + s] = acc + mp.att_score.b[0];
+      }
+    }
+    // attbymemory, SS:285-290: a = softmax(e + h_prev Wm^T + bm)
+    lin_fwd<real>(mp.att_mem, B, hp, R, z.data(), S, false);
+    hs.a.resize((size_t)B * S);
+    for (int b = 0; b < B; ++b) {
+      real mx = -INFINITY;
+      for (int s = 0; s < S; ++s) {
+        z[(size_t)b * S + s] += e[(size_t)b * S + s];
+        mx = z[(size_t)b * S + s] > mx ? z[(size_t)b * S + s] : mx;
+      }
+      real den = 0;
+      for (int s = 0; s < S; ++s) {
+        const real ex = std::exp(z[(size_t)b * S + s] - mx);
+        hs.a[(size_t)b * S + s] = ex;
+        den += ex;
+      }
+      for (int s = 0; s < S; ++s) hs.a[(size_t)b * S + s] /= den;
+    }
+    // attselect, SS:254-263: v[b,m] = sum_s I[b,m,s] a[b,s]
+    for (int b = 0; b < B; ++b)
+      for (int m = 0; m < M; ++m) {
+        const real* ir = hs.I.data() + ((size_t)b * M + m) * S;
+        real acc = 0;
+        for (int s = 0; s < S; ++s) acc += ir[s] * hs.a[(size_t)b * S + s];
+        v[(size_t)b * M + m] = acc;
+      }
+    // classifier, SS:265-283
+    hs.j.resize((size_t)B * M);
+    lin_fwd<real>(mp.feat_attprob, B, hs.a.data(), S, hs.j.data(), M, false);
+    for (size_t i = 0; i < (size_t)B * M; ++i) hs.j[i] += hs.qf[i] + v[i];
+    lin_fwd<real>(mp.lstm_i2h, B, hs.j.data(), M, g4.data(), 4 * R, false);
+    lin_fwd<real>(mp.lstm_h2h, B, hp, R, g4.data(), 4 * R, true);
+    hs.gi.resize((size_t)B * R); hs.gg.resize((size_t)B * R);
+    hs.gf.resize((size_t)B * R); hs.go.resize((size_t)B * R);
+    hs.c.resize((size_t)B * R); hs.tanhc.resize((size_t)B * R);
+    hs.h.resize((size_t)B * R);
+    for (int b = 0; b < B; ++b)
+      for (int r = 0; r < R; ++r) {
+        const real* gb = g4.data() + (size_t)b * 4 * R;
+        // Reshape(4,R)+SplitTable: 1=in(sigm) 2=in_transform(tanh) 3=forget 4=out
+        // ATTLSTM.lua:12-19
+        const real gi = sigm(gb[r]), gg = std::tanh(gb[R + r]),
+                   gf = sigm(gb[2 * R + r]), go = sigm(gb[3 * R + r]);
+        const size_t o = (size_t)b * R + r;
+        const real cn = gf * cp[o] + gi * gg;  // ATTLSTM.lua:21-24
+        const real tc = std::tanh(cn);
+        hs.gi[o] = gi; hs.gg[o] = gg; hs.gf[o] = gf; hs.go[o] = go;
+        hs.c[o] = cn; hs.tanhc[o] = tc; hs.h[o] = go * tc;  // :25
+      }
+    lin_fwd<real>(mp.lstm_out, B, hs.h.data(), R, pre.data(), M, false);
+    hs.mf.resize((size_t)B * M);
+    for (size_t i = 0; i < (size_t)B * M; ++i) {
+      real val = pre[i] + hs.j[i];
+      if (m_mf) val = m_mf[(size_t)h * B * M + i] ? val * s_mf : real(0);
+      hs.mf[i] = val;
+    }
+    lin_fwd<real>(mp.cls, B, hs.mf.data(), M, logits.data(), K, false);
+    // do_pred = Sum(2)(Sigmoid(Linear(M,1))), SS:281
+    for (int b = 0; b < B; ++b) {
+      real acc = mp.do_pred.b[0];
+      for (int m = 0; m < M; ++m) acc += mp.do_pred.W[m] * hs.mf[(size_t)b * M + m];
+      if (dopred_out) dopred_out[(size_t)h * B + b] = sigm(acc);
+    }
+    // CrossEntropyCriterion SS:518 + first-max argmax SS:488
+    dlogits_all[h].assign((size_t)B * K, 0);
+    real loss = 0;
+    for (int b = 0; b < B; ++b) {
+      const real* lb = logits.data() + (size_t)b * K;
+      real mx = lb[0];
+      int am = 0;
+      for (int k = 1; k < K; ++k)
+        if (lb[k] > mx) { mx = lb[k]; am = k; }
+      if (argmax) argmax[(size_t)h * B + b] = am + 1;
+      real den = 0;
+      for (int k = 0; k < K; ++k) den += std::exp(lb[k] - mx);
+      const real lse = mx + std::log(den);
+      if (labels) {
+        const int y = labels[b] - 1;
+        loss += lse - lb[y];
+        real* dl = dlogits_all[h].data() + (size_t)b * K;
+        for (int k = 0; k < K; ++k) dl[k] = std::exp(lb[k] - lse) / real(B);
+        dl[y] -= real(1) / real(B);
+      }
+    }
+    if (losses) losses[h] = loss / real(B);
+    if (logits_out)
+      std::memcpy(logits_out + (size_t)h * B * K, logits.data(), sizeof(real) * B * K);
+    if (att_out)
+      std::memcpy(att_out + (size_t)h * B * S, hs.a.data(), sizeof(real) * B * S);
+    if (attc_out)
+      std::memcpy(attc_out + (size_t)h * B * R, hs.c.data(), sizeof(real) * B * R);
+    if (atth_out)
+      std::memcpy(atth_out + (size_t)h * B * R, hs.h.data(), sizeof(real) * B * R);
+    c_hist[h + 1] = hs.c;
+    h_hist[h + 1] = hs.h;
+  }
+  if (!do_bwd) return 0;
+  if (!labels) return -5;
+
+  // ================================================= RAU backward, SS:561-579
+  // d_do_pred is multiplied by 0 (SS:566) and gradattprob is zero (SS:361,573).
+  vec<real> dq((size_t)B * Q, 0);                             // sum over hops, SS:579
+  vec<real> dc_next((size_t)B * R, 0), dh_next((size_t)B * R, 0);  // SS:561-562
+  vec<real> dmf((size_t)B * M), dpre((size_t)B * M), dj((size_t)B * M),
+      dhn((size_t)B * R), dg4((size_t)B * 4 * R), dhp((size_t)B * R),
+      dcp((size_t)B * R), da((size_t)B * S), dz((size_t)B * S), du((size_t)B * A),
+      dqf((size_t)B * M), dqt((size_t)B * M), dqd((size_t)B * Q);
+  for (int h = H - 1; h >= 0; --h) {
+    HopSave<real>& hs = hops[h];
+    const real* hp = h_hist[h].data();
+    const real* cp = c_hist[h].data();
+    vec<real>& dl = dlogits_all[h];
+    for (auto& x : dl) x *= hop_w[h];  // dpred:mul(nHop) SS:569 / MS:568-570 / Full:587-589
+    // cls backward; do_pred contributes zero gradient (SS:566)
+    lin_bwd<real>(mp.cls, B, hs.mf.data(), M, dl.data(), K, dmf.data(), M, false);
+    for (size_t i = 0; i < (size_t)B * M; ++i)
+      dpre[i] = m_mf ? (m_mf[(size_t)h * B * M + i] ? dmf[i] * s_mf : real(0)) : dmf[i];
+    // pre = j + lstm_out(h)
+    dj = dpre;
+    lin_bwd<real>(mp.lstm_out, B, hs.h.data(), R, dpre.data(), M, dhn.data(), R, false);
+    for (size_t i = 0; i < (size_t)B * R; ++i) dhn[i] += dh_next[i];
+    // ATTLSTM backward
+    for (int b = 0; b < B; ++b)
+      for (int r = 0; r < R; ++r) {
+        const size_t o = (size_t)b * R + r;
+        const real tc = hs.tanhc[o], gi = hs.gi[o], gg = hs.gg[o], gf = hs.gf[o],
+                   go = hs.go[o];
+        const real d_o = dhn[o] * tc;
+        const real dc = dc_next[o] + dhn[o] * go * (real(1) - tc * tc);
+        const real df = dc * cp[o], di = dc * gg, dgg = dc * gi;
+        dcp[o] = dc * gf;
+        real* db = dg4.data() + (size_t)b * 4 * R;
+        db[r] = di * gi * (real(1) - gi);
+        db[R + r] = dgg * (real(1) - gg * gg);
+        db[2 * R + r] = df * gf * (real(1) - gf);
+        db[3 * R + r] = d_o * go * (real(1) - go);
+      }
+    lin_bwd<real>(mp.lstm_i2h, B, hs.j.data(), M, dg4.data(), 4 * R, dj.data(), M, true);
+    lin_bwd<real>(mp.lstm_h2h, B, hp, R, dg4.data(), 4 * R, dhp.data(), R, false);
+    // j = qf + v + feat_attprob(a): dqf = dj, dv = dj, da = dj Wf
+    lin_bwd<real>(mp.feat_attprob, B, hs.a.data(), S, dj.data(), M, da.data(), S, false);
+    dqf = dj;
+    // attselect backward: dI = dv (x) a ; da += sum_m dv I
+    vec<real> dI((size_t)B * M * S);
+#pragma omp parallel for schedule(static)
+    for (int b = 0; b < B; ++b) {
+      for (int m = 0; m < M; ++m) {
+        const real dv = dj[(size_t)b * M + m];
+        const real* ir = hs.I.data() + ((size_t)b * M + m) * S;
+        real* dir = dI.data() + ((size_t)b * M + m) * S;
+        for (int s = 0; s < S; ++s) {
+          dir[s] = dv * hs.a[(size_t)b * S + s];
+          da[(size_t)b * S + s] += dv * ir[s];
+        }
+      }
+      // softmax backward: dz = a * (da - sum a*da)
+      real dot = 0;
+      for (int s = 0; s < S; ++s) dot += hs.a[(size_t)b * S + s] * da[(size_t)b * S + s];
+      for (int s = 0; s < S; ++s)
+        dz[(size_t)b * S + s] = hs.a[(size_t)b * S + s] * (da[(size_t)b * S + s] - dot);
+    }
+    // z = e + att_mem(h_prev)
+    lin_bwd<real>(mp.att_mem, B, hp, R, dz.data(), S, dhp.data(), R, true);
+    // attbycontent backward (de = dz)
+    for (auto& x : du) x = 0;
+    {
+      vec<real> dS((size_t)B * A * S);
+      real dbs = 0;
+      for (size_t i = 0; i < (size_t)B * S; ++i) dbs += dz[i];
+      mp.att_score.db[0] += dbs;
+#pragma omp parallel for schedule(static)
+      for (int b = 0; b < B; ++b) {
+        const real* Tb = hs.T.data() + (size_t)b * A * S;
+        real* dSb = dS.data() + (size_t)b * A * S;
+        for (int k = 0; k < A; ++k) {
+          real acc = 0;
+          for (int s = 0; s < S; ++s) {
+            const real t = Tb[(size_t)k * S + s];
+            const real d = dz[(size_t)b * S + s] * mp.att_score.W[k] * (real(1) - t * t);
+            dSb[(size_t)k * S + s] = d;
+            acc += d;
+          }
+          du[(size_t)b * A + k] = acc;
+        }
+        // dI[b,:,s] += Wp^T dS[b,:,s]
+        real* dIb = dI.data() + (size_t)b * M * S;
+        for (int k = 0; k < A; ++k) {
+          const real* w = mp.att_i.W + (size_t)k * M;
+          const real* dr = dSb + (size_t)k * S;
+          for (int m = 0; m < M; ++m) {
+            const real wv = w[m];
+            real* dir = dIb + (size_t)m * S;
+            for (int s = 0; s < S; ++s) dir[s] += wv * dr[s];
+          }
+        }
+      }
+      // parameter grads of att_score / att_i (serial over b for determinism)
+      for (int k = 0; k < A; ++k) {
+        real acc = 0;
+        for (int b = 0; b < B; ++b)
+          for (int s = 0; s < S; ++s)
+            acc += dz[(size_t)b * S + s] * hs.T[((size_t)b * A + k) * S + s];
+        mp.att_score.dW[k] += acc;
+      }
+#pragma omp parallel for schedule(static)
+      for (int k = 0; k < A; ++k) {
+        real bacc = 0;
+        vec<real> wacc(M, 0);
+        for (int b = 0; b < B; ++b) {
+          const real* dr = dS.data() + ((size_t)b * A + k) * S;
+          for (int s = 0; s < S; ++s) bacc += dr[s];
+          for (int m = 0; m < M; ++m) {
+            const real* ir = hs.I.data() + ((size_t)b * M + m) * S;
+            real acc = 0;
+            for (int s = 0; s < S; ++s) acc += dr[s] * ir[s];
+            wacc[m] += acc;
+          }
+        }
+        mp.att_i.db[k] += bacc;
+        for (int m = 0; m < M; ++m) mp.att_i.dW[(size_t)k * M + m] += wacc[m];
+      }
+    }
+    // u = att_q(qf)
+    lin_bwd<real>(mp.att_q, B, hs.qf.data(), M, du.data(), A, dqf.data(), M, true);
+    // i_embed backward: dZ = dI * (1 - I^2); dWi += dZ Xd^T; dX is dead (SS:579)
+    for (size_t i = 0; i < dI.size(); ++i) dI[i] *= (real(1) - hs.I[i] * hs.I[i]);
+#pragma omp parallel for schedule(static)
+    for (int m = 0; m < M; ++m) {
+      real bacc = 0;
+      vec<real> wacc(D, 0);
+      vec<real> xd(S);
+      for (int b = 0; b < B; ++b) {
+        const real* dzr = dI.data() + ((size_t)b * M + m) * S;
+        for (int s = 0; s < S; ++s) bacc += dzr[s];
+        const real* Xb = feats + (size_t)b * D * S;
+        const uint8_t* mb = m_x ? m_x + ((size_t)h * B + b) * D * S : nullptr;
+        for (int d = 0; d < D; ++d) {
+          real acc = 0;
+          const real* xr = Xb + (size_t)d * S;
+          if (mb) {
+            const uint8_t* mr = mb + (size_t)d * S;
+            for (int s = 0; s < S; ++s)
+              if (mr[s]) acc += dzr[s] * (xr[s] * s_x);
+          } else {
+            for (int s = 0; s < S; ++s) acc += dzr[s] * xr[s];
+          }
+          wacc[d] += acc;
+        }
+      }
+      mp.i_embed.db[m] += bacc;
+      for (int d = 0; d < D; ++d) mp.i_embed.dW[(size_t)m * D + d] += wacc[d];
+    }
+    // q_embed backward
+    for (size_t i = 0; i < (size_t)B * M; ++i)
+      dqt[i] = dqf[i] * (real(1) - hs.qf[i] * hs.qf[i]);
+    lin_bwd<real>(mp.q_proj, B, hs.qd.data(), Q, dqt.data(), M, dqd.data(), Q, false);
+    lin_bwd<real>(mp.h_proj, B, hp, R, dqt.data(), M, dhp.data(), R, true);
+    for (size_t i = 0; i < (size_t)B * Q; ++i)
+      dq[i] += m_q ? (m_q[(size_t)h * B * Q + i] ? dqd[i] * s_q : real(0)) : dqd[i];
+    dc_next = dcp;
+    dh_next = dhp;
+  }
+
+  // ============================================== encoder backward, SS:581-596
+  RnnP<real>& r = rp;
+  vec<real> dstate((size_t)B * Q, 0);  // drnn_state[max_len+1] = zeros, SS:581
+  vec<real> dsum((size_t)B * 4 * Rq), dprev((size_t)B * Q), dx2((size_t)B * Rq),
+      dh1((size_t)B * Rq), dwe((size_t)B * E);
+  for (int t = max_len; t >= 1; --t) {
+    TokSave<real>& ts = toks[t];
+    const vec<real>& prev = toks[t - 1].state;
+    // rows with x_len[k]==t are REPLACED by dq[k], SS:584-591
+    for (int b = 0; b < B; ++b)
+      if (lens[b] == t)
+        std::memcpy(&dstate[(size_t)b * Q], &dq[(size_t)b * Q], sizeof(real) * Q);
+    for (auto& x : dprev) x = 0;
+    for (int L = 1; L >= 0; --L) {
+      const real* prev_c = prev.data() + 2 * L * Rq;
+      const real* prev_h = prev.data() + (2 * L + 1) * Rq;
+      for (int b = 0; b < B; ++b)
+        for (int rr = 0; rr < Rq; ++rr) {
+          const size_t o = (size_t)b * Rq + rr;
+          real dc = dstate[(size_t)b * Q + 2 * L * Rq + rr];
+          real dh = dstate[(size_t)b * Q + (2 * L + 1) * Rq + rr];
+          if (L == 0) dh += dh1[o];  // h1 also feeds layer 2 (fan-out sum)
+          const real gi = ts.gi[L][o], gf = ts.gf[L][o], go = ts.go[L][o],
+                     gg = ts.gg[L][o], tc = ts.tanhc[L][o];
+          const real d_o = dh * tc;
+          dc += dh * go * (real(1) - tc * tc);
+          real* ds = dsum.data() + (size_t)b * 4 * Rq;
+          ds[rr] = dc * gg * gi * (real(1) - gi);
+          ds[Rq + rr] = dc * prev_c[(size_t)b * Q + rr] * gf * (real(1) - gf);
+          ds[2 * Rq + rr] = d_o * go * (real(1) - go);
+          ds[3 * Rq + rr] = dc * gi * (real(1) - gg * gg);
+          dprev[(size_t)b * Q + 2 * L * Rq + rr] = dc * gf;
+        }
+      // h2h: d prev_h
+      lin_bwd<real>(r.h2h[L], B, prev_h, Q, dsum.data(), 4 * Rq,
+                    dprev.data() + (2 * L + 1) * Rq, Q, false);
+      if (L == 1) {
+        lin_bwd<real>(r.i2h[1], B, ts.x2.data(), Rq, dsum.data(), 4 * Rq, dx2.data(),
+                      Rq, false);
+        for (int b = 0; b < B; ++b)
+          for (int rr = 0; rr < Rq; ++rr) {
+            const size_t o = (size_t)b * Rq + rr;
+            dh1[o] = m_rnn ? (m_rnn[((size_t)(t - 1) * B + b) * Rq + rr]
+                                  ? dx2[o] * s_rnn
+                                  : real(0))
+                           : dx2[o];
+          }
+      } else {
+        lin_bwd<real>(r.i2h[0], B, ts.we.data(), E, dsum.data(), 4 * Rq, dwe.data(), E,
+                      false);
+      }
+    }
+    // word_embed backward (SS:593): tanh, dropout, LookupTable scatter-add
+    const int32_t* xt = tokens + (size_t)(t - 1) * B;
+    for (int b = 0; b < B; ++b)
+      for (int e = 0; e < E; ++e) {
+        const real y = ts.we[(size_t)b * E + e];
+        real d = dwe[(size_t)b * E + e] * (real(1) - y * y);
+        if (m_we) d = m_we[((size_t)(t - 1) * B + b) * E + e] ? d * s_we : real(0);
+        g_embed[(size_t)(xt[b] - 1) * E + e] += d;
+      }
+    dstate = dprev;
+  }
+  return 0;
+}
+
+// --------------------------------------------------------------- Philox4x32-10
+// Identical constants/round function to rau_vqa_amd/csrc/philox.h.
+inline void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                          uint32_t k0, uint32_t k1, uint32_t out[4]) {
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+    const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+    const uint32_t n1 = (uint32_t)p1;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    const uint32_t n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+template <typename real>
+void noise_clip_adam(size_t n, real* x, real* g, real* m, real* v,
+                     const real* noise, int64_t step_t, int64_t adam_t, real lr,
+                     real beta1, real beta2, real eps, real eta, real gamma,
+                     real clip, real* out_norm) {
+  // SS:598-599: var = eta / ((step_t+1) * gamma)  (gamma multiplies)
+  const real nstd = std::sqrt(eta / (real(step_t + 1) * gamma));
+  double ss = 0;
+  for (size_t i = 0; i < n; ++i) {
+    if (noise) g[i] += noise[i] * nstd;  // SS:600-605
+    ss += (double)g[i] * (double)g[i];
+  }
+  const real norm = (real)std::sqrt(ss);
+  if (out_norm) *out_norm = norm;
+  if (norm > clip) {  // SS:608-629
+    const real sc = clip / norm;
+    for (size_t i = 0; i < n; ++i) g[i] *= sc;
+  }
+  // utils/optim_updates.lua:75-86 (epsilon OUTSIDE the sqrt)
+  const real bc1 = real(1) - std::pow(beta1, real(adam_t));
+  const real bc2 = real(1) - std::pow(beta2, real(adam_t));
+  const real stepsize = lr * std::sqrt(bc2) / bc1;
+  for (size_t i = 0; i < n; ++i) {
+    m[i] = m[i] * beta1 + (real(1) - beta1) * g[i];
+    v[i] = v[i] * beta2 + (real(1) - beta2) * g[i] * g[i];
+    x[i] -= stepsize * m[i] / (std::sqrt(v[i]) + eps);
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t rau_oracle_n_embed(const rau_oracle_cfg* c) { return (size_t)c->V * c->E; }
+size_t rau_oracle_n_rnn(const rau_oracle_cfg* c) {
+  RnnP<float> r(*c, nullptr, nullptr);
+  return r.n;
+}
+size_t rau_oracle_n_mult(const rau_oracle_cfg* c) {
+  MultP<float> m(*c, nullptr, nullptr);
+  return m.n;
+}
+
+#define RAU_ORACLE_DEF(SUF, REAL)                                               \
+  int rau_oracle_step_##SUF(                                                    \
+      const rau_oracle_cfg* cfg, const REAL* embed, const REAL* rnn,            \
+      const REAL* mult, const REAL* feats, const int32_t* tokens,               \
+      const int32_t* lens, const int32_t* labels, const uint8_t* m_we,          \
+      const uint8_t* m_rnn, const uint8_t* m_q, const uint8_t* m_x,             \
+      const uint8_t* m_mf, const REAL* hop_w, REAL* losses, int32_t* argmax,    \
+      REAL* logits, REAL* dopred, REAL* att, REAL* q, REAL* att_c, REAL* att_h, \
+      REAL* g_embed, REAL* g_rnn, REAL* g_mult) {                               \
+    return step<REAL>(*cfg, embed, rnn, mult, feats, tokens, lens, labels,      \
+                      m_we, m_rnn, m_q, m_x, m_mf, hop_w, losses, argmax,       \
+                      logits, dopred, att, q, att_c, att_h, g_embed, g_rnn,     \
+                      g_mult);                                                  \
+  }
+RAU_ORACLE_DEF(f32, float)
+RAU_ORACLE_DEF(f64, double)
+
+// keep-flag for flat element i of site `site` at training step `step`: one
+// Philox call (counter = {i>>4 lo, i>>4 hi, site, step}, key = seed) yields 16
+// bytes, element i uses byte (i & 15) (little-endian within the 4 words); keep iff
+// byte >= round(p*256).  p = 0.5 -> threshold 128 -> exactly P(keep) = 1/2.
+void rau_oracle_fill_mask(uint64_t seed, uint32_t site, uint32_t step, float p,
+                          size_t n, uint8_t* keep) {
+  const uint32_t thr = (uint32_t)std::lround((double)p * 256.0);
+  for (size_t blk = 0; blk * 16 < n; ++blk) {
+    uint32_t o[4];
+    philox4x32_10((uint32_t)blk, (uint32_t)(blk >> 32), site, step, (uint32_t)seed,
+                  (uint32_t)(seed >> 32), o);
+    for (int j = 0; j < 16 && blk * 16 + j < n; ++j) {
+      const uint32_t byte = (o[j >> 2] >> (8 * (j & 3))) & 0xFFu;
+      keep[blk * 16 + j] = byte >= thr ? 1 : 0;
+    }
+  }
+}
+
+#define RAU_ORACLE_UPD_DEF(SUF, REAL)                                           \
+  void rau_oracle_noise_clip_adam_##SUF(                                        \
+      size_t n, REAL* x, REAL* g, REAL* m, REAL* v, const REAL* noise,          \
+      int64_t step_t, int64_t adam_t, REAL lr, REAL beta1, REAL beta2,          \
+      REAL eps, REAL eta, REAL gamma, REAL clip, REAL* out_norm) {              \
+    noise_clip_adam<REAL>(n, x, g, m, v, noise, step_t, adam_t, lr, beta1,      \
+                          beta2, eps, eta, gamma, clip, out_norm);              \
+  }
+RAU_ORACLE_UPD_DEF(f32, float)
+RAU_ORACLE_UPD_DEF(f64, double)
+
+}  // extern "C"

@@ -1,0 +1,180 @@
+"""PyTorch-CPU autograd restatement of the reference graph -- TEST INFRASTRUCTURE ONLY.
+
+Second, independently written restatement of the RAU path, at the module
+granularity of the reference's nngraph (separate dropout / linear / 1x1 conv /
+tanh / add / softmax ... ops, backward by autograd).  Two uses:
+
+* tests/test_oracle_agree.py: cross-validates oracle/rau_cpu.cc (hand-derived
+  backward) in fp64 -- a transcription error in one is caught by the other.
+* bench.py cpu_baseline: "reference graph restated on PyTorch-CPU, N cores"
+  (CPU-A).  Never labelled Torch7.
+
+Reference lines (under /root/reference; SS =
+experiments/Ours_SS/LstmAttCtrlGradNoiseDontSelect.lua):
+  word_embed SS:203-206, DeepLSTM model/DeepLSTM.lua:14-71, q_embed SS:231-236,
+  i_embed SS:238-242, attbycontent SS:244-252, attselect SS:254-263,
+  classifier SS:265-283 (+ model/ATTLSTM.lua:4-74), attbymemory SS:285-290,
+  multimodal SS:292-307, feval SS:428-596.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn.functional as F
+
+
+def _split(flat, specs):
+    """Views into a flat parameter vector: specs = [(name, out, in)], weight then bias."""
+    out, off = {}, 0
+    for name, o, i in specs:
+        out[name + ".W"] = flat[off:off + o * i].view(o, i)
+        off += o * i
+        out[name + ".b"] = flat[off:off + o]
+        off += o
+    assert off == flat.numel(), (off, flat.numel())
+    return out
+
+
+def mult_specs(sh):
+    Q = 4 * sh.Rq
+    return [("q_proj", sh.M, Q), ("h_proj", sh.M, sh.R), ("i_embed", sh.M, sh.D),
+            ("att_q", sh.A, sh.M), ("att_i", sh.A, sh.M), ("att_score", 1, sh.A),
+            ("att_mem", sh.S, sh.R), ("feat_attprob", sh.M, sh.S),
+            ("lstm_i2h", 4 * sh.R, sh.M), ("lstm_h2h", 4 * sh.R, sh.R),
+            ("lstm_out", sh.M, sh.R), ("cls", sh.K, sh.M), ("do_pred", 1, sh.M)]
+
+
+def rnn_specs(sh):
+    return [("l1_i2h", 4 * sh.Rq, sh.E), ("l1_h2h", 4 * sh.Rq, sh.Rq),
+            ("l2_i2h", 4 * sh.Rq, sh.Rq), ("l2_h2h", 4 * sh.Rq, sh.Rq)]
+
+
+def _drop(x, mask, p):
+    """nn.Dropout v2 with an explicit keep mask (None = evaluate mode)."""
+    if mask is None:
+        return x
+    return x * (mask.to(x.dtype) / (1.0 - p))
+
+
+def deep_lstm(sh, P, x, state, mask_mid):
+    """model/DeepLSTM.lua:14-71.  state = [c1 h1 c2 h2] packed on dim 1."""
+    Rq = sh.Rq
+    outs = []
+    inp = x
+    for L in range(2):
+        prev_c = state[:, 2 * L * Rq:(2 * L + 1) * Rq]
+        prev_h = state[:, (2 * L + 1) * Rq:(2 * L + 2) * Rq]
+        if L == 1:
+            inp = _drop(outs[1], mask_mid, sh.p_rnn)
+        n = "l%d" % (L + 1)
+        sums = F.linear(inp, P[n + "_i2h.W"], P[n + "_i2h.b"]) + \
+            F.linear(prev_h, P[n + "_h2h.W"], P[n + "_h2h.b"])
+        sig = torch.sigmoid(sums[:, :3 * Rq])
+        in_gate, forget_gate, out_gate = sig[:, :Rq], sig[:, Rq:2 * Rq], sig[:, 2 * Rq:]
+        in_transform = torch.tanh(sums[:, 3 * Rq:])
+        next_c = forget_gate * prev_c + in_gate * in_transform
+        next_h = out_gate * torch.tanh(next_c)
+        outs += [next_c, next_h]
+    return torch.cat(outs, 1)
+
+
+def att_lstm(sh, P, x, prev_c, prev_h):
+    """model/ATTLSTM.lua:4-28 with one layer and dropout 0."""
+    R = sh.R
+    gates = F.linear(x, P["lstm_i2h.W"], P["lstm_i2h.b"]) + \
+        F.linear(prev_h, P["lstm_h2h.W"], P["lstm_h2h.b"])
+    g = gates.view(-1, 4, R)
+    in_gate = torch.sigmoid(g[:, 0])
+    in_transform = torch.tanh(g[:, 1])
+    forget_gate = torch.sigmoid(g[:, 2])
+    out_gate = torch.sigmoid(g[:, 3])
+    next_c = forget_gate * prev_c + in_gate * in_transform
+    next_h = out_gate * torch.tanh(next_c)
+    return next_c, next_h
+
+
+def multimodal(sh, P, q, feats4d, prev_c, prev_h, mq, mx, mmf):
+    """SS:292-307: returns (logits, do_pred, attprob, next_c, next_h)."""
+    B = q.shape[0]
+    # q_embed
+    qf = torch.tanh(F.linear(_drop(q, mq, sh.p_q), P["q_proj.W"], P["q_proj.b"]) +
+                    F.linear(prev_h, P["h_proj.W"], P["h_proj.b"]))
+    # i_embed: Dropout -> 1x1 conv -> Tanh -> Reshape(M, S)
+    xi = _drop(feats4d, mx, sh.p_x)
+    ifeat = torch.tanh(F.conv2d(xi, P["i_embed.W"].view(sh.M, sh.D, 1, 1), P["i_embed.b"]))
+    ifeat = ifeat.reshape(B, sh.M, sh.S)
+    # attbycontent
+    qatt = F.linear(qf, P["att_q.W"], P["att_q.b"]).unsqueeze(2).expand(B, sh.A, sh.S)
+    iproj = F.conv2d(ifeat.reshape(B, sh.M, sh.S, 1), P["att_i.W"].view(sh.A, sh.M, 1, 1),
+                     P["att_i.b"]).reshape(B, sh.A, sh.S)
+    addfeat = torch.tanh(iproj + qatt).reshape(B, sh.A, sh.S, 1)
+    attscore = F.conv2d(addfeat, P["att_score.W"].view(1, sh.A, 1, 1),
+                        P["att_score.b"]).reshape(B, sh.S)
+    # attbymemory
+    attprob = torch.softmax(attscore + F.linear(prev_h, P["att_mem.W"], P["att_mem.b"]), dim=1)
+    # attselect
+    attfeat = (ifeat * attprob.unsqueeze(1).expand(B, sh.M, sh.S)).sum(2)
+    # classifier
+    join_input = (qf + attfeat) + F.linear(attprob, P["feat_attprob.W"], P["feat_attprob.b"])
+    next_c, next_h = att_lstm(sh, P, join_input, prev_c, prev_h)
+    merge = _drop(join_input + F.linear(next_h, P["lstm_out.W"], P["lstm_out.b"]), mmf, sh.p_mf)
+    score = F.linear(merge, P["cls.W"], P["cls.b"])
+    do_pred = torch.sigmoid(F.linear(merge, P["do_pred.W"], P["do_pred.b"])).sum(1)
+    return score, do_pred, attprob, next_c, next_h
+
+
+def step(sh, params, feats, tokens, lens, labels, masks=None, hop_w=None,
+         backward=True, dtype=torch.float64):
+    """One feval forward(+backward), SS:428-596.  Same I/O convention as oracle.step."""
+    t = lambda a: torch.as_tensor(a).to(dtype)
+    flat = {k: t(params[k]).clone().requires_grad_(backward) for k in ("embed", "rnn", "mult")}
+    Emb = flat["embed"].view(sh.V, sh.E)
+    Pr = _split(flat["rnn"], rnn_specs(sh))
+    Pm = _split(flat["mult"], mult_specs(sh))
+    feats4d = t(feats).reshape(sh.B, sh.D, sh.S, 1)
+    tokens = torch.as_tensor(tokens).long()
+    lens = torch.as_tensor(lens).long()
+    mk = lambda k: None if (masks is None or masks.get(k) is None) else torch.as_tensor(masks[k])
+    m_we, m_rnn, m_q, m_x, m_mf = mk("we"), mk("rnn"), mk("q"), mk("x"), mk("mf")
+    if hop_w is None:
+        hop_w = [float(sh.H)] * sh.H
+    B, Q = sh.B, 4 * sh.Rq
+    # encoder
+    max_len = int(lens.max())
+    state = torch.zeros(B, Q, dtype=dtype)
+    q = torch.zeros(B, Q, dtype=dtype)
+    for tt in range(1, max_len + 1):
+        we = torch.tanh(_drop(Emb[tokens[tt - 1] - 1], None if m_we is None else m_we[tt - 1], sh.p_we))
+        state = deep_lstm(sh, Pr, we, state, None if m_rnn is None else m_rnn[tt - 1])
+        sel = (lens == tt).unsqueeze(1)
+        q = torch.where(sel, state, q)
+    # hops
+    c = torch.zeros(B, sh.R, dtype=dtype)
+    h = torch.zeros(B, sh.R, dtype=dtype)
+    out = {"losses": [], "argmax": [], "logits": [], "dopred": [], "att": [],
+           "att_c": [], "att_h": []}
+    total = 0.0
+    y = None if labels is None else torch.as_tensor(labels).long() - 1
+    for hop in range(sh.H):
+        score, dp, a, c, h = multimodal(
+            sh, Pm, q, feats4d, c, h,
+            None if m_q is None else m_q[hop],
+            None if m_x is None else m_x[hop].reshape(sh.B, sh.D, sh.S, 1),
+            None if m_mf is None else m_mf[hop])
+        out["logits"].append(score.detach())
+        out["dopred"].append(dp.detach())
+        out["att"].append(a.detach())
+        out["att_c"].append(c.detach())
+        out["att_h"].append(h.detach())
+        out["argmax"].append(torch.argmax(score.detach(), dim=1) + 1)
+        if y is not None:
+            loss = F.cross_entropy(score, y)           # CrossEntropyCriterion, SS:518
+            out["losses"].append(loss.detach())
+            total = total + float(hop_w[hop]) * loss   # dpred:mul(w), SS:569
+    res = {k: torch.stack(v).numpy() for k, v in out.items() if v}
+    res["q"] = q.detach().numpy()
+    if backward:
+        total.backward()
+        res["g_embed"] = flat["embed"].grad.numpy()
+        res["g_rnn"] = flat["rnn"].grad.numpy()
+        res["g_mult"] = flat["mult"].grad.numpy()
+    return res
