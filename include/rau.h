@@ -1,0 +1,200 @@
+/*
+ * rau.h -- C ABI of librau.so: the MI355X-native Recurrent Answering Unit
+ * forward/backward (hand-written HIP for gfx950 behind plain pointers).
+ *
+ * This is the drop-in boundary for ONE path of HyeonwooNoh/RAU_VQA: the tensor
+ * half of `feval` (reference experiments/Ours_SS/LstmAttCtrlGradNoiseDontSelect.lua
+ * :428-596, "SS" below) plus the network it drives (SS:198-316,
+ * model/ATTLSTM.lua, model/DeepLSTM.lua).  The reference reaches that path
+ * through the Torch7 nn.Module protocol, not through an FFI of its own, so each
+ * entry point below cites the nn.Module call sites it replaces.  A LuaJIT
+ * `ffi.cdef` shim that re-presents these calls as :forward/:backward/
+ * :getParameters objects is in bindings/rau.lua; INTEGRATION.md shows the
+ * reference-side patch.
+ *
+ * Conventions
+ *  - every function returns 0 on success or a negative rau_status; the message
+ *    for the calling thread's last failure is rau_last_error().  Nothing throws
+ *    or longjmps across the boundary (Lua `error()` is raised by the shim).
+ *  - no global state: everything hangs off an opaque rau_ctx (one per GPU,
+ *    driven by one host thread at a time -- same rule as a Lua state).
+ *  - the ctx owns all device memory.  Host pointers passed in are owned by the
+ *    caller and are consumed before the call returns unless stated otherwise.
+ *  - all work is enqueued on the ctx's HIP stream; host-visible results are
+ *    valid after rau_sync() (or any call documented as synchronising).
+ *  - ids are 1-based like the reference's Lua tensors: token ids 1..V with
+ *    1 = ZEROPAD (utils/vqa_prepro_loader.lua:1393), answer ids 1..K, and the
+ *    returned argmax ids are 1..K with torch.max's first-max tie rule (SS:488).
+ *  - there is NO CPU fallback: rau_create fails if no gfx950 device is usable.
+ */
+#ifndef RAU_H
+#define RAU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RAU_ABI_VERSION 1
+
+typedef enum rau_status {
+  RAU_OK = 0,
+  RAU_ERR_INVALID = -1,   /* bad argument / shape / id out of range */
+  RAU_ERR_DEVICE = -2,    /* HIP error, no device, wrong architecture */
+  RAU_ERR_STATE = -3,     /* call order (e.g. backward before forward) */
+  RAU_ERR_NOMEM = -4
+} rau_status;
+
+typedef enum rau_group {   /* flat parameter groups, SS:322-324 getParameters() */
+  RAU_GROUP_EMBED = 0,     /* protos.word_embed */
+  RAU_GROUP_RNN = 1,       /* protos.rnn  (DeepLSTM) */
+  RAU_GROUP_MULT = 2       /* protos.multimodal */
+} rau_group;
+
+typedef enum rau_mode {    /* m:training() / m:evaluate(), SS:449-450,479,648-649,676 */
+  RAU_MODE_TRAIN = 0,
+  RAU_MODE_EVAL = 1
+} rau_mode;
+
+typedef enum rau_mask_site {   /* the five nn.Dropout sites on the path */
+  RAU_MASK_WE = 0,   /* [T,B,E]   word_embed Dropout(0.5), SS:205 */
+  RAU_MASK_RNN = 1,  /* [T,B,Rq]  DeepLSTM inter-layer dropout, DeepLSTM.lua:39 */
+  RAU_MASK_Q = 2,    /* [H,B,Q]   q_embed Dropout(0.5), SS:233 */
+  RAU_MASK_X = 3,    /* [H,B,D,S] i_embed Dropout(0.5) on the feature map, SS:239 */
+  RAU_MASK_MF = 4    /* [H,B,M]   classifier merge_feat Dropout(0.5), SS:277 */
+} rau_mask_site;
+
+typedef enum rau_dtype {
+  RAU_F32 = 0        /* f32 operands, f32 MFMA accumulate (exact fmaf chain) */
+} rau_dtype;
+
+/* Network hyper-parameters: the hard-coded locals of SS:202,209-229 plus the
+ * data-defined sizes.  Q (question state width) is 4*Rq: 2 layers x {c,h}. */
+typedef struct rau_config {
+  int32_t B;    /* batch size per GPU (opt.batch_size) */
+  int32_t T;    /* seq_len: rows of the token matrix x[T,B] */
+  int32_t V;    /* vocab_size incl. ZEROPAD */
+  int32_t E;    /* embed_dim = 200, SS:202 */
+  int32_t Rq;   /* rnn_size = 512, SS:209 (nrnn_layer fixed at 2, SS:210) */
+  int32_t D;    /* cnnout_dim 512 | 2048, SS:216 */
+  int32_t S;    /* cnnout_w*cnnout_h = 196, SS:219 (must be a multiple of 4) */
+  int32_t M;    /* multfeat_dim = 512, SS:220 */
+  int32_t A;    /* attfeat_dim = 256, SS:221 */
+  int32_t R;    /* att_rnn_size = 512, SS:225 (1 layer, dropout 0) */
+  int32_t K;    /* answer_size = 1000, SS:222 */
+  int32_t H;    /* nHop */
+  float p_we, p_rnn, p_q, p_x, p_mf;  /* dropout probabilities, 0.5 each */
+  int32_t dtype;      /* rau_dtype */
+  int32_t device_id;  /* HIP device ordinal (opt.gpuid) */
+} rau_config;
+
+typedef struct rau_ctx rau_ctx;
+
+/* Fills *cfg with the reference's defaults (Ours_SS, 14x14x512, nhop 8). */
+void rau_default_config(rau_config* cfg);
+
+const char* rau_last_error(void);
+int rau_abi_version(void);
+
+/* Builds the three protos + their clones (SS:200-347): allocates parameters,
+ * gradients, activations for T tokens and H hops, and the ctx stream. */
+int rau_create(const rau_config* cfg, rau_ctx** out);
+void rau_destroy(rau_ctx* ctx);
+
+/* ---- parameters: m:getParameters(), SS:322-324 ------------------------------
+ * Flat DEVICE buffers (weights, gradients) of a group and its length in floats.
+ * Layout: rau_layout_entry() lists each tensor; weight [out,in] then bias [out]
+ * per layer (DESIGN.md section "Flat parameter layout"). */
+int rau_params(rau_ctx* ctx, int group, float** weights, float** grads, size_t* n);
+int rau_layout_count(const rau_ctx* ctx, int group);
+int rau_layout_entry(const rau_ctx* ctx, int group, int index, const char** name,
+                     size_t* offset, int32_t* rows, int32_t* cols);
+/* host <-> device copies of a whole group (synchronising) */
+int rau_set_params(rau_ctx* ctx, int group, const float* host, size_t n);
+int rau_get_params(rau_ctx* ctx, int group, float* host, size_t n);
+int rau_get_grads(rau_ctx* ctx, int group, float* host, size_t n);
+int rau_set_grads(rau_ctx* ctx, int group, const float* host, size_t n);
+/* param:uniform(lo,hi) on each flat vector, SS:352-354 (Philox, not Torch's MT) */
+int rau_init_uniform(rau_ctx* ctx, uint64_t seed, float lo, float hi);
+/* embed_grad:zero() rnn_grad:zero() mult_grad:zero(), SS:429-431 */
+int rau_zero_grads(rau_ctx* ctx);
+
+/* ---- mode and dropout --------------------------------------------------------
+ * :training()/:evaluate() on every clone.  In TRAIN mode the five dropout sites
+ * draw masks either from explicit keep flags (rau_set_mask, parity tests) or
+ * from the Philox4x32-10 stream keyed by (seed, site, step) (rau_set_dropout_seed;
+ * regenerated on device inside rau_forward). */
+int rau_set_mode(rau_ctx* ctx, int mode);
+int rau_set_dropout_seed(rau_ctx* ctx, uint64_t seed, uint32_t step);
+/* keep: uint8 0/1 flags for the whole site in the shape listed at rau_mask_site;
+ * n = element count.  Switches that site to explicit masks until
+ * rau_set_dropout_seed is called again. */
+int rau_set_mask(rau_ctx* ctx, int site, const uint8_t* keep, size_t n);
+/* reads back the keep flags the next/last forward uses (tests; synchronising) */
+int rau_get_mask(rau_ctx* ctx, int site, uint8_t* keep, size_t n);
+
+/* ---- batch: what next_batch_feat returns + the H2D of SS:434-439 -------------
+ * feats [B,D,S] float (NCHW with W*H flattened), tokens [T,B] int32, lens [B]
+ * int32 (0..T), labels [B] int32 (1..K) or NULL for inference.  Copies to the
+ * ctx's device buffers; also builds the per-token position index that makes
+ * the LookupTable gradient a deterministic gather-sum. */
+int rau_set_batch(rau_ctx* ctx, const float* feats, const int32_t* tokens,
+                  const int32_t* lens, const int32_t* labels);
+/* device pointer of the resident feature buffer (producer may write it directly) */
+int rau_batch_feats(rau_ctx* ctx, float** feats_dev);
+
+/* ---- the hot path ------------------------------------------------------------
+ * rau_forward : SS:443-520  encoder unroll, length select, H-hop RAU, per-hop
+ *               CrossEntropyCriterion forward, first-max argmax.
+ * rau_backward: SS:561-596  per-hop criterion backward scaled by hop_w[h]
+ *               (SS:569 nHop / MS:568-570 one / Full:587-589 0|1), RAU BPTT,
+ *               d_do_pred*0 and gradattprob=0, dq=sum over hops, encoder BPTT,
+ *               LookupTable scatter.  Gradients ACCUMULATE into the flat grad
+ *               buffers like accGradParameters; call rau_zero_grads first. */
+int rau_forward(rau_ctx* ctx);
+int rau_backward(rau_ctx* ctx, const float* hop_w /* [H] host */);
+
+/* ---- results (valid after rau_sync; these calls synchronise themselves) ------ */
+int rau_sync(rau_ctx* ctx);
+int rau_get_losses(rau_ctx* ctx, float* losses /* [H] */);
+int rau_get_argmax(rau_ctx* ctx, int32_t* ans /* [H,B] 1-based */);
+int rau_get_logits(rau_ctx* ctx, float* logits /* [H,B,K] */);
+int rau_get_dopred(rau_ctx* ctx, float* dopred /* [H,B] */);
+int rau_get_attention(rau_ctx* ctx, float* att /* [H,B,S] */);
+int rau_get_question_state(rau_ctx* ctx, float* q /* [B,Q] */);
+int rau_get_att_state(rau_ctx* ctx, float* c /* [H,B,R] */, float* h /* [H,B,R] */);
+
+/* ---- update: SS:597-630 + utils/optim_updates.lua:59-87 (row "next-1") -------
+ * Gradient noise N(0, eta/((step_t+1)*gamma)), per-group L2 clip, Adam with
+ * epsilon outside the sqrt; lr applies to EMBED and RNN, mult_lr to MULT
+ * (SS:770-772).  noise_seed keys the on-device normal generator; eta = 0
+ * disables noise.  out_norms[3] (host, may be NULL) receives pre-clip norms. */
+int rau_noise_clip_adam(rau_ctx* ctx, int64_t step_t, float lr, float mult_lr,
+                        float beta1, float beta2, float eps, float eta,
+                        float gamma, float clip, uint64_t noise_seed,
+                        float* out_norms);
+
+/* ---- timing / interop ---------------------------------------------------------
+ * The ctx's hipStream_t (as void*) so a host can order its own work (e.g. an
+ * RCCL all-reduce of the flat grad buffers issued through torch.distributed)
+ * after the ctx's kernels without a device-wide sync. */
+int rau_stream(rau_ctx* ctx, void** hip_stream);
+/* HIP-event bracket on the ctx stream: kernel time of everything enqueued
+ * between begin and end, in milliseconds (end synchronises). */
+int rau_timer_begin(rau_ctx* ctx);
+int rau_timer_end(rau_ctx* ctx, float* ms);
+/* Average duration (ms) and launch count of the named kernel class since the
+ * last rau_prof_reset, measured with HIP events on the ctx stream when
+ * profiling is enabled (adds two events per launch; off by default). */
+int rau_prof_enable(rau_ctx* ctx, int on);
+int rau_prof_reset(rau_ctx* ctx);
+int rau_prof_count(rau_ctx* ctx);
+int rau_prof_entry(rau_ctx* ctx, int index, const char** name, int64_t* launches,
+                   double* total_ms, double* flops, double* bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RAU_H */

@@ -27,7 +27,7 @@ using vec = std::vector<real>;
 template <typename real>
 void gemm_nt(int M, int N, int K, const real* A, int lda, const real* B, int ldb,
              real* C, int ldc, bool acc) {
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if ((double)M * N * K > 2e5)
   for (int m = 0; m < M; ++m) {
     const real* a = A + (size_t)m * lda;
     real* c = C + (size_t)m * ldc;
@@ -43,7 +43,7 @@ void gemm_nt(int M, int N, int K, const real* A, int lda, const real* B, int ldb
 template <typename real>
 void gemm_nn(int M, int N, int K, const real* A, int lda, const real* B, int ldb,
              real* C, int ldc, bool acc) {
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if ((double)M * N * K > 2e5)
   for (int m = 0; m < M; ++m) {
     real* c = C + (size_t)m * ldc;
     if (!acc)
@@ -60,7 +60,7 @@ void gemm_nn(int M, int N, int K, const real* A, int lda, const real* B, int ldb
 template <typename real>
 void gemm_tn_acc(int M, int N, int K, const real* A, int lda, const real* B,
                  int ldb, real* C, int ldc) {
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if ((double)M * N * K > 2e5)
   for (int m = 0; m < M; ++m) {
     real* c = C + (size_t)m * ldc;
     for (int k = 0; k < K; ++k) {
@@ -196,6 +196,7 @@ int step(const rau_oracle_cfg& c, const real* embed, const real* rnn,
   const int B = c.B, T = c.T, E = c.E, Rq = c.Rq, D = c.D, S = c.S, M = c.M,
             A = c.A, R = c.R, K = c.K, H = c.H;
   const int Q = 4 * Rq;
+  const bool big = (double)B * S * M * (D + A) > 2e6;  // worth an OpenMP team
   const bool do_bwd = g_embed || g_rnn || g_mult;
   if (do_bwd && !(g_embed && g_rnn && g_mult)) return -1;
   for (int b = 0; b < B; ++b) {
@@ -306,7 +307,7 @@ int step(const rau_oracle_cfg& c, const real* embed, const real* rnn,
     for (auto& x : hs.qf) x = std::tanh(x);
     // i_embed, SS:238-242: I[b,m,s] = tanh(sum_d Wi[m,d] * drop(X)[b,d,s] + bi[m])
     hs.I.assign((size_t)B * M * S, 0);
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (big)
     for (int b = 0; b < B; ++b) {
       real* Ib = hs.I.data() + (size_t)b * M * S;
       const real* Xb = feats + (size_t)b * D * S;
@@ -329,7 +330,7 @@ int step(const rau_oracle_cfg& c, const real* embed, const real* rnn,
     lin_fwd<real>(mp.att_q, B, hs.qf.data(), M, u.data(), A, false);
     hs.T.assign((size_t)B * A * S, 0);
     vec<real> e((size_t)B * S);
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (big)
     for (int b = 0; b < B; ++b) {
       const real* Ib = hs.I.data() + (size_t)b * M * S;
       real* Tb = hs.T.data() + (size_t)b * A * S;
@@ -493,7 +494,7 @@ int step(const rau_oracle_cfg& c, const real* embed, const real* rnn,
     dqf = dj;
     // attselect backward: dI = dv (x) a ; da += sum_m dv I
     vec<real> dI((size_t)B * M * S);
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (big)
     for (int b = 0; b < B; ++b) {
       for (int m = 0; m < M; ++m) {
         const real dv = dj[(size_t)b * M + m];
@@ -519,7 +520,7 @@ int step(const rau_oracle_cfg& c, const real* embed, const real* rnn,
       real dbs = 0;
       for (size_t i = 0; i < (size_t)B * S; ++i) dbs += dz[i];
       mp.att_score.db[0] += dbs;
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (big)
       for (int b = 0; b < B; ++b) {
         const real* Tb = hs.T.data() + (size_t)b * A * S;
         real* dSb = dS.data() + (size_t)b * A * S;
@@ -553,7 +554,7 @@ int step(const rau_oracle_cfg& c, const real* embed, const real* rnn,
             acc += dz[(size_t)b * S + s] * hs.T[((size_t)b * A + k) * S + s];
         mp.att_score.dW[k] += acc;
       }
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (big)
       for (int k = 0; k < A; ++k) {
         real bacc = 0;
         vec<real> wacc(M, 0);
@@ -575,7 +576,7 @@ int step(const rau_oracle_cfg& c, const real* embed, const real* rnn,
     lin_bwd<real>(mp.att_q, B, hs.qf.data(), M, du.data(), A, dqf.data(), M, true);
     // i_embed backward: dZ = dI * (1 - I^2); dWi += dZ Xd^T; dX is dead (SS:579)
     for (size_t i = 0; i < dI.size(); ++i) dI[i] *= (real(1) - hs.I[i] * hs.I[i]);
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (big)
     for (int m = 0; m < M; ++m) {
       real bacc = 0;
       vec<real> wacc(D, 0);

@@ -1,0 +1,42 @@
+// common.h -- shared device/host helpers for librau.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace rau {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kWave = 64;  // CDNA wavefront width
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// Dropout keep-bit of flat element `e` of a bit-packed mask (bit e&31 of word e>>5).
+__device__ __forceinline__ uint32_t mask_bit(const uint32_t* __restrict__ bits, size_t e) {
+  return (bits[e >> 5] >> (e & 31)) & 1u;
+}
+// Four keep bits of elements e..e+3 (e % 4 == 0), in bits 0..3.
+__device__ __forceinline__ uint32_t mask_nib(const uint32_t* __restrict__ bits, size_t e) {
+  return (bits[e >> 5] >> (e & 31)) & 0xFu;
+}
+
+// XCD-aware remap of a linear workgroup id: blocks id and id+8 share an XCD, so
+// give each XCD a contiguous chunk of the logical grid (bijective for any nwg).
+__device__ __forceinline__ int xcd_remap(int id, int nwg) {
+  const int xcd = id & 7, q = nwg >> 3, r = nwg & 7;
+  const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + (id >> 3);
+}
+
+}  // namespace rau

@@ -1,0 +1,478 @@
+// gemm_core.h -- f32-MFMA GEMM engine for gfx950 (v_mfma_f32_32x32x2_f32).
+//
+// One workgroup = 256 threads = 4 waves (2x2) computes a BM x BN tile of
+//   C[m,n] = sum_k A(m,k) * B(k,n)
+// Operands are staged global -> registers -> LDS as k-major tiles
+// As[BK][BM+pad], Bs[BK][BN+pad] (double buffered, one barrier per K-step),
+// so every MFMA fragment read is a conflict-free ds_read_b32 (lane l reads
+// row k = l>>5, column l&31).  f32 MFMA runs at 256 FLOP/clk/CU, i.e. one
+// 32x32x2 MFMA per 64 cycles per SIMD, so LDS bandwidth is never the limit
+// here; the tile shape is chosen for HBM/L2 intensity instead.
+//
+// "Loader" classes define how A / B elements are produced (plain, dropout-
+// masked, or computed on the fly), "Epilogue" classes define what happens to
+// the accumulators.  Numerics: exact f32 (bitwise a k-ordered fmaf chain).
+#pragma once
+#include "common.h"
+
+namespace rau {
+
+constexpr int BK = 16;    // K-step per LDS stage
+constexpr int LPAD = 4;   // row padding (floats): keeps 16-B alignment
+
+// Superset of the arguments any loader/epilogue combination needs.
+struct GemmParams {
+  int M, N, K;          // output rows / cols, reduction length (per sample in SC mode)
+  int nk;               // number of BK-steps in the whole reduction
+  int nk_per_split;     // BK-steps handled by one blockIdx.z
+  int tiles_m, tiles_n;
+  // A operand
+  const float* A; long a_rs; long a_bs;
+  // B operand
+  const float* B; long b_rs; long b_bs;
+  // flattened (sample, position) column space: n -> (n / S, n % S)
+  int S;
+  int cps;              // BK-chunks per sample (SC loaders)
+  // dropout mask applied by a masked loader
+  const uint32_t* mask; float mscale; size_t mask_e0;
+  // dS-on-the-fly loader: dS[b,k,s] = dz[b,s] * ws[k] * (1 - T[b,k,s]^2)
+  const float* dz; const float* ws;
+  // epilogue
+  float* C; long c_rs; long c_bs; long slab_stride;
+  const float* bias; const float* bias2;
+  const float* addend; long add_rs;
+  const float* ymul; long y_rs;       // multiply by (1 - y^2)
+  const uint32_t* emask; size_t emask_e0; float emscale;
+  int accumulate; int act;            // act: 0 none, 1 tanh
+  float alpha;
+  // conv epilogue extras
+  const float* u;      // [B, A]        (attention score epilogue)
+  const float* v1;     // ws / dj
+  const float* v2;     // a
+  const float* I;      // saved I
+  float* out2;         // e_part
+};
+
+// ---------------------------------------------------------------- loaders
+// Every loader: init(...), load(step) global->regs, store(lds) regs->LDS tile
+// [BK][BT+LPAD].
+
+// Operand stored [rows][K], K contiguous.
+template <int BT>
+struct LoadKC {
+  static constexpr int NI = BT * 4 / 256;
+  const float* p[NI];
+  bool ok[NI];
+  float4 v[NI];
+  int kc, K;
+  __device__ __forceinline__ void init(const float* base, long rs, int row0, int rows,
+                                       int K_, int tid) {
+    K = K_;
+    kc = (tid & 3) * 4;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int r = (tid + i * 256) >> 2;
+      ok[i] = row0 + r < rows;
+      p[i] = base + (long)(row0 + r) * rs + kc;
+    }
+  }
+  __device__ __forceinline__ void load(int step) {
+    const int k0 = step * BK;
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+      v[i] = (ok[i] && k0 + kc < K) ? *reinterpret_cast<const float4*>(p[i] + k0)
+                                    : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  __device__ __forceinline__ void store(float* lds, int tid) const {
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int r = (tid + i * 256) >> 2;
+      float* d = lds + kc * (BT + LPAD) + r;
+      d[0] = v[i].x;
+      d[BT + LPAD] = v[i].y;
+      d[2 * (BT + LPAD)] = v[i].z;
+      d[3 * (BT + LPAD)] = v[i].w;
+    }
+  }
+};
+
+// Operand stored [K][cols], cols contiguous.  FLAT: cols are a flattened
+// (sample, position) index, element (k, n) at base + (n/S)*bs + k*rs + n%S.
+// KIND: 0 plain, 1 dropout-masked (bit index = element offset from base),
+//       2 dS on the fly from T (base = T), dz[n], ws[k].
+template <int BT, bool FLAT, int KIND>
+struct LoadRC {
+  static constexpr int CPR = BT / 4;
+  static constexpr int RPP = 256 / CPR;
+  static constexpr int NI = BK / RPP;
+  const float* p;
+  long rs;
+  size_t eoff;
+  bool ok;
+  int kr, c4, K;
+  float4 v[NI];
+  const uint32_t* mask;
+  float mscale;
+  const float* ws;
+  float4 dzv;
+  __device__ __forceinline__ void init(const GemmParams& P, const float* base, long rs_,
+                                       long bs, int col0, int cols, int tid) {
+    K = P.K;
+    rs = rs_;
+    c4 = (tid % CPR) * 4;
+    kr = tid / CPR;
+    const int col = col0 + c4;
+    ok = col < cols;
+    long off = col;
+    if (FLAT) off = (long)(col / P.S) * bs + (col % P.S);
+    if (!ok) off = 0;
+    p = base + off;
+    eoff = (size_t)off;
+    if (KIND == 1) { mask = P.mask; mscale = P.mscale; eoff += P.mask_e0; }
+    if (KIND == 2) {
+      ws = P.ws;
+      dzv = ok ? *reinterpret_cast<const float4*>(P.dz + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+  __device__ __forceinline__ void load(int step) {
+    const int k0 = step * BK;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int k = k0 + kr + i * RPP;
+      float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (ok && k < K) {
+        x = *reinterpret_cast<const float4*>(p + (long)k * rs);
+        if (KIND == 1) {
+          const uint32_t nib = mask_nib(mask, eoff + (size_t)k * rs);
+          x.x = (nib & 1u) ? x.x * mscale : 0.f;
+          x.y = (nib & 2u) ? x.y * mscale : 0.f;
+          x.z = (nib & 4u) ? x.z * mscale : 0.f;
+          x.w = (nib & 8u) ? x.w * mscale : 0.f;
+        }
+        if (KIND == 2) {
+          const float w = ws[k];
+          x.x = dzv.x * w * (1.f - x.x * x.x);
+          x.y = dzv.y * w * (1.f - x.y * x.y);
+          x.z = dzv.z * w * (1.f - x.z * x.z);
+          x.w = dzv.w * w * (1.f - x.w * x.w);
+        }
+      }
+      v[i] = x;
+    }
+  }
+  __device__ __forceinline__ void store(float* lds, int tid) const {
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+      *reinterpret_cast<float4*>(lds + (kr + i * RPP) * (BT + LPAD) + c4) = v[i];
+  }
+};
+
+// "Sample-chunk" loader for weight gradients of the 1x1 convolutions: operand
+// stored [sample][rows][S], reduction over (sample, position); step g covers
+// positions [16*(g % cps), +16) of sample g / cps, zero-filled past S.
+// KIND as in LoadRC (mask bit index = element offset; 2 = dS from T).
+template <int BT, int KIND>
+struct LoadSC {
+  static constexpr int NI = BT * 4 / 256;
+  long roff[NI];
+  bool ok[NI];
+  float wsr[NI];
+  float4 v[NI];
+  const float* base;
+  long bs;
+  int kc, S, cps;
+  const uint32_t* mask;
+  float mscale;
+  size_t me0;
+  const float* dz;
+  __device__ __forceinline__ void init(const GemmParams& P, const float* base_, long bs_,
+                                       int row0, int rows, int tid) {
+    base = base_;
+    bs = bs_;
+    S = P.S;
+    cps = P.cps;
+    kc = (tid & 3) * 4;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int r = (tid + i * 256) >> 2;
+      ok[i] = row0 + r < rows;
+      roff[i] = (long)(row0 + r) * S + kc;
+      if (KIND == 2) wsr[i] = ok[i] ? P.ws[row0 + r] : 0.f;
+    }
+    if (KIND == 1) { mask = P.mask; mscale = P.mscale; me0 = P.mask_e0; }
+    if (KIND == 2) dz = P.dz;
+  }
+  __device__ __forceinline__ void load(int g) {
+    const int b = g / cps;
+    const int s0 = (g - b * cps) * BK;
+    const bool kin = s0 + kc < S;
+    float4 dzv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (KIND == 2 && kin) dzv = *reinterpret_cast<const float4*>(dz + (long)b * S + s0 + kc);
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (ok[i] && kin) {
+        const long e = (long)b * bs + roff[i] + s0;
+        x = *reinterpret_cast<const float4*>(base + e);
+        if (KIND == 1) {
+          const uint32_t nib = mask_nib(mask, me0 + (size_t)e);
+          x.x = (nib & 1u) ? x.x * mscale : 0.f;
+          x.y = (nib & 2u) ? x.y * mscale : 0.f;
+          x.z = (nib & 4u) ? x.z * mscale : 0.f;
+          x.w = (nib & 8u) ? x.w * mscale : 0.f;
+        }
+        if (KIND == 2) {
+          x.x = dzv.x * wsr[i] * (1.f - x.x * x.x);
+          x.y = dzv.y * wsr[i] * (1.f - x.y * x.y);
+          x.z = dzv.z * wsr[i] * (1.f - x.z * x.z);
+          x.w = dzv.w * wsr[i] * (1.f - x.w * x.w);
+        }
+      }
+      v[i] = x;
+    }
+  }
+  __device__ __forceinline__ void store(float* lds, int tid) const {
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int r = (tid + i * 256) >> 2;
+      float* d = lds + kc * (BT + LPAD) + r;
+      d[0] = v[i].x;
+      d[BT + LPAD] = v[i].y;
+      d[2 * (BT + LPAD)] = v[i].z;
+      d[3 * (BT + LPAD)] = v[i].w;
+    }
+  }
+};
+
+// A/B "source kinds" used to pick a loader in the kernel template.
+enum Src : int {
+  SRC_KC = 0,        // [rows][K]
+  SRC_RC = 1,        // [K][cols]
+  SRC_RC_FLAT = 2,   // [sample][K][S], flattened columns
+  SRC_RC_FLAT_MASK = 3,
+  SRC_RC_FLAT_DS = 4,
+  SRC_SC = 5,        // [sample][rows][S], reduction over (sample, position)
+  SRC_SC_MASK = 6,
+  SRC_SC_DS = 7
+};
+
+template <int BT, int SRC> struct LoaderOf;
+template <int BT> struct LoaderOf<BT, SRC_KC> {
+  using type = LoadKC<BT>;
+  static __device__ __forceinline__ void init(type& L, const GemmParams& P, const float* base,
+                                              long rs, long bs, int row0, int rows, int tid) {
+    L.init(base, rs, row0, rows, P.K, tid);
+  }
+};
+#define RAU_LOADER_RC(SRCV, FLATV, KINDV)                                                     \
+  template <int BT> struct LoaderOf<BT, SRCV> {                                               \
+    using type = LoadRC<BT, FLATV, KINDV>;                                                    \
+    static __device__ __forceinline__ void init(type& L, const GemmParams& P,                 \
+                                                const float* base, long rs, long bs,          \
+                                                int row0, int rows, int tid) {                \
+      L.init(P, base, rs, bs, row0, rows, tid);                                               \
+    }                                                                                         \
+  };
+RAU_LOADER_RC(SRC_RC, false, 0)
+RAU_LOADER_RC(SRC_RC_FLAT, true, 0)
+RAU_LOADER_RC(SRC_RC_FLAT_MASK, true, 1)
+RAU_LOADER_RC(SRC_RC_FLAT_DS, true, 2)
+#define RAU_LOADER_SC(SRCV, KINDV)                                                            \
+  template <int BT> struct LoaderOf<BT, SRCV> {                                               \
+    using type = LoadSC<BT, KINDV>;                                                           \
+    static __device__ __forceinline__ void init(type& L, const GemmParams& P,                 \
+                                                const float* base, long rs, long bs,          \
+                                                int row0, int rows, int tid) {                \
+      L.init(P, base, bs, row0, rows, tid);                                                   \
+    }                                                                                         \
+  };
+RAU_LOADER_SC(SRC_SC, 0)
+RAU_LOADER_SC(SRC_SC_MASK, 1)
+RAU_LOADER_SC(SRC_SC_DS, 2)
+
+// -------------------------------------------------------------- epilogues
+enum Epi : int {
+  EPI_LIN = 0,       // generic pointwise epilogue, row-major C
+  EPI_SLAB = 1,      // split-K partial: raw accumulators to slab blockIdx.z
+  EPI_CONV_TANH = 2, // I = tanh(acc + bias[m]) in [sample][M][S]
+  EPI_ATT_SCORE = 3, // T = tanh(acc + bias[m] + u[b,m]); e_part[tm,n] = sum_m ws[m] T
+  EPI_DI = 4         // dZ = (acc + dj[b,m] a[n]) * (1 - I^2)
+};
+
+template <int BM, int BN, int ASRC, int BSRC, int EPI>
+__global__ __launch_bounds__(256) void gemm_kernel(const GemmParams P) {
+  constexpr int WM = BM / 2, WN = BN / 2;   // wave tile
+  constexpr int IM = WM / 32, JN = WN / 32; // 32x32 blocks per wave
+  constexpr int LDA = BM + LPAD, LDB = BN + LPAD;
+  __shared__ __attribute__((aligned(16))) float smem[2 * BK * LDA + 2 * BK * LDB + (EPI == EPI_ATT_SCORE ? 2 * BN : 0)];
+  float* As = smem;
+  float* Bs = smem + 2 * BK * LDA;
+
+  const int tid = threadIdx.x;
+  const int l = tid & 63, w = tid >> 6;
+  const int wm = w & 1, wn = w >> 1;
+
+  const int nwg = P.tiles_m * P.tiles_n;
+  const int id = xcd_remap(blockIdx.x, nwg);
+  const int tm = id % P.tiles_m, tn = id / P.tiles_m;
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  const int step0 = blockIdx.z * P.nk_per_split;
+  int nsteps = P.nk - step0;
+  if (nsteps > P.nk_per_split) nsteps = P.nk_per_split;
+
+  typename LoaderOf<BM, ASRC>::type LA;
+  typename LoaderOf<BN, BSRC>::type LB;
+  LoaderOf<BM, ASRC>::init(LA, P, P.A, P.a_rs, P.a_bs, m0, P.M, tid);
+  LoaderOf<BN, BSRC>::init(LB, P, P.B, P.b_rs, P.b_bs, n0, P.N, tid);
+
+  f32x16 acc[IM][JN];
+#pragma unroll
+  for (int i = 0; i < IM; ++i)
+#pragma unroll
+    for (int j = 0; j < JN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  if (nsteps > 0) {
+    LA.load(step0);
+    LB.load(step0);
+    LA.store(As, tid);
+    LB.store(Bs, tid);
+  }
+  __syncthreads();
+
+  const int fa = (l >> 5) * LDA + wm * WM + (l & 31);
+  const int fb = (l >> 5) * LDB + wn * WN + (l & 31);
+  for (int it = 0; it < nsteps; ++it) {
+    const int cur = it & 1;
+    const bool more = it + 1 < nsteps;
+    if (more) {
+      LA.load(step0 + it + 1);
+      LB.load(step0 + it + 1);
+    }
+    const float* as = As + cur * BK * LDA + fa;
+    const float* bs = Bs + cur * BK * LDB + fb;
+#pragma unroll
+    for (int kk = 0; kk < BK / 2; ++kk) {
+      float a[IM], b[JN];
+#pragma unroll
+      for (int i = 0; i < IM; ++i) a[i] = as[kk * 2 * LDA + i * 32];
+#pragma unroll
+      for (int j = 0; j < JN; ++j) b[j] = bs[kk * 2 * LDB + j * 32];
+#pragma unroll
+      for (int i = 0; i < IM; ++i)
+#pragma unroll
+        for (int j = 0; j < JN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    if (more) {
+      LA.store(As + (cur ^ 1) * BK * LDA, tid);
+      LB.store(Bs + (cur ^ 1) * BK * LDB, tid);
+    }
+    __syncthreads();
+  }
+
+  // ------------------------------------------------------------ epilogue
+  // accumulator element r of block (i,j): row = (r&3) + 8*(r>>2) + 4*(l>>5), col = l&31
+  const int rbase = m0 + wm * WM + 4 * (l >> 5);
+  const int cbase = n0 + wn * WN + (l & 31);
+
+  if (EPI == EPI_LIN || EPI == EPI_SLAB) {
+    float* C = P.C + (EPI == EPI_SLAB ? (long)blockIdx.z * P.slab_stride : 0);
+#pragma unroll
+    for (int j = 0; j < JN; ++j) {
+      const int n = cbase + j * 32;
+      if (n >= P.N) continue;
+      float bsum = 0.f;
+      if (EPI == EPI_LIN) {
+        if (P.bias) bsum += P.bias[n];
+        if (P.bias2) bsum += P.bias2[n];
+      }
+#pragma unroll
+      for (int i = 0; i < IM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = rbase + i * 32 + (r & 3) + 8 * (r >> 2);
+          if (m >= P.M) continue;
+          float v = acc[i][j][r];
+          const long ci = (long)m * P.c_rs + n;
+          if (EPI == EPI_LIN) {
+            v = v * P.alpha + bsum;
+            if (P.addend) v += P.addend[(long)m * P.add_rs + n];
+            if (P.accumulate) v += C[ci];
+            if (P.act == 1) v = tanhf(v);
+            if (P.ymul) {
+              const float y = P.ymul[(long)m * P.y_rs + n];
+              v *= (1.f - y * y);
+            }
+            if (P.emask)
+              v = mask_bit(P.emask, P.emask_e0 + (size_t)m * P.N + n) ? v * P.emscale : 0.f;
+          }
+          C[ci] = v;
+        }
+    }
+  } else {
+    // flattened-column epilogues: n -> (b, s)
+    float esum[JN];
+#pragma unroll
+    for (int j = 0; j < JN; ++j) {
+      esum[j] = 0.f;
+      const int n = cbase + j * 32;
+      if (n >= P.N) continue;
+      const int b = n / P.S, s = n - b * P.S;
+      const long cb = (long)b * P.c_bs + s;
+      float an = 0.f;
+      if (EPI == EPI_DI) an = P.v2[n];
+#pragma unroll
+      for (int i = 0; i < IM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = rbase + i * 32 + (r & 3) + 8 * (r >> 2);
+          if (m >= P.M) continue;
+          const long ci = cb + (long)m * P.S;
+          float v = acc[i][j][r];
+          if (EPI == EPI_CONV_TANH) {
+            P.C[ci] = tanhf(v + P.bias[m]);
+          } else if (EPI == EPI_ATT_SCORE) {
+            const float t = tanhf(v + P.bias[m] + P.u[(long)b * P.M + m]);
+            P.C[ci] = t;
+            esum[j] += P.v1[m] * t;
+          } else if (EPI == EPI_DI) {
+            const float y = P.I[ci];
+            P.C[ci] = (v + P.v1[(long)b * P.M + m] * an) * (1.f - y * y);
+          }
+        }
+    }
+    if (EPI == EPI_ATT_SCORE) {
+      // reduce over the tile's BM rows: lane halves, then the two wm waves
+      float* red = smem + 2 * BK * LDA + 2 * BK * LDB;  // [2][BN]
+#pragma unroll
+      for (int j = 0; j < JN; ++j) {
+        float v = esum[j] + __shfl_xor(esum[j], 32, 64);
+        if (l < 32) red[wm * BN + wn * WN + j * 32 + l] = v;
+      }
+      __syncthreads();
+      if (tid < BN) {
+        const int n = n0 + tid;
+        if (n < P.N) P.out2[(long)tm * P.N + n] = red[tid] + red[BN + tid];
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------ host launch
+template <int BM, int BN, int ASRC, int BSRC, int EPI>
+inline hipError_t launch_gemm(hipStream_t st, GemmParams P, int splits) {
+  P.tiles_m = (P.M + BM - 1) / BM;
+  P.tiles_n = (P.N + BN - 1) / BN;
+  if (splits < 1) splits = 1;
+  if (splits > P.nk) splits = P.nk > 0 ? P.nk : 1;
+  P.nk_per_split = (P.nk + splits - 1) / splits;
+  splits = P.nk_per_split > 0 ? (P.nk + P.nk_per_split - 1) / P.nk_per_split : 1;
+  dim3 grid(P.tiles_m * P.tiles_n, 1, splits);
+  hipLaunchKernelGGL((gemm_kernel<BM, BN, ASRC, BSRC, EPI>), grid, dim3(256), 0, st, P);
+  return hipGetLastError();
+}
+
+}  // namespace rau

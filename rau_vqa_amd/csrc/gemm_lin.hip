@@ -1,0 +1,73 @@
+// gemm_lin.hip -- Linear-layer GEMMs on the f32-MFMA engine (gemm_core.h):
+// forward y = x W^T (gemm_nt), input gradient dx = dy W (gemm_nn) and the
+// deterministic split-K weight gradient dW += dy^T x (gemm_tn_acc).
+#include "gemm_core.h"
+#include "kernels.h"
+
+namespace rau {
+
+static GemmParams lin_params(int M, int N, int K, const float* A, long lda, const float* W,
+                             long ldw, float* C, long ldc, const LinOpts& o) {
+  GemmParams P{};
+  P.M = M; P.N = N; P.K = K;
+  P.nk = (K + BK - 1) / BK;
+  P.A = A; P.a_rs = lda;
+  P.B = W; P.b_rs = ldw;
+  P.C = C; P.c_rs = ldc;
+  P.bias = o.bias; P.bias2 = o.bias2;
+  P.addend = o.addend; P.add_rs = o.add_rs;
+  P.accumulate = o.accumulate; P.act = o.act;
+  P.ymul = o.ymul; P.y_rs = o.y_rs;
+  P.emask = o.emask; P.emask_e0 = o.emask_e0; P.emscale = o.emscale;
+  P.alpha = o.alpha;
+  return P;
+}
+
+// Tile choice: these GEMMs have few rows (batch) so 64x64 tiles keep more CUs busy.
+hipError_t gemm_nt(hipStream_t st, int M, int N, int K, const float* A, long lda,
+                   const float* W, long ldw, float* C, long ldc, const LinOpts& o) {
+  GemmParams P = lin_params(M, N, K, A, lda, W, ldw, C, ldc, o);
+  if ((long)M * N >= 128L * 128 * 256)
+    return launch_gemm<128, 128, SRC_KC, SRC_KC, EPI_LIN>(st, P, 1);
+  return launch_gemm<64, 64, SRC_KC, SRC_KC, EPI_LIN>(st, P, 1);
+}
+
+hipError_t gemm_nn(hipStream_t st, int M, int N, int K, const float* A, long lda,
+                   const float* W, long ldw, float* C, long ldc, const LinOpts& o) {
+  GemmParams P = lin_params(M, N, K, A, lda, W, ldw, C, ldc, o);
+  if ((long)M * N >= 128L * 128 * 256)
+    return launch_gemm<128, 128, SRC_KC, SRC_RC, EPI_LIN>(st, P, 1);
+  return launch_gemm<64, 64, SRC_KC, SRC_RC, EPI_LIN>(st, P, 1);
+}
+
+static int tn_splits(int M, int N, int K) {
+  const int tiles = ((M + 127) / 128) * ((N + 127) / 128);
+  const int nk = (K + BK - 1) / BK;
+  int s = 512 / tiles;
+  if (s > nk / 8) s = nk / 8;
+  if (s < 1) s = 1;
+  const int per = (nk + s - 1) / s;
+  return (nk + per - 1) / per;
+}
+size_t gemm_tn_slab_floats(int M, int N, int K) {
+  const int s = tn_splits(M, N, K);
+  return s > 1 ? (size_t)s * M * N : 0;
+}
+hipError_t gemm_tn_acc(hipStream_t st, int M, int N, int K, const float* A, long lda,
+                       const float* B, long ldb, float* C, long ldc, float* slab) {
+  LinOpts o;
+  o.accumulate = 1;
+  const int s = tn_splits(M, N, K);
+  if (s <= 1) {
+    GemmParams P = lin_params(M, N, K, A, lda, B, ldb, C, ldc, o);
+    return launch_gemm<128, 128, SRC_RC, SRC_RC, EPI_LIN>(st, P, 1);
+  }
+  if (ldc != N) return hipErrorInvalidValue;
+  GemmParams P = lin_params(M, N, K, A, lda, B, ldb, slab, N, o);
+  P.slab_stride = (long)M * N;
+  hipError_t e = launch_gemm<128, 128, SRC_RC, SRC_RC, EPI_SLAB>(st, P, s);
+  if (e != hipSuccess) return e;
+  return splitk_reduce_acc(st, (size_t)M * N, s, slab, (size_t)M * N, C);
+}
+
+}  // namespace rau

@@ -1,0 +1,125 @@
+// kernels.h -- host-callable launchers of the HIP kernels (internal to librau.so).
+// Every launcher enqueues on `st` and returns hipGetLastError().
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace rau {
+
+// ------------------------------------------------------------ GEMM (gemm_lin.hip)
+struct LinOpts {
+  const float* bias = nullptr;    // + bias[n]
+  const float* bias2 = nullptr;   // + bias2[n]
+  const float* addend = nullptr;  // + addend[m*add_rs + n]
+  long add_rs = 0;
+  int accumulate = 0;             // + C_old
+  int act = 0;                    // 1: tanh
+  const float* ymul = nullptr;    // * (1 - y^2)
+  long y_rs = 0;
+  const uint32_t* emask = nullptr;  // dropout on the output (bit index e0 + m*N + n)
+  size_t emask_e0 = 0;
+  float emscale = 1.f;
+  float alpha = 1.f;
+};
+// C[M,N] = epi(A[M,K] * W[N,K]^T)      (Linear forward)
+hipError_t gemm_nt(hipStream_t st, int M, int N, int K, const float* A, long lda,
+                   const float* W, long ldw, float* C, long ldc, const LinOpts& o);
+// C[M,N] = epi(A[M,K] * W[K,N])        (Linear input gradient)
+hipError_t gemm_nn(hipStream_t st, int M, int N, int K, const float* A, long lda,
+                   const float* W, long ldw, float* C, long ldc, const LinOpts& o);
+// C[M,N] += A[K,M]^T * B[K,N]          (Linear weight gradient; deterministic split-K
+// through `slab`, which must hold gemm_tn_slab_floats(M,N,K) floats)
+size_t gemm_tn_slab_floats(int M, int N, int K);
+hipError_t gemm_tn_acc(hipStream_t st, int M, int N, int K, const float* A, long lda,
+                       const float* B, long ldb, float* C, long ldc, float* slab);
+
+// ----------------------------------------------------------- conv GEMMs (gemm_conv.hip)
+// I[b,m,s] = tanh(sum_d Wi[m,d] * drop(X)[b,d,s] + bi[m])      (reference SS:238-242)
+hipError_t conv_embed_fwd(hipStream_t st, int nB, int D, int S, int M, const float* X,
+                          const uint32_t* mask, size_t mask_e0, float mscale, const float* Wi,
+                          const float* bi, float* I);
+// T[b,k,s] = tanh(sum_m Wp[k,m] I[b,m,s] + bp[k] + u[b,k]); e_part[t][b*S+s] = partial
+// sum_k ws[k] T over the t-th 128-row tile (SS:244-252).  Returns tile count via *tiles.
+int conv_att_tiles(int A);
+hipError_t conv_att_fwd(hipStream_t st, int nB, int M, int S, int A, const float* I,
+                        const float* Wp, const float* bp, const float* u, const float* ws,
+                        float* T, float* e_part);
+// dZ[b,m,s] = (sum_k Wp[k,m] dS[b,k,s] + dj[b,m] a[b,s]) * (1 - I^2),
+// dS[b,k,s] = dz[b,s] ws[k] (1 - T^2) computed on the fly.
+hipError_t conv_att_dgrad(hipStream_t st, int nB, int M, int S, int A, const float* T,
+                          const float* dz, const float* ws, const float* Wp, const float* dj,
+                          const float* a, const float* I, float* dZ);
+// dWp[k,m] += sum_{b,s} dS[b,k,s] I[b,m,s]   and   dWi[m,d] += sum_{b,s} dZ[b,m,s] drop(X)[b,d,s]
+size_t conv_wgrad_slab_floats(int nB, int rowsA, int rowsB, int S);
+hipError_t conv_att_wgrad(hipStream_t st, int nB, int M, int S, int A, const float* T,
+                          const float* dz, const float* ws, const float* I, float* dWp,
+                          float* slab);
+hipError_t conv_embed_wgrad(hipStream_t st, int nB, int D, int S, int M, const float* dZ,
+                            const float* X, const uint32_t* mask, size_t mask_e0, float mscale, float* dWi,
+                            float* slab);
+
+// --------------------------------------------------------- pointwise (kernels.hip)
+enum GateOrder { GATES_ATT = 0 /* i g f o, ATTLSTM.lua:12-19 */,
+                 GATES_DEEP = 1 /* i f o g, DeepLSTM.lua:46-54 */ };
+
+hipError_t fill_masks(hipStream_t st, uint64_t seed, uint32_t site, uint32_t step, float p,
+                      size_t n, uint32_t* bits);
+hipError_t embed_fwd(hipStream_t st, int rows, int E, const float* emb, const int32_t* tokens,
+                     const uint32_t* mask, float mscale, float* we);
+// in place on g4: pre-activations -> activated gates; c = f c_prev + i g; h = o tanh c
+hipError_t lstm_fwd(hipStream_t st, int order, int nB, int R, float* g4, const float* c_prev,
+                    long cp_rs, float* c, long c_rs, float* h, long h_rs, float* tanhc,
+                    float* drop_out, const uint32_t* mask, size_t mask_e0, float mscale);
+// dsum from (dh [+dh2], dc_next); optional row replacement by dq rows where lens[b]==t
+hipError_t lstm_bwd(hipStream_t st, int order, int nB, int R, const float* gates,
+                    const float* c_prev, long cp_rs, const float* tanhc, const float* dh,
+                    long dh_rs, const float* dh2, const float* dc_next, float* dsum,
+                    float* dc_prev, const int32_t* lens, int t, const float* dq_c,
+                    const float* dq_h, long dq_rs);
+hipError_t softmax_fwd(hipStream_t st, int rows, int S, const float* e_part, int parts,
+                       long part_stride, const float* bs, const float* zm, float* a);
+hipError_t attselect_fwd(hipStream_t st, int nB, int M, int S, const float* I, const float* a,
+                         const float* qf, float* jv);
+hipError_t attselect_bwd(hipStream_t st, int nB, int M, int S, const float* I, const float* dj,
+                         float* da_part /* [M/64][nB*S] */);
+hipError_t softmax_bwd(hipStream_t st, int rows, int S, const float* a, const float* da_lin,
+                       const float* da_part, int parts, long part_stride, float* dz);
+// du[b,k] = ws[k] sum_s dz[b,s] (1-T^2);  dwsp[b,k] = sum_s dz[b,s] T[b,k,s]
+hipError_t att_score_bwd(hipStream_t st, int nB, int A, int S, const float* T, const float* dz,
+                         const float* ws, float* du, float* dwsp);
+// rs[row] = sum_s X[row, s]
+hipError_t row_sums(hipStream_t st, int rows, int S, const float* X, float* rs);
+// dst[n] += sum_rows X[row*ld + n]   (two-stage, deterministic; tmp >= 32*N floats)
+hipError_t colsum_acc(hipStream_t st, int rows, int N, const float* X, long ld, float* dst,
+                      float* tmp);
+// per-row CE: argmax (1-based, first max), loss row, dl = (softmax - onehot)/nB, do_pred
+hipError_t ce_fwd(hipStream_t st, int nB, int K, int M, const float* logits,
+                  const int32_t* labels, const float* mf, const float* wd, const float* bd,
+                  float* dl, float* lossrow, int32_t* argmax, float* dopred);
+hipError_t loss_reduce(hipStream_t st, int H, int nB, const float* lossrow, float* losses);
+hipError_t scale_hops(hipStream_t st, int H, size_t per_hop, const float* w_dev, float* x);
+hipError_t gather_q(hipStream_t st, int nB, int Rq, int T, const int32_t* lens, const float* c1,
+                    const float* h1, const float* c2, const float* h2, float* q);
+hipError_t apply_mask(hipStream_t st, size_t n, size_t period, const float* x,
+                      const uint32_t* mask, float mscale, float* y);
+// dq[i] = sum_h dQD[h][i] * mask_h[i] * scale
+hipError_t dq_reduce(hipStream_t st, int H, size_t n, const float* dQD, const uint32_t* mask,
+                     float mscale, float* dq);
+// dx2 -> dh1 extra: y = x * mask * scale (mask may be null)
+hipError_t embed_bwd(hipStream_t st, int nuniq, int E, const int32_t* utok, const int32_t* ustart,
+                     const int32_t* upos, const float* dwe, const float* we,
+                     const uint32_t* mask, float mscale, float* gE);
+hipError_t splitk_reduce_acc(hipStream_t st, size_t n, int splits, const float* slab,
+                             size_t slab_stride, float* dst);
+hipError_t uniform_fill(hipStream_t st, uint64_t seed, uint32_t stream, size_t n, float lo,
+                        float hi, float* x);
+// noise + norm + clip + adam (SS:597-630, optim_updates.lua:59-87)
+hipError_t add_noise_sqnorm(hipStream_t st, size_t n, float* g, float nstd, uint64_t seed,
+                            uint32_t stream, float* partial /* >= 1024 */);
+hipError_t finish_norm(hipStream_t st, int nparts, const float* partial, float* norm_out);
+hipError_t clip_adam(hipStream_t st, size_t n, float* x, float* g, float* m, float* v,
+                     const float* norm, float clip, float stepsize, float beta1, float beta2,
+                     float eps);
+
+}  // namespace rau

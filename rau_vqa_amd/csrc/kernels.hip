@@ -1,0 +1,685 @@
+// kernels.hip -- pointwise, reduction, softmax and gather kernels of the RAU path.
+// All are HBM/latency-bound byte movers: coalesced (float4 where the layout
+// allows), one wave per row for row reductions (64-lane shuffle trees), and
+// two-stage deterministic reductions instead of float atomics.
+#include "common.h"
+#include "kernels.h"
+#include "philox.h"
+
+namespace rau {
+
+static inline int grid_for(size_t n, int block = 256, int cap = 256 * 8) {
+  size_t g = (n + block - 1) / block;
+  if (g > (size_t)cap) g = cap;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+// ------------------------------------------------------------- dropout masks
+__global__ void k_fill_masks(uint64_t seed, uint32_t site, uint32_t step, uint32_t thr,
+                             size_t nwords, uint32_t* __restrict__ bits) {
+  for (size_t w = blockIdx.x * (size_t)blockDim.x + threadIdx.x; w < nwords;
+       w += (size_t)gridDim.x * blockDim.x) {
+    const uint32_t lo = philox_keep16(seed, site, step, 2 * w, thr);
+    const uint32_t hi = philox_keep16(seed, site, step, 2 * w + 1, thr);
+    bits[w] = lo | (hi << 16);
+  }
+}
+hipError_t fill_masks(hipStream_t st, uint64_t seed, uint32_t site, uint32_t step, float p,
+                      size_t n, uint32_t* bits) {
+  const size_t nwords = (n + 31) / 32;
+  const uint32_t thr = (uint32_t)lroundf(p * 256.0f);
+  hipLaunchKernelGGL(k_fill_masks, dim3(grid_for(nwords)), dim3(256), 0, st, seed, site, step,
+                     thr, nwords, bits);
+  return hipGetLastError();
+}
+
+__global__ void k_uniform_fill(uint64_t seed, uint32_t stream, size_t n, float lo, float hi,
+                               float* __restrict__ x) {
+  for (size_t q = blockIdx.x * (size_t)blockDim.x + threadIdx.x; q * 4 < n;
+       q += (size_t)gridDim.x * blockDim.x) {
+    const Philox4 o = philox4x32_10((uint32_t)q, (uint32_t)(q >> 32), stream, 0x55AAu,
+                                    (uint32_t)seed, (uint32_t)(seed >> 32));
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (q * 4 + j < n) x[q * 4 + j] = lo + (hi - lo) * ((o.v[j] >> 8) * (1.0f / 16777216.0f));
+  }
+}
+hipError_t uniform_fill(hipStream_t st, uint64_t seed, uint32_t stream, size_t n, float lo,
+                        float hi, float* x) {
+  hipLaunchKernelGGL(k_uniform_fill, dim3(grid_for((n + 3) / 4)), dim3(256), 0, st, seed, stream,
+                     n, lo, hi, x);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------ word embedding
+// we[row, e] = tanh(drop(E[token[row]-1, e]))      reference SS:203-206
+__global__ void k_embed_fwd(int rows, int E, const float* __restrict__ emb,
+                            const int32_t* __restrict__ tokens,
+                            const uint32_t* __restrict__ mask, float mscale,
+                            float* __restrict__ we) {
+  const size_t n = (size_t)rows * E;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const int row = (int)(i / E), e = (int)(i - (size_t)row * E);
+    float v = emb[(size_t)(tokens[row] - 1) * E + e];
+    if (mask) v = mask_bit(mask, i) ? v * mscale : 0.f;
+    we[i] = tanhf(v);
+  }
+}
+hipError_t embed_fwd(hipStream_t st, int rows, int E, const float* emb, const int32_t* tokens,
+                     const uint32_t* mask, float mscale, float* we) {
+  hipLaunchKernelGGL(k_embed_fwd, dim3(grid_for((size_t)rows * E)), dim3(256), 0, st, rows, E,
+                     emb, tokens, mask, mscale, we);
+  return hipGetLastError();
+}
+
+// LookupTable gradient as a gather-sum: block u owns one distinct token and
+// adds its positions' gradients in a fixed order (deterministic, no atomics).
+__global__ void k_embed_bwd(int E, const int32_t* __restrict__ utok,
+                            const int32_t* __restrict__ ustart,
+                            const int32_t* __restrict__ upos, const float* __restrict__ dwe,
+                            const float* __restrict__ we, const uint32_t* __restrict__ mask,
+                            float mscale, float* __restrict__ gE) {
+  const int u = blockIdx.x;
+  const int tok = utok[u];
+  const int p0 = ustart[u], p1 = ustart[u + 1];
+  for (int e = threadIdx.x; e < E; e += blockDim.x) {
+    float acc = 0.f;
+    for (int p = p0; p < p1; ++p) {
+      const size_t i = (size_t)upos[p] * E + e;
+      const float y = we[i];
+      float d = dwe[i] * (1.f - y * y);
+      if (mask) d = mask_bit(mask, i) ? d * mscale : 0.f;
+      acc += d;
+    }
+    gE[(size_t)(tok - 1) * E + e] += acc;
+  }
+}
+hipError_t embed_bwd(hipStream_t st, int nuniq, int E, const int32_t* utok, const int32_t* ustart,
+                     const int32_t* upos, const float* dwe, const float* we,
+                     const uint32_t* mask, float mscale, float* gE) {
+  if (nuniq <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_embed_bwd, dim3(nuniq), dim3(64), 0, st, E, utok, ustart, upos, dwe, we,
+                     mask, mscale, gE);
+  return hipGetLastError();
+}
+
+// --------------------------------------------------------------- LSTM cells
+// gate slots in the 4R-wide pre-activation row
+template <int ORDER> struct GateSlots;
+template <> struct GateSlots<GATES_ATT> { enum { I = 0, G = 1, F = 2, O = 3 }; };
+template <> struct GateSlots<GATES_DEEP> { enum { I = 0, F = 1, O = 2, G = 3 }; };
+
+template <int ORDER>
+__global__ void k_lstm_fwd(int nB, int R, float* __restrict__ g4,
+                           const float* __restrict__ c_prev, long cp_rs, float* __restrict__ c,
+                           long c_rs, float* __restrict__ h, long h_rs,
+                           float* __restrict__ tanhc, float* __restrict__ drop_out,
+                           const uint32_t* __restrict__ mask, size_t mask_e0, float mscale) {
+  using GS = GateSlots<ORDER>;
+  const size_t n = (size_t)nB * R;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const int b = (int)(i / R), r = (int)(i - (size_t)b * R);
+    float* g = g4 + (size_t)b * 4 * R;
+    const float gi = sigmoidf_(g[GS::I * R + r]);
+    const float gf = sigmoidf_(g[GS::F * R + r]);
+    const float go = sigmoidf_(g[GS::O * R + r]);
+    const float gg = tanhf(g[GS::G * R + r]);
+    g[GS::I * R + r] = gi;
+    g[GS::F * R + r] = gf;
+    g[GS::O * R + r] = go;
+    g[GS::G * R + r] = gg;
+    const float cn = gf * c_prev[(size_t)b * cp_rs + r] + gi * gg;
+    const float tc = tanhf(cn);
+    const float hn = go * tc;
+    c[(size_t)b * c_rs + r] = cn;
+    h[(size_t)b * h_rs + r] = hn;
+    tanhc[i] = tc;
+    if (drop_out) {
+      float v = hn;
+      if (mask) v = mask_bit(mask, mask_e0 + i) ? hn * mscale : 0.f;
+      drop_out[i] = v;
+    }
+  }
+}
+hipError_t lstm_fwd(hipStream_t st, int order, int nB, int R, float* g4, const float* c_prev,
+                    long cp_rs, float* c, long c_rs, float* h, long h_rs, float* tanhc,
+                    float* drop_out, const uint32_t* mask, size_t mask_e0, float mscale) {
+  const dim3 g(grid_for((size_t)nB * R)), b(256);
+  if (order == GATES_ATT)
+    hipLaunchKernelGGL(k_lstm_fwd<GATES_ATT>, g, b, 0, st, nB, R, g4, c_prev, cp_rs, c, c_rs, h,
+                       h_rs, tanhc, drop_out, mask, mask_e0, mscale);
+  else
+    hipLaunchKernelGGL(k_lstm_fwd<GATES_DEEP>, g, b, 0, st, nB, R, g4, c_prev, cp_rs, c, c_rs, h,
+                       h_rs, tanhc, drop_out, mask, mask_e0, mscale);
+  return hipGetLastError();
+}
+
+template <int ORDER>
+__global__ void k_lstm_bwd(int nB, int R, const float* __restrict__ gates,
+                           const float* __restrict__ c_prev, long cp_rs,
+                           const float* __restrict__ tanhc, const float* __restrict__ dh,
+                           long dh_rs, const float* __restrict__ dh2,
+                           const float* __restrict__ dc_next, float* __restrict__ dsum,
+                           float* __restrict__ dc_prev, const int32_t* __restrict__ lens, int t,
+                           const float* __restrict__ dq_c, const float* __restrict__ dq_h,
+                           long dq_rs) {
+  using GS = GateSlots<ORDER>;
+  const size_t n = (size_t)nB * R;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const int b = (int)(i / R), r = (int)(i - (size_t)b * R);
+    float dhv, dcv;
+    if (lens && lens[b] == t) {  // rows REPLACED by dq, reference SS:584-591
+      dhv = dq_h[(size_t)b * dq_rs + r];
+      dcv = dq_c[(size_t)b * dq_rs + r];
+    } else {
+      dhv = dh ? dh[(size_t)b * dh_rs + r] : 0.f;
+      dcv = dc_next ? dc_next[i] : 0.f;
+    }
+    if (dh2) dhv += dh2[i];
+    const float* g = gates + (size_t)b * 4 * R;
+    const float gi = g[GS::I * R + r], gf = g[GS::F * R + r], go = g[GS::O * R + r],
+                gg = g[GS::G * R + r];
+    const float tc = tanhc[i];
+    const float d_o = dhv * tc;
+    const float dc = dcv + dhv * go * (1.f - tc * tc);
+    float* ds = dsum + (size_t)b * 4 * R;
+    ds[GS::I * R + r] = dc * gg * gi * (1.f - gi);
+    ds[GS::F * R + r] = dc * c_prev[(size_t)b * cp_rs + r] * gf * (1.f - gf);
+    ds[GS::O * R + r] = d_o * go * (1.f - go);
+    ds[GS::G * R + r] = dc * gi * (1.f - gg * gg);
+    dc_prev[i] = dc * gf;
+  }
+}
+hipError_t lstm_bwd(hipStream_t st, int order, int nB, int R, const float* gates,
+                    const float* c_prev, long cp_rs, const float* tanhc, const float* dh,
+                    long dh_rs, const float* dh2, const float* dc_next, float* dsum,
+                    float* dc_prev, const int32_t* lens, int t, const float* dq_c,
+                    const float* dq_h, long dq_rs) {
+  const dim3 g(grid_for((size_t)nB * R)), b(256);
+  if (order == GATES_ATT)
+    hipLaunchKernelGGL(k_lstm_bwd<GATES_ATT>, g, b, 0, st, nB, R, gates, c_prev, cp_rs, tanhc,
+                       dh, dh_rs, dh2, dc_next, dsum, dc_prev, lens, t, dq_c, dq_h, dq_rs);
+  else
+    hipLaunchKernelGGL(k_lstm_bwd<GATES_DEEP>, g, b, 0, st, nB, R, gates, c_prev, cp_rs, tanhc,
+                       dh, dh_rs, dh2, dc_next, dsum, dc_prev, lens, t, dq_c, dq_h, dq_rs);
+  return hipGetLastError();
+}
+
+// --------------------------------------------------- attention softmax / context
+// One wave per row; a = softmax(sum_parts e_part + bs + zm).  reference SS:285-290
+__global__ void k_softmax_fwd(int rows, int S, const float* __restrict__ e_part, int parts,
+                              long part_stride, const float* __restrict__ bs,
+                              const float* __restrict__ zm, float* __restrict__ a) {
+  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int l = threadIdx.x & 63;
+  const float b0 = bs[0];
+  float mx = -INFINITY;
+  for (int s = l; s < S; s += 64) {
+    float z = b0 + zm[(size_t)row * S + s];
+    for (int p = 0; p < parts; ++p) z += e_part[p * part_stride + (size_t)row * S + s];
+    a[(size_t)row * S + s] = z;
+    mx = fmaxf(mx, z);
+  }
+  mx = wave_max(mx);
+  float den = 0.f;
+  for (int s = l; s < S; s += 64) {
+    const float ex = expf(a[(size_t)row * S + s] - mx);
+    a[(size_t)row * S + s] = ex;
+    den += ex;
+  }
+  den = wave_sum(den);
+  const float inv = 1.f / den;
+  for (int s = l; s < S; s += 64) a[(size_t)row * S + s] *= inv;
+}
+hipError_t softmax_fwd(hipStream_t st, int rows, int S, const float* e_part, int parts,
+                       long part_stride, const float* bs, const float* zm, float* a) {
+  hipLaunchKernelGGL(k_softmax_fwd, dim3((rows + 3) / 4), dim3(256), 0, st, rows, S, e_part, parts,
+                     part_stride, bs, zm, a);
+  return hipGetLastError();
+}
+
+// jv[b,m] = qf[b,m] + sum_s I[b,m,s] a[b,s]     (attselect SS:254-263 + CAddTable SS:270)
+// one wave per (b, m) row, float4 lanes; 8 rows per wave, 32 rows per block.
+__global__ void k_attselect_fwd(int nB, int M, int S, const float* __restrict__ I,
+                                const float* __restrict__ a, const float* __restrict__ qf,
+                                float* __restrict__ jv) {
+  const int mblocks = (M + 31) / 32;
+  const int b = blockIdx.x / mblocks;
+  const int mb = (blockIdx.x - b * mblocks) * 32 + (threadIdx.x >> 6) * 8;
+  const int l = threadIdx.x & 63;
+  const int S4 = S >> 2;
+  for (int r = 0; r < 8; ++r) {
+    const int m = mb + r;
+    if (m >= M) break;
+    const float4* row = reinterpret_cast<const float4*>(I + ((size_t)b * M + m) * S);
+    const float4* av = reinterpret_cast<const float4*>(a + (size_t)b * S);
+    float acc = 0.f;
+    for (int q = l; q < S4; q += 64) {
+      const float4 x = row[q], y = av[q];
+      acc += x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w;
+    }
+    acc = wave_sum(acc);
+    if (l == 0) jv[(size_t)b * M + m] = acc + qf[(size_t)b * M + m];
+  }
+}
+hipError_t attselect_fwd(hipStream_t st, int nB, int M, int S, const float* I, const float* a,
+                         const float* qf, float* jv) {
+  hipLaunchKernelGGL(k_attselect_fwd, dim3(nB * ((M + 31) / 32)), dim3(256), 0, st, nB, M, S, I,
+                     a, qf, jv);
+  return hipGetLastError();
+}
+
+// da_part[c][b,s] = sum_{m in chunk c of 64} dj[b,m] I[b,m,s]; lanes own float4 of s,
+// the block's 4 waves take 16 rows each and combine through LDS in wave order.
+__global__ void k_attselect_bwd(int nB, int M, int S, const float* __restrict__ I,
+                                const float* __restrict__ dj, float* __restrict__ da_part) {
+  extern __shared__ __attribute__((aligned(16))) float red[];  // [4][S]
+  const int chunks = (M + 63) / 64;
+  const int b = blockIdx.x / chunks, c = blockIdx.x - b * chunks;
+  const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+  const int S4 = S >> 2;
+  for (int q = l; q < S4; q += 64) {
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int r = 0; r < 16; ++r) {
+      const int m = c * 64 + w * 16 + r;
+      if (m >= M) break;
+      const float d = dj[(size_t)b * M + m];
+      const float4 x = reinterpret_cast<const float4*>(I + ((size_t)b * M + m) * S)[q];
+      acc.x += d * x.x; acc.y += d * x.y; acc.z += d * x.z; acc.w += d * x.w;
+    }
+    reinterpret_cast<float4*>(red + (size_t)w * S)[q] = acc;
+  }
+  __syncthreads();
+  for (int s = threadIdx.x; s < S; s += blockDim.x)
+    da_part[(size_t)c * nB * S + (size_t)b * S + s] =
+        ((red[s] + red[S + s]) + red[2 * S + s]) + red[3 * S + s];
+}
+hipError_t attselect_bwd(hipStream_t st, int nB, int M, int S, const float* I, const float* dj,
+                         float* da_part) {
+  hipLaunchKernelGGL(k_attselect_bwd, dim3(nB * ((M + 63) / 64)), dim3(256),
+                     4 * S * sizeof(float), st, nB, M, S, I, dj, da_part);
+  return hipGetLastError();
+}
+
+// dz = a * (da - sum_s a da), da = da_lin + sum_parts da_part
+__global__ void k_softmax_bwd(int rows, int S, const float* __restrict__ a,
+                              const float* __restrict__ da_lin, const float* __restrict__ da_part,
+                              int parts, long part_stride, float* __restrict__ dz) {
+  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int l = threadIdx.x & 63;
+  float dot = 0.f;
+  for (int s = l; s < S; s += 64) {
+    float d = da_lin[(size_t)row * S + s];
+    for (int p = 0; p < parts; ++p) d += da_part[p * part_stride + (size_t)row * S + s];
+    dz[(size_t)row * S + s] = d;
+    dot += a[(size_t)row * S + s] * d;
+  }
+  dot = wave_sum(dot);
+  for (int s = l; s < S; s += 64)
+    dz[(size_t)row * S + s] = a[(size_t)row * S + s] * (dz[(size_t)row * S + s] - dot);
+}
+hipError_t softmax_bwd(hipStream_t st, int rows, int S, const float* a, const float* da_lin,
+                       const float* da_part, int parts, long part_stride, float* dz) {
+  hipLaunchKernelGGL(k_softmax_bwd, dim3((rows + 3) / 4), dim3(256), 0, st, rows, S, a, da_lin,
+                     da_part, parts, part_stride, dz);
+  return hipGetLastError();
+}
+
+// one wave per (b,k) row of T
+__global__ void k_att_score_bwd(int nB, int A, int S, const float* __restrict__ T,
+                                const float* __restrict__ dz, const float* __restrict__ ws,
+                                float* __restrict__ du, float* __restrict__ dwsp) {
+  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= nB * A) return;
+  const int b = row / A, k = row - b * A;
+  const int l = threadIdx.x & 63;
+  const int S4 = S >> 2;
+  const float4* tr = reinterpret_cast<const float4*>(T + (size_t)row * S);
+  const float4* dr = reinterpret_cast<const float4*>(dz + (size_t)b * S);
+  float s1 = 0.f, s2 = 0.f;
+  for (int q = l; q < S4; q += 64) {
+    const float4 t = tr[q], d = dr[q];
+    s1 += d.x * (1.f - t.x * t.x) + d.y * (1.f - t.y * t.y) + d.z * (1.f - t.z * t.z) +
+          d.w * (1.f - t.w * t.w);
+    s2 += d.x * t.x + d.y * t.y + d.z * t.z + d.w * t.w;
+  }
+  s1 = wave_sum(s1);
+  s2 = wave_sum(s2);
+  if (l == 0) {
+    du[row] = ws[k] * s1;
+    dwsp[row] = s2;
+  }
+}
+hipError_t att_score_bwd(hipStream_t st, int nB, int A, int S, const float* T, const float* dz,
+                         const float* ws, float* du, float* dwsp) {
+  hipLaunchKernelGGL(k_att_score_bwd, dim3((nB * A + 3) / 4), dim3(256), 0, st, nB, A, S, T, dz,
+                     ws, du, dwsp);
+  return hipGetLastError();
+}
+
+__global__ void k_row_sums(int rows, int S, const float* __restrict__ X, float* __restrict__ rs) {
+  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int l = threadIdx.x & 63;
+  const int S4 = S >> 2;
+  const float4* xr = reinterpret_cast<const float4*>(X + (size_t)row * S);
+  float acc = 0.f;
+  for (int q = l; q < S4; q += 64) {
+    const float4 x = xr[q];
+    acc += (x.x + x.y) + (x.z + x.w);
+  }
+  acc = wave_sum(acc);
+  if (l == 0) rs[row] = acc;
+}
+hipError_t row_sums(hipStream_t st, int rows, int S, const float* X, float* rs) {
+  hipLaunchKernelGGL(k_row_sums, dim3((rows + 3) / 4), dim3(256), 0, st, rows, S, X, rs);
+  return hipGetLastError();
+}
+
+// ----------------------------------------------- deterministic column sums
+constexpr int kColChunks = 32;
+__global__ void k_colsum_stage1(int rows, int N, const float* __restrict__ X, long ld,
+                                float* __restrict__ tmp) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  const int per = (rows + kColChunks - 1) / kColChunks;
+  const int r0 = blockIdx.y * per;
+  int r1 = r0 + per;
+  if (r1 > rows) r1 = rows;
+  float acc = 0.f;
+  for (int r = r0; r < r1; ++r) acc += X[(size_t)r * ld + n];
+  tmp[(size_t)blockIdx.y * N + n] = acc;
+}
+__global__ void k_colsum_stage2(int N, const float* __restrict__ tmp, float* __restrict__ dst) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  float acc = 0.f;
+  for (int c = 0; c < kColChunks; ++c) acc += tmp[(size_t)c * N + n];
+  dst[n] += acc;
+}
+hipError_t colsum_acc(hipStream_t st, int rows, int N, const float* X, long ld, float* dst,
+                      float* tmp) {
+  hipLaunchKernelGGL(k_colsum_stage1, dim3((N + 63) / 64, kColChunks), dim3(64), 0, st, rows, N,
+                     X, ld, tmp);
+  hipLaunchKernelGGL(k_colsum_stage2, dim3((N + 63) / 64), dim3(64), 0, st, N, tmp, dst);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------- classifier loss head
+// One block per sample.  CrossEntropyCriterion (SS:310,518) + torch.max first-max
+// argmax (SS:488) + do_pred = sigmoid(mf . wd + bd) (SS:281).
+__global__ void k_ce_fwd(int nB, int K, int M, const float* __restrict__ logits,
+                         const int32_t* __restrict__ labels, const float* __restrict__ mf,
+                         const float* __restrict__ wd, const float* __restrict__ bd,
+                         float* __restrict__ dl, float* __restrict__ lossrow,
+                         int32_t* __restrict__ argmax, float* __restrict__ dopred) {
+  __shared__ float s_val[4];
+  __shared__ int s_idx[4];
+  __shared__ float s_sum[4];
+  const int b = blockIdx.x;
+  const int tid = threadIdx.x, l = tid & 63, w = tid >> 6;
+  const float* lg = logits + (size_t)b * K;
+  // max + first argmax
+  float mx = -INFINITY;
+  int ai = 0x7fffffff;
+  for (int k = tid; k < K; k += 256) {
+    const float v = lg[k];
+    if (v > mx) { mx = v; ai = k; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(mx, o, 64);
+    const int oi = __shfl_xor(ai, o, 64);
+    if (ov > mx || (ov == mx && oi < ai)) { mx = ov; ai = oi; }
+  }
+  if (l == 0) { s_val[w] = mx; s_idx[w] = ai; }
+  __syncthreads();
+  mx = s_val[0]; ai = s_idx[0];
+#pragma unroll
+  for (int i = 1; i < 4; ++i)
+    if (s_val[i] > mx || (s_val[i] == mx && s_idx[i] < ai)) { mx = s_val[i]; ai = s_idx[i]; }
+  float den = 0.f;
+  for (int k = tid; k < K; k += 256) den += expf(lg[k] - mx);
+  den = wave_sum(den);
+  if (l == 0) s_sum[w] = den;
+  __syncthreads();
+  den = (s_sum[0] + s_sum[1]) + (s_sum[2] + s_sum[3]);
+  const float lse = mx + logf(den);
+  if (tid == 0) argmax[b] = ai + 1;
+  if (labels) {
+    const int y = labels[b] - 1;
+    const float invB = 1.f / (float)nB;
+    for (int k = tid; k < K; k += 256) {
+      float p = expf(lg[k] - lse) * invB;
+      if (k == y) p -= invB;
+      dl[(size_t)b * K + k] = p;
+    }
+    if (tid == 0) lossrow[b] = lse - lg[y];
+  }
+  // do_pred
+  float acc = 0.f;
+  for (int m = tid; m < M; m += 256) acc += mf[(size_t)b * M + m] * wd[m];
+  acc = wave_sum(acc);
+  __syncthreads();
+  if (l == 0) s_sum[w] = acc;
+  __syncthreads();
+  if (tid == 0) dopred[b] = sigmoidf_(((s_sum[0] + s_sum[1]) + (s_sum[2] + s_sum[3])) + bd[0]);
+}
+hipError_t ce_fwd(hipStream_t st, int nB, int K, int M, const float* logits,
+                  const int32_t* labels, const float* mf, const float* wd, const float* bd,
+                  float* dl, float* lossrow, int32_t* argmax, float* dopred) {
+  hipLaunchKernelGGL(k_ce_fwd, dim3(nB), dim3(256), 0, st, nB, K, M, logits, labels, mf, wd, bd,
+                     dl, lossrow, argmax, dopred);
+  return hipGetLastError();
+}
+
+__global__ void k_loss_reduce(int nB, const float* __restrict__ lossrow,
+                              float* __restrict__ losses) {
+  const int h = blockIdx.x;
+  float acc = 0.f;
+  for (int b = threadIdx.x; b < nB; b += 64) acc += lossrow[(size_t)h * nB + b];
+  acc = wave_sum(acc);
+  if (threadIdx.x == 0) losses[h] = acc / (float)nB;
+}
+hipError_t loss_reduce(hipStream_t st, int H, int nB, const float* lossrow, float* losses) {
+  hipLaunchKernelGGL(k_loss_reduce, dim3(H), dim3(64), 0, st, nB, lossrow, losses);
+  return hipGetLastError();
+}
+
+__global__ void k_scale_hops(size_t per_hop, size_t n, const float* __restrict__ w,
+                             float* __restrict__ x) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n;
+       i += (size_t)gridDim.x * blockDim.x)
+    x[i] *= w[i / per_hop];
+}
+hipError_t scale_hops(hipStream_t st, int H, size_t per_hop, const float* w_dev, float* x) {
+  const size_t n = per_hop * H;
+  hipLaunchKernelGGL(k_scale_hops, dim3(grid_for(n)), dim3(256), 0, st, per_hop, n, w_dev, x);
+  return hipGetLastError();
+}
+
+// q[b] = [c1 h1 c2 h2] at t = lens[b] (state arrays are [T+1][nB][Rq], slot 0 = zeros)
+__global__ void k_gather_q(int nB, int Rq, const int32_t* __restrict__ lens,
+                           const float* __restrict__ c1, const float* __restrict__ h1,
+                           const float* __restrict__ c2, const float* __restrict__ h2,
+                           float* __restrict__ q) {
+  const size_t n = (size_t)nB * 4 * Rq;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const int b = (int)(i / (4 * Rq));
+    const int j = (int)(i - (size_t)b * 4 * Rq);
+    const int slot = j / Rq, r = j - slot * Rq;
+    const float* src = slot == 0 ? c1 : slot == 1 ? h1 : slot == 2 ? c2 : h2;
+    const int t = lens[b];
+    q[i] = t > 0 ? src[((size_t)t * nB + b) * Rq + r] : 0.f;
+  }
+}
+hipError_t gather_q(hipStream_t st, int nB, int Rq, int T, const int32_t* lens, const float* c1,
+                    const float* h1, const float* c2, const float* h2, float* q) {
+  hipLaunchKernelGGL(k_gather_q, dim3(grid_for((size_t)nB * 4 * Rq)), dim3(256), 0, st, nB, Rq,
+                     lens, c1, h1, c2, h2, q);
+  return hipGetLastError();
+}
+
+// y[i] = x[i % period] * mask(i) * scale      (i over n; mask may be null)
+__global__ void k_apply_mask(size_t n, size_t period, const float* __restrict__ x,
+                             const uint32_t* __restrict__ mask, float mscale,
+                             float* __restrict__ y) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const float v = x[i % period];
+    y[i] = mask ? (mask_bit(mask, i) ? v * mscale : 0.f) : v;
+  }
+}
+hipError_t apply_mask(hipStream_t st, size_t n, size_t period, const float* x,
+                      const uint32_t* mask, float mscale, float* y) {
+  hipLaunchKernelGGL(k_apply_mask, dim3(grid_for(n)), dim3(256), 0, st, n, period, x, mask,
+                     mscale, y);
+  return hipGetLastError();
+}
+
+__global__ void k_dq_reduce(int H, size_t n, const float* __restrict__ dQD,
+                            const uint32_t* __restrict__ mask, float mscale,
+                            float* __restrict__ dq) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n;
+       i += (size_t)gridDim.x * blockDim.x) {
+    float acc = 0.f;
+    for (int h = H - 1; h >= 0; --h) {  // reference accumulates hop H first (SS:564)
+      const size_t e = (size_t)h * n + i;
+      const float v = dQD[e];
+      acc += mask ? (mask_bit(mask, e) ? v * mscale : 0.f) : v;
+    }
+    dq[i] = acc;
+  }
+}
+hipError_t dq_reduce(hipStream_t st, int H, size_t n, const float* dQD, const uint32_t* mask,
+                     float mscale, float* dq) {
+  hipLaunchKernelGGL(k_dq_reduce, dim3(grid_for(n)), dim3(256), 0, st, H, n, dQD, mask, mscale,
+                     dq);
+  return hipGetLastError();
+}
+
+__global__ void k_splitk_reduce_acc(size_t n4, int splits, const float4* __restrict__ slab,
+                                    size_t stride4, float4* __restrict__ dst) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4;
+       i += (size_t)gridDim.x * blockDim.x) {
+    float4 acc = slab[i];
+    for (int s = 1; s < splits; ++s) {
+      const float4 v = slab[(size_t)s * stride4 + i];
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    float4 d = dst[i];
+    d.x += acc.x; d.y += acc.y; d.z += acc.z; d.w += acc.w;
+    dst[i] = d;
+  }
+}
+__global__ void k_splitk_reduce_acc1(size_t n, int splits, const float* __restrict__ slab,
+                                     size_t stride, float* __restrict__ dst) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n;
+       i += (size_t)gridDim.x * blockDim.x) {
+    float acc = slab[i];
+    for (int s = 1; s < splits; ++s) acc += slab[(size_t)s * stride + i];
+    dst[i] += acc;
+  }
+}
+hipError_t splitk_reduce_acc(hipStream_t st, size_t n, int splits, const float* slab,
+                             size_t slab_stride, float* dst) {
+  const bool v4 = (n % 4 == 0) && (slab_stride % 4 == 0) && (((uintptr_t)dst & 15) == 0) &&
+                  (((uintptr_t)slab & 15) == 0);
+  if (v4)
+    hipLaunchKernelGGL(k_splitk_reduce_acc, dim3(grid_for(n / 4)), dim3(256), 0, st, n / 4, splits,
+                       reinterpret_cast<const float4*>(slab), slab_stride / 4,
+                       reinterpret_cast<float4*>(dst));
+  else
+    hipLaunchKernelGGL(k_splitk_reduce_acc1, dim3(grid_for(n)), dim3(256), 0, st, n, splits, slab,
+                       slab_stride, dst);
+  return hipGetLastError();
+}
+
+// --------------------------------------------------- noise / clip / Adam (next-1)
+__device__ __forceinline__ float2 box_muller(uint32_t a, uint32_t b) {
+  const float u1 = ((a >> 8) + 1) * (1.0f / 16777216.0f);  // (0,1]
+  const float u2 = (b >> 8) * (1.0f / 16777216.0f);
+  const float r = sqrtf(-2.f * logf(u1));
+  float s, c;
+  sincosf(6.28318530717958647692f * u2, &s, &c);
+  return make_float2(r * c, r * s);
+}
+__global__ void k_add_noise_sqnorm(size_t n, float* __restrict__ g, float nstd, uint64_t seed,
+                                   uint32_t stream, float* __restrict__ partial) {
+  __shared__ float s_sum[4];
+  float acc = 0.f;
+  for (size_t q = blockIdx.x * (size_t)blockDim.x + threadIdx.x; q * 4 < n;
+       q += (size_t)gridDim.x * blockDim.x) {
+    float z[4] = {0.f, 0.f, 0.f, 0.f};
+    if (nstd > 0.f) {
+      const Philox4 o = philox4x32_10((uint32_t)q, (uint32_t)(q >> 32), stream, 0xA5A5u,
+                                      (uint32_t)seed, (uint32_t)(seed >> 32));
+      const float2 n0 = box_muller(o.v[0], o.v[1]), n1 = box_muller(o.v[2], o.v[3]);
+      z[0] = n0.x; z[1] = n0.y; z[2] = n1.x; z[3] = n1.y;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (q * 4 + j < n) {
+        const float v = g[q * 4 + j] + z[j] * nstd;
+        g[q * 4 + j] = v;
+        acc += v * v;
+      }
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) s_sum[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = (s_sum[0] + s_sum[1]) + (s_sum[2] + s_sum[3]);
+}
+hipError_t add_noise_sqnorm(hipStream_t st, size_t n, float* g, float nstd, uint64_t seed,
+                            uint32_t stream, float* partial) {
+  hipLaunchKernelGGL(k_add_noise_sqnorm, dim3(1024), dim3(256), 0, st, n, g, nstd, seed, stream,
+                     partial);
+  return hipGetLastError();
+}
+__global__ void k_finish_norm(int nparts, const float* __restrict__ partial,
+                              float* __restrict__ norm_out) {
+  __shared__ float s_sum[4];
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < nparts; i += 256) acc += partial[i];
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) s_sum[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) norm_out[0] = sqrtf((s_sum[0] + s_sum[1]) + (s_sum[2] + s_sum[3]));
+}
+hipError_t finish_norm(hipStream_t st, int nparts, const float* partial, float* norm_out) {
+  hipLaunchKernelGGL(k_finish_norm, dim3(1), dim3(256), 0, st, nparts, partial, norm_out);
+  return hipGetLastError();
+}
+__global__ void k_clip_adam(size_t n, float* __restrict__ x, float* __restrict__ g,
+                            float* __restrict__ m, float* __restrict__ v,
+                            const float* __restrict__ norm, float clip, float stepsize,
+                            float beta1, float beta2, float eps) {
+  const float nv = norm[0];
+  const float sc = nv > clip ? clip / nv : 1.f;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const float gi = g[i] * sc;
+    g[i] = gi;
+    const float mi = m[i] * beta1 + (1.f - beta1) * gi;
+    const float vi = v[i] * beta2 + (1.f - beta2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    x[i] -= stepsize * mi / (sqrtf(vi) + eps);
+  }
+}
+hipError_t clip_adam(hipStream_t st, size_t n, float* x, float* g, float* m, float* v,
+                     const float* norm, float clip, float stepsize, float beta1, float beta2,
+                     float eps) {
+  hipLaunchKernelGGL(k_clip_adam, dim3(grid_for(n)), dim3(256), 0, st, n, x, g, m, v, norm, clip,
+                     stepsize, beta1, beta2, eps);
+  return hipGetLastError();
+}
+
+}  // namespace rau

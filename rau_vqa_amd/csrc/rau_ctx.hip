@@ -1,0 +1,1161 @@
+// rau_ctx.hip -- the rau_ctx object and the C ABI of include/rau.h.
+//
+// Orchestrates one training step of the Recurrent Answering Unit on one
+// MI355X: question encoder (word embedding + 2-layer LSTM over <=T tokens),
+// H weight-shared answering hops (attention over the S-position feature map,
+// attention LSTM, classifier, cross-entropy) and the full backward pass into
+// the three flat gradient buffers.  Reference being replaced: feval in
+// experiments/Ours_SS/LstmAttCtrlGradNoiseDontSelect.lua:428-596 and the graph
+// it drives (SS:198-316, model/ATTLSTM.lua, model/DeepLSTM.lua).
+//
+// Restructuring relative to the reference's module-by-module execution (all of
+// it value-preserving; see DESIGN.md "Schedule"):
+//   * work that does not depend on the recurrence is hoisted out of the loops
+//     and batched: layer input projections over all tokens, the q projection
+//     over all hops, dq = sum_h over hops, and every Linear weight gradient
+//     (one [H*B]- or [T*B]-row GEMM per weight instead of one per clone);
+//   * dropout masks are bit-packed and applied while staging GEMM operands;
+//   * the dead gradient w.r.t. the feature map (SS:579 discards it) is skipped.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "../../include/rau.h"
+#include "kernels.h"
+
+using namespace rau;
+
+// ------------------------------------------------------------------ errors
+static thread_local char g_err[512] = "";
+static int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+#define HIPC(expr)                                                                        \
+  do {                                                                                    \
+    hipError_t e_ = (expr);                                                               \
+    if (e_ != hipSuccess)                                                                 \
+      return fail(RAU_ERR_DEVICE, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_),  \
+                  __FILE__, __LINE__);                                                    \
+  } while (0)
+#define NEED(cond, ...)                               \
+  do {                                                \
+    if (!(cond)) return fail(RAU_ERR_INVALID, __VA_ARGS__); \
+  } while (0)
+
+// ------------------------------------------------------------------ ctx
+namespace {
+
+struct Lin {  // one Linear (or 1x1 conv) inside a flat group
+  float *W, *b, *dW, *db;
+  int out, in;
+};
+struct Entry {
+  std::string name;
+  size_t off;
+  int rows, cols;
+};
+struct Group {
+  float* w = nullptr;
+  float* g = nullptr;
+  float* m = nullptr;  // Adam moments (allocated on first update)
+  float* v = nullptr;
+  size_t n = 0;
+  int64_t adam_t = 0;
+  std::vector<Entry> layout;
+};
+struct ProfRec {
+  int cls;
+  hipEvent_t a, b;
+};
+struct ProfCls {
+  std::string name;
+  int64_t launches = 0;
+  double ms = 0, flops = 0, bytes = 0;
+};
+
+}  // namespace
+
+struct rau_ctx {
+  rau_config cfg;
+  int Q;
+  hipStream_t st = nullptr;
+  std::vector<void*> allocs;
+  Group grp[3];
+  // mult
+  Lin q_proj, h_proj, i_embed, att_q, att_i, att_score, att_mem, feat_attprob, lstm_i2h,
+      lstm_h2h, lstm_out, cls, do_pred;
+  // rnn
+  Lin i2h[2], h2h[2];
+  // batch
+  float* feats = nullptr;
+  int32_t *tokens = nullptr, *lens_d = nullptr, *labels_d = nullptr;
+  std::vector<int32_t> lens_h;
+  int max_len = 0;
+  bool have_batch = false, have_labels = false;
+  int nuniq = 0;
+  int32_t *utok = nullptr, *ustart = nullptr, *upos = nullptr;
+  // dropout
+  int mode = RAU_MODE_TRAIN;
+  uint32_t* mbits[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  size_t mcount[5] = {0, 0, 0, 0, 0};
+  bool mexplicit[5] = {false, false, false, false, false};
+  float mp[5];
+  uint64_t seed = 0;
+  uint32_t step = 0;
+  // encoder activations
+  float *we, *G1, *G2, *c1, *h1, *c2, *h2, *tc1, *tc2, *x2, *q;
+  // RAU activations
+  float *qd, *Yq, *qf, *I, *T, *u, *e_part, *zm, *a, *jv, *j, *g4, *cc, *hh, *tc, *mf, *logits,
+      *dl, *lossrow, *dopred, *losses_d, *hopw_d;
+  int32_t* argmax_d;
+  // backward temporaries
+  float *dpre, *dhn, *dg4, *dcn[2], *dhp[2], *dj, *da_lin, *da_part, *dz, *du, *dwsp, *dZ, *rsum,
+      *dqt, *dQD, *dq, *slab, *coltmp, *tmpS;
+  float *dG1, *dG2, *dX2, *dwe, *edc[2][2], *edh[2];
+  size_t slab_floats = 0;
+  // update
+  float *npart = nullptr, *norms_d = nullptr;
+  bool fwd_done = false;
+  // timing
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  bool prof_on = false;
+  std::vector<ProfCls> pcls;
+  std::vector<ProfRec> precs;
+  std::vector<hipEvent_t> evpool;
+};
+
+namespace {
+
+template <typename Tp>
+int dalloc(rau_ctx* c, Tp** p, size_t count) {
+  void* d = nullptr;
+  const size_t bytes = std::max<size_t>(count, 1) * sizeof(Tp);
+  hipError_t e = hipMalloc(&d, bytes);
+  if (e != hipSuccess)
+    return fail(RAU_ERR_NOMEM, "hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
+  e = hipMemsetAsync(d, 0, bytes, c->st);
+  if (e != hipSuccess) return fail(RAU_ERR_DEVICE, "hipMemsetAsync: %s", hipGetErrorString(e));
+  c->allocs.push_back(d);
+  *p = reinterpret_cast<Tp*>(d);
+  return 0;
+}
+
+struct LayoutBuilder {
+  Group* g;
+  size_t off = 0;
+  Lin take(const char* name, int out, int in) {
+    Lin l;
+    l.out = out;
+    l.in = in;
+    g->layout.push_back({std::string(name) + ".weight", off, out, in});
+    l.W = reinterpret_cast<float*>(off);
+    off += (size_t)out * in;
+    g->layout.push_back({std::string(name) + ".bias", off, out, 1});
+    l.b = reinterpret_cast<float*>(off);
+    off += out;
+    return l;
+  }
+};
+void bind(Lin& l, const Group& g) {
+  const size_t ow = reinterpret_cast<size_t>(l.W), ob = reinterpret_cast<size_t>(l.b);
+  l.W = g.w + ow;
+  l.b = g.w + ob;
+  l.dW = g.g + ow;
+  l.db = g.g + ob;
+}
+
+int prof_class(rau_ctx* c, const char* name) {
+  for (size_t i = 0; i < c->pcls.size(); ++i)
+    if (c->pcls[i].name == name) return (int)i;
+  c->pcls.push_back(ProfCls{name});
+  return (int)c->pcls.size() - 1;
+}
+hipEvent_t prof_event(rau_ctx* c) {
+  if (!c->evpool.empty()) {
+    hipEvent_t e = c->evpool.back();
+    c->evpool.pop_back();
+    return e;
+  }
+  hipEvent_t e;
+  hipEventCreate(&e);
+  return e;
+}
+
+}  // namespace
+
+// Launch wrapper: counts launches/FLOPs/bytes per kernel class and, when
+// profiling is on, brackets the launch with HIP events on the ctx stream.
+#define RUN(cname, fl, by, expr)                                                          \
+  do {                                                                                    \
+    ProfRec pr_;                                                                          \
+    int pc_ = -1;                                                                         \
+    if (ctx->prof_on) {                                                                   \
+      pc_ = prof_class(ctx, cname);                                                       \
+      ctx->pcls[pc_].launches++;                                                          \
+      ctx->pcls[pc_].flops += (double)(fl);                                               \
+      ctx->pcls[pc_].bytes += (double)(by);                                               \
+      pr_.cls = pc_;                                                                      \
+      pr_.a = prof_event(ctx);                                                            \
+      pr_.b = prof_event(ctx);                                                            \
+      hipEventRecord(pr_.a, ctx->st);                                                     \
+    }                                                                                     \
+    hipError_t e_ = (expr);                                                               \
+    if (pc_ >= 0) {                                                                       \
+      hipEventRecord(pr_.b, ctx->st);                                                     \
+      ctx->precs.push_back(pr_);                                                          \
+    }                                                                                     \
+    if (e_ != hipSuccess)                                                                 \
+      return fail(RAU_ERR_DEVICE, "kernel %s: %s (%s:%d)", cname, hipGetErrorString(e_),  \
+                  __FILE__, __LINE__);                                                    \
+  } while (0)
+
+static int prof_collect(rau_ctx* ctx) {
+  if (ctx->precs.empty()) return 0;
+  HIPC(hipStreamSynchronize(ctx->st));
+  for (auto& r : ctx->precs) {
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, r.a, r.b);
+    ctx->pcls[r.cls].ms += ms;
+    ctx->evpool.push_back(r.a);
+    ctx->evpool.push_back(r.b);
+  }
+  ctx->precs.clear();
+  return 0;
+}
+
+// ================================================================== C ABI
+extern "C" {
+
+const char* rau_last_error(void) { return g_err; }
+int rau_abi_version(void) { return RAU_ABI_VERSION; }
+
+void rau_default_config(rau_config* cfg) {
+  std::memset(cfg, 0, sizeof(*cfg));
+  cfg->B = 100;   // opt.batch_size default, SS:48
+  cfg->T = 26;
+  cfg->V = 14000;
+  cfg->E = 200;
+  cfg->Rq = 512;
+  cfg->D = 512;
+  cfg->S = 196;
+  cfg->M = 512;
+  cfg->A = 256;
+  cfg->R = 512;
+  cfg->K = 1000;
+  cfg->H = 8;
+  cfg->p_we = cfg->p_rnn = cfg->p_q = cfg->p_x = cfg->p_mf = 0.5f;
+  cfg->dtype = RAU_F32;
+  cfg->device_id = 0;
+}
+
+int rau_create(const rau_config* cfg, rau_ctx** out) {
+  NEED(cfg && out, "rau_create: null argument");
+  const rau_config& c = *cfg;
+  NEED(c.B > 0 && c.T > 0 && c.V > 1 && c.H > 0, "rau_create: B,T,H must be > 0 and V > 1");
+  NEED(c.E > 0 && c.E % 4 == 0, "rau_create: E=%d must be a positive multiple of 4", c.E);
+  NEED(c.S > 0 && c.S % 4 == 0, "rau_create: S=%d must be a positive multiple of 4", c.S);
+  NEED(c.K > 0 && c.K % 4 == 0, "rau_create: K=%d must be a positive multiple of 4", c.K);
+  NEED(c.Rq > 0 && c.Rq % 4 == 0 && c.R > 0 && c.R % 4 == 0 && c.M > 0 && c.M % 4 == 0 &&
+           c.A > 0 && c.A % 4 == 0 && c.D > 0 && c.D % 4 == 0,
+       "rau_create: Rq,R,M,A,D must be positive multiples of 4");
+  NEED(c.dtype == RAU_F32, "rau_create: dtype %d not supported", c.dtype);
+  const float ps[5] = {c.p_we, c.p_rnn, c.p_q, c.p_x, c.p_mf};
+  for (float p : ps) NEED(p >= 0.f && p < 1.f, "rau_create: dropout p=%f out of [0,1)", p);
+
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev <= 0)
+    return fail(RAU_ERR_DEVICE, "no HIP device available (%s); librau has no CPU fallback",
+                hipGetErrorString(e));
+  NEED(c.device_id >= 0 && c.device_id < ndev, "rau_create: device_id %d of %d", c.device_id, ndev);
+  HIPC(hipSetDevice(c.device_id));
+  hipDeviceProp_t prop;
+  HIPC(hipGetDeviceProperties(&prop, c.device_id));
+  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(RAU_ERR_DEVICE, "device %d is %s; librau is built for gfx950 only", c.device_id,
+                prop.gcnArchName);
+
+  rau_ctx* ctx = new rau_ctx();
+  ctx->cfg = c;
+  ctx->Q = 4 * c.Rq;
+  for (int i = 0; i < 5; ++i) ctx->mp[i] = ps[i];
+  *out = nullptr;
+#define CK(x)                \
+  do {                       \
+    int rc_ = (x);           \
+    if (rc_ != 0) {          \
+      rau_destroy(ctx);      \
+      return rc_;            \
+    }                        \
+  } while (0)
+  {
+    hipError_t es = hipStreamCreateWithFlags(&ctx->st, hipStreamNonBlocking);
+    if (es != hipSuccess) {
+      delete ctx;
+      return fail(RAU_ERR_DEVICE, "hipStreamCreate: %s", hipGetErrorString(es));
+    }
+  }
+  hipEventCreate(&ctx->ev0);
+  hipEventCreate(&ctx->ev1);
+
+  const int B = c.B, T = c.T, E = c.E, Rq = c.Rq, D = c.D, S = c.S, M = c.M, A = c.A, R = c.R,
+            K = c.K, H = c.H, Q = ctx->Q;
+  // ---- parameter layouts (weight [out,in] then bias [out])
+  {
+    Group& g = ctx->grp[RAU_GROUP_EMBED];
+    g.layout.push_back({"word_embed.weight", 0, c.V, E});  // LookupTable, SS:204
+    g.n = (size_t)c.V * E;
+  }
+  {
+    LayoutBuilder lb{&ctx->grp[RAU_GROUP_RNN]};
+    ctx->i2h[0] = lb.take("rnn.l1.i2h", 4 * Rq, E);   // DeepLSTM.lua:42
+    ctx->h2h[0] = lb.take("rnn.l1.h2h", 4 * Rq, Rq);  // DeepLSTM.lua:43
+    ctx->i2h[1] = lb.take("rnn.l2.i2h", 4 * Rq, Rq);
+    ctx->h2h[1] = lb.take("rnn.l2.h2h", 4 * Rq, Rq);
+    ctx->grp[RAU_GROUP_RNN].n = lb.off;
+  }
+  {
+    LayoutBuilder lb{&ctx->grp[RAU_GROUP_MULT]};
+    ctx->q_proj = lb.take("q_embed.q_proj", M, Q);          // SS:233
+    ctx->h_proj = lb.take("q_embed.h_proj", M, R);          // SS:234
+    ctx->i_embed = lb.take("i_embed.conv", M, D);           // SS:240
+    ctx->att_q = lb.take("attbycontent.qfeatatt", A, M);    // SS:246
+    ctx->att_i = lb.take("attbycontent.ifeatproj", A, M);   // SS:247
+    ctx->att_score = lb.take("attbycontent.attscore", 1, A);  // SS:251
+    ctx->att_mem = lb.take("attbymemory.linear", S, R);     // SS:287
+    ctx->feat_attprob = lb.take("classifier.feat_attprob", M, S);  // SS:271
+    ctx->lstm_i2h = lb.take("classifier.attlstm.i2h", 4 * R, M);   // ATTLSTM.lua:6
+    ctx->lstm_h2h = lb.take("classifier.attlstm.h2h", 4 * R, R);   // ATTLSTM.lua:7
+    ctx->lstm_out = lb.take("classifier.lstm_out", M, R);          // SS:279
+    ctx->cls = lb.take("classifier.out_score", K, M);              // SS:280
+    ctx->do_pred = lb.take("classifier.out_do_pred", 1, M);        // SS:281
+    ctx->grp[RAU_GROUP_MULT].n = lb.off;
+  }
+  for (int gi = 0; gi < 3; ++gi) {
+    CK(dalloc(ctx, &ctx->grp[gi].w, ctx->grp[gi].n + 4));
+    CK(dalloc(ctx, &ctx->grp[gi].g, ctx->grp[gi].n + 4));
+  }
+  for (int L = 0; L < 2; ++L) {
+    bind(ctx->i2h[L], ctx->grp[RAU_GROUP_RNN]);
+    bind(ctx->h2h[L], ctx->grp[RAU_GROUP_RNN]);
+  }
+  Lin* ml[] = {&ctx->q_proj, &ctx->h_proj, &ctx->i_embed, &ctx->att_q, &ctx->att_i,
+               &ctx->att_score, &ctx->att_mem, &ctx->feat_attprob, &ctx->lstm_i2h,
+               &ctx->lstm_h2h, &ctx->lstm_out, &ctx->cls, &ctx->do_pred};
+  for (Lin* l : ml) bind(*l, ctx->grp[RAU_GROUP_MULT]);
+
+  // ---- batch
+  CK(dalloc(ctx, &ctx->feats, (size_t)B * D * S));
+  CK(dalloc(ctx, &ctx->tokens, (size_t)T * B));
+  CK(dalloc(ctx, &ctx->lens_d, (size_t)B));
+  CK(dalloc(ctx, &ctx->labels_d, (size_t)B));
+  CK(dalloc(ctx, &ctx->utok, (size_t)T * B));
+  CK(dalloc(ctx, &ctx->ustart, (size_t)T * B + 1));
+  CK(dalloc(ctx, &ctx->upos, (size_t)T * B));
+  // ---- masks (bit-packed, +1 word slack)
+  ctx->mcount[RAU_MASK_WE] = (size_t)T * B * E;
+  ctx->mcount[RAU_MASK_RNN] = (size_t)T * B * Rq;
+  ctx->mcount[RAU_MASK_Q] = (size_t)H * B * Q;
+  ctx->mcount[RAU_MASK_X] = (size_t)H * B * D * S;
+  ctx->mcount[RAU_MASK_MF] = (size_t)H * B * M;
+  for (int i = 0; i < 5; ++i) CK(dalloc(ctx, &ctx->mbits[i], (ctx->mcount[i] + 31) / 32 + 1));
+  // ---- encoder
+  const size_t TB = (size_t)T * B;
+  CK(dalloc(ctx, &ctx->we, TB * E));
+  CK(dalloc(ctx, &ctx->G1, TB * 4 * Rq));
+  CK(dalloc(ctx, &ctx->G2, TB * 4 * Rq));
+  CK(dalloc(ctx, &ctx->c1, (TB + B) * Rq));
+  CK(dalloc(ctx, &ctx->h1, (TB + B) * Rq));
+  CK(dalloc(ctx, &ctx->c2, (TB + B) * Rq));
+  CK(dalloc(ctx, &ctx->h2, (TB + B) * Rq));
+  CK(dalloc(ctx, &ctx->tc1, TB * Rq));
+  CK(dalloc(ctx, &ctx->tc2, TB * Rq));
+  CK(dalloc(ctx, &ctx->x2, TB * Rq));
+  CK(dalloc(ctx, &ctx->q, (size_t)B * Q));
+  // ---- RAU
+  const size_t HB = (size_t)H * B;
+  CK(dalloc(ctx, &ctx->qd, HB * Q));
+  CK(dalloc(ctx, &ctx->Yq, HB * M));
+  CK(dalloc(ctx, &ctx->qf, HB * M));
+  CK(dalloc(ctx, &ctx->I, HB * M * S));
+  CK(dalloc(ctx, &ctx->T, HB * A * S));
+  CK(dalloc(ctx, &ctx->u, (size_t)B * A));
+  CK(dalloc(ctx, &ctx->e_part, (size_t)conv_att_tiles(A) * B * S));
+  CK(dalloc(ctx, &ctx->zm, (size_t)B * S));
+  CK(dalloc(ctx, &ctx->a, HB * S));
+  CK(dalloc(ctx, &ctx->jv, (size_t)B * M));
+  CK(dalloc(ctx, &ctx->j, HB * M));
+  CK(dalloc(ctx, &ctx->g4, HB * 4 * R));
+  CK(dalloc(ctx, &ctx->cc, (HB + B) * R));
+  CK(dalloc(ctx, &ctx->hh, (HB + B) * R));
+  CK(dalloc(ctx, &ctx->tc, HB * R));
+  CK(dalloc(ctx, &ctx->mf, HB * M));
+  CK(dalloc(ctx, &ctx->logits, HB * K));
+  CK(dalloc(ctx, &ctx->dl, HB * K));
+  CK(dalloc(ctx, &ctx->lossrow, HB));
+  CK(dalloc(ctx, &ctx->dopred, HB));
+  CK(dalloc(ctx, &ctx->losses_d, (size_t)H));
+  CK(dalloc(ctx, &ctx->hopw_d, (size_t)H));
+  CK(dalloc(ctx, &ctx->argmax_d, HB));
+  // ---- backward
+  CK(dalloc(ctx, &ctx->dpre, HB * M));
+  CK(dalloc(ctx, &ctx->dhn, (size_t)B * R));
+  CK(dalloc(ctx, &ctx->dg4, HB * 4 * R));
+  for (int i = 0; i < 2; ++i) {
+    CK(dalloc(ctx, &ctx->dcn[i], (size_t)B * R));
+    CK(dalloc(ctx, &ctx->dhp[i], (size_t)B * R));
+  }
+  CK(dalloc(ctx, &ctx->dj, HB * M));
+  CK(dalloc(ctx, &ctx->da_lin, (size_t)B * S));
+  CK(dalloc(ctx, &ctx->da_part, (size_t)((M + 63) / 64) * B * S));
+  CK(dalloc(ctx, &ctx->dz, HB * S));
+  CK(dalloc(ctx, &ctx->du, HB * A));
+  CK(dalloc(ctx, &ctx->dwsp, HB * A));
+  CK(dalloc(ctx, &ctx->dZ, (size_t)B * M * S));
+  CK(dalloc(ctx, &ctx->rsum, HB * M));
+  CK(dalloc(ctx, &ctx->dqt, HB * M));
+  CK(dalloc(ctx, &ctx->dQD, HB * Q));
+  CK(dalloc(ctx, &ctx->dq, (size_t)B * Q));
+  {
+    size_t sl = std::max(conv_wgrad_slab_floats(B, A, M, S), conv_wgrad_slab_floats(B, M, D, S));
+    const int rowsH = H * B, rowsT = T * B;
+    const int shapes[][3] = {{K, M, rowsH},      {M, R, rowsH},      {4 * R, M, rowsH},
+                             {4 * R, R, rowsH},  {M, S, rowsH},      {S, R, rowsH},
+                             {A, M, rowsH},      {M, Q, rowsH},      {4 * Rq, E, rowsT},
+                             {4 * Rq, Rq, rowsT}};
+    for (auto& s : shapes) sl = std::max(sl, gemm_tn_slab_floats(s[0], s[1], s[2]));
+    ctx->slab_floats = sl;
+    CK(dalloc(ctx, &ctx->slab, sl));
+  }
+  {
+    const int widest = std::max({4 * R, 4 * Rq, K, M, S, A, Q});
+    CK(dalloc(ctx, &ctx->coltmp, (size_t)32 * widest));
+    CK(dalloc(ctx, &ctx->tmpS, (size_t)S));
+  }
+  CK(dalloc(ctx, &ctx->dG1, TB * 4 * Rq));
+  CK(dalloc(ctx, &ctx->dG2, TB * 4 * Rq));
+  CK(dalloc(ctx, &ctx->dX2, TB * Rq));
+  CK(dalloc(ctx, &ctx->dwe, TB * E));
+  for (int L = 0; L < 2; ++L) {
+    CK(dalloc(ctx, &ctx->edc[L][0], (size_t)B * Rq));
+    CK(dalloc(ctx, &ctx->edc[L][1], (size_t)B * Rq));
+    CK(dalloc(ctx, &ctx->edh[L], (size_t)B * Rq));
+  }
+  CK(dalloc(ctx, &ctx->npart, (size_t)1024));
+  CK(dalloc(ctx, &ctx->norms_d, (size_t)4));
+#undef CK
+  {
+    hipError_t es = hipStreamSynchronize(ctx->st);
+    if (es != hipSuccess) {
+      rau_destroy(ctx);
+      return fail(RAU_ERR_DEVICE, "rau_create sync: %s", hipGetErrorString(es));
+    }
+  }
+  *out = ctx;
+  return RAU_OK;
+}
+
+void rau_destroy(rau_ctx* ctx) {
+  if (!ctx) return;
+  if (ctx->st) hipStreamSynchronize(ctx->st);
+  for (void* p : ctx->allocs) hipFree(p);
+  for (auto& r : ctx->precs) {
+    hipEventDestroy(r.a);
+    hipEventDestroy(r.b);
+  }
+  for (auto e : ctx->evpool) hipEventDestroy(e);
+  if (ctx->ev0) hipEventDestroy(ctx->ev0);
+  if (ctx->ev1) hipEventDestroy(ctx->ev1);
+  if (ctx->st) hipStreamDestroy(ctx->st);
+  delete ctx;
+}
+
+// ------------------------------------------------------------- parameters
+static int check_group(rau_ctx* ctx, int group) {
+  NEED(ctx, "null ctx");
+  NEED(group >= 0 && group < 3, "bad group %d", group);
+  return 0;
+}
+int rau_params(rau_ctx* ctx, int group, float** weights, float** grads, size_t* n) {
+  if (int rc = check_group(ctx, group)) return rc;
+  if (weights) *weights = ctx->grp[group].w;
+  if (grads) *grads = ctx->grp[group].g;
+  if (n) *n = ctx->grp[group].n;
+  return RAU_OK;
+}
+int rau_layout_count(const rau_ctx* ctx, int group) {
+  if (!ctx || group < 0 || group > 2) return fail(RAU_ERR_INVALID, "bad ctx/group");
+  return (int)ctx->grp[group].layout.size();
+}
+int rau_layout_entry(const rau_ctx* ctx, int group, int index, const char** name, size_t* offset,
+                     int32_t* rows, int32_t* cols) {
+  if (!ctx || group < 0 || group > 2) return fail(RAU_ERR_INVALID, "bad ctx/group");
+  const auto& l = ctx->grp[group].layout;
+  NEED(index >= 0 && index < (int)l.size(), "layout index %d out of range", index);
+  if (name) *name = l[index].name.c_str();
+  if (offset) *offset = l[index].off;
+  if (rows) *rows = l[index].rows;
+  if (cols) *cols = l[index].cols;
+  return RAU_OK;
+}
+static int copy_group(rau_ctx* ctx, int group, bool grads, float* host, const float* chost,
+                      size_t n) {
+  if (int rc = check_group(ctx, group)) return rc;
+  Group& g = ctx->grp[group];
+  NEED(n == g.n, "group %d has %zu floats, caller passed %zu", group, g.n, n);
+  float* dev = grads ? g.g : g.w;
+  if (chost)
+    HIPC(hipMemcpyAsync(dev, chost, n * sizeof(float), hipMemcpyHostToDevice, ctx->st));
+  else
+    HIPC(hipMemcpyAsync(host, dev, n * sizeof(float), hipMemcpyDeviceToHost, ctx->st));
+  HIPC(hipStreamSynchronize(ctx->st));
+  return RAU_OK;
+}
+int rau_set_params(rau_ctx* ctx, int group, const float* host, size_t n) {
+  NEED(host, "null host pointer");
+  return copy_group(ctx, group, false, nullptr, host, n);
+}
+int rau_get_params(rau_ctx* ctx, int group, float* host, size_t n) {
+  NEED(host, "null host pointer");
+  return copy_group(ctx, group, false, host, nullptr, n);
+}
+int rau_get_grads(rau_ctx* ctx, int group, float* host, size_t n) {
+  NEED(host, "null host pointer");
+  return copy_group(ctx, group, true, host, nullptr, n);
+}
+int rau_set_grads(rau_ctx* ctx, int group, const float* host, size_t n) {
+  NEED(host, "null host pointer");
+  return copy_group(ctx, group, true, nullptr, host, n);
+}
+int rau_init_uniform(rau_ctx* ctx, uint64_t seed, float lo, float hi) {
+  NEED(ctx, "null ctx");
+  for (int gi = 0; gi < 3; ++gi)
+    RUN("uniform_fill", 0, ctx->grp[gi].n * 4.0,
+        uniform_fill(ctx->st, seed, (uint32_t)gi, ctx->grp[gi].n, lo, hi, ctx->grp[gi].w));
+  return RAU_OK;
+}
+int rau_zero_grads(rau_ctx* ctx) {
+  NEED(ctx, "null ctx");
+  for (int gi = 0; gi < 3; ++gi)
+    HIPC(hipMemsetAsync(ctx->grp[gi].g, 0, ctx->grp[gi].n * sizeof(float), ctx->st));
+  return RAU_OK;
+}
+
+// ---------------------------------------------------------------- dropout
+int rau_set_mode(rau_ctx* ctx, int mode) {
+  NEED(ctx, "null ctx");
+  NEED(mode == RAU_MODE_TRAIN || mode == RAU_MODE_EVAL, "bad mode %d", mode);
+  ctx->mode = mode;
+  return RAU_OK;
+}
+int rau_set_dropout_seed(rau_ctx* ctx, uint64_t seed, uint32_t step) {
+  NEED(ctx, "null ctx");
+  ctx->seed = seed;
+  ctx->step = step;
+  for (int i = 0; i < 5; ++i) ctx->mexplicit[i] = false;
+  return RAU_OK;
+}
+int rau_set_mask(rau_ctx* ctx, int site, const uint8_t* keep, size_t n) {
+  NEED(ctx && keep, "null argument");
+  NEED(site >= 0 && site < 5, "bad mask site %d", site);
+  NEED(n == ctx->mcount[site], "mask site %d has %zu elements, caller passed %zu", site,
+       ctx->mcount[site], n);
+  std::vector<uint32_t> bits((n + 31) / 32, 0u);
+  for (size_t i = 0; i < n; ++i)
+    if (keep[i]) bits[i >> 5] |= 1u << (i & 31);
+  HIPC(hipMemcpyAsync(ctx->mbits[site], bits.data(), bits.size() * 4, hipMemcpyHostToDevice,
+                      ctx->st));
+  HIPC(hipStreamSynchronize(ctx->st));
+  ctx->mexplicit[site] = true;
+  return RAU_OK;
+}
+static int gen_masks(rau_ctx* ctx) {
+  if (ctx->mode != RAU_MODE_TRAIN) return 0;
+  for (int i = 0; i < 5; ++i)
+    if (!ctx->mexplicit[i] && ctx->mp[i] > 0.f)
+      RUN("fill_masks", 0, ctx->mcount[i] / 8.0,
+          fill_masks(ctx->st, ctx->seed, (uint32_t)i, ctx->step, ctx->mp[i], ctx->mcount[i],
+                     ctx->mbits[i]));
+  return 0;
+}
+int rau_get_mask(rau_ctx* ctx, int site, uint8_t* keep, size_t n) {
+  NEED(ctx && keep, "null argument");
+  NEED(site >= 0 && site < 5, "bad mask site %d", site);
+  NEED(n == ctx->mcount[site], "mask site %d has %zu elements, caller passed %zu", site,
+       ctx->mcount[site], n);
+  if (!ctx->mexplicit[site]) {
+    const int m = ctx->mode;
+    ctx->mode = RAU_MODE_TRAIN;
+    const int rc = gen_masks(ctx);
+    ctx->mode = m;
+    if (rc) return rc;
+  }
+  std::vector<uint32_t> bits((n + 31) / 32);
+  HIPC(hipMemcpyAsync(bits.data(), ctx->mbits[site], bits.size() * 4, hipMemcpyDeviceToHost,
+                      ctx->st));
+  HIPC(hipStreamSynchronize(ctx->st));
+  for (size_t i = 0; i < n; ++i) keep[i] = (bits[i >> 5] >> (i & 31)) & 1u;
+  return RAU_OK;
+}
+
+// ------------------------------------------------------------------ batch
+int rau_set_batch(rau_ctx* ctx, const float* feats, const int32_t* tokens, const int32_t* lens,
+                  const int32_t* labels) {
+  NEED(ctx && tokens && lens, "null argument");
+  const rau_config& c = ctx->cfg;
+  int max_len = 0;
+  for (int b = 0; b < c.B; ++b) {
+    NEED(lens[b] >= 0 && lens[b] <= c.T, "lens[%d]=%d out of [0,%d]", b, lens[b], c.T);
+    max_len = std::max(max_len, lens[b]);
+  }
+  for (size_t i = 0; i < (size_t)c.T * c.B; ++i)
+    NEED(tokens[i] >= 1 && tokens[i] <= c.V, "token %d at %zu out of [1,%d]", tokens[i], i, c.V);
+  if (labels)
+    for (int b = 0; b < c.B; ++b)
+      NEED(labels[b] >= 1 && labels[b] <= c.K, "labels[%d]=%d out of [1,%d]", b, labels[b], c.K);
+  // distinct-token index over the live positions (t < lens[b]): makes the
+  // LookupTable gradient a fixed-order gather-sum.
+  std::vector<std::pair<int32_t, int32_t>> pos;  // (token, position)
+  for (int t = 0; t < max_len; ++t)
+    for (int b = 0; b < c.B; ++b)
+      if (t < lens[b]) pos.push_back({tokens[(size_t)t * c.B + b], t * c.B + b});
+  std::sort(pos.begin(), pos.end());
+  std::vector<int32_t> utok, ustart, upos;
+  for (size_t i = 0; i < pos.size(); ++i) {
+    if (i == 0 || pos[i].first != pos[i - 1].first) {
+      utok.push_back(pos[i].first);
+      ustart.push_back((int32_t)i);
+    }
+    upos.push_back(pos[i].second);
+  }
+  ustart.push_back((int32_t)pos.size());
+  ctx->nuniq = (int)utok.size();
+  if (feats)
+    HIPC(hipMemcpyAsync(ctx->feats, feats, (size_t)c.B * c.D * c.S * sizeof(float),
+                        hipMemcpyHostToDevice, ctx->st));
+  HIPC(hipMemcpyAsync(ctx->tokens, tokens, (size_t)c.T * c.B * 4, hipMemcpyHostToDevice, ctx->st));
+  HIPC(hipMemcpyAsync(ctx->lens_d, lens, (size_t)c.B * 4, hipMemcpyHostToDevice, ctx->st));
+  if (labels)
+    HIPC(hipMemcpyAsync(ctx->labels_d, labels, (size_t)c.B * 4, hipMemcpyHostToDevice, ctx->st));
+  if (!utok.empty()) {
+    HIPC(hipMemcpyAsync(ctx->utok, utok.data(), utok.size() * 4, hipMemcpyHostToDevice, ctx->st));
+    HIPC(hipMemcpyAsync(ctx->upos, upos.data(), upos.size() * 4, hipMemcpyHostToDevice, ctx->st));
+  }
+  HIPC(hipMemcpyAsync(ctx->ustart, ustart.data(), ustart.size() * 4, hipMemcpyHostToDevice,
+                      ctx->st));
+  HIPC(hipStreamSynchronize(ctx->st));
+  ctx->lens_h.assign(lens, lens + c.B);
+  ctx->max_len = max_len;
+  ctx->have_batch = true;
+  ctx->have_labels = labels != nullptr;
+  ctx->fwd_done = false;
+  return RAU_OK;
+}
+int rau_batch_feats(rau_ctx* ctx, float** feats_dev) {
+  NEED(ctx && feats_dev, "null argument");
+  *feats_dev = ctx->feats;
+  return RAU_OK;
+}
+
+// ================================================================ forward
+int rau_forward(rau_ctx* ctx) {
+  NEED(ctx, "null ctx");
+  if (!ctx->have_batch) return fail(RAU_ERR_STATE, "rau_forward: no batch (call rau_set_batch)");
+  const rau_config& c = ctx->cfg;
+  const int B = c.B, E = c.E, Rq = c.Rq, D = c.D, S = c.S, M = c.M, A = c.A, R = c.R, K = c.K,
+            H = c.H, Q = ctx->Q;
+  const int TL = ctx->max_len;
+  hipStream_t st = ctx->st;
+  if (int rc = gen_masks(ctx)) return rc;
+  const bool tr = ctx->mode == RAU_MODE_TRAIN;
+  auto mk = [&](int site) -> const uint32_t* {
+    return (tr && ctx->mp[site] > 0.f) ? ctx->mbits[site] : nullptr;
+  };
+  auto sc = [&](int site) { return 1.f / (1.f - ctx->mp[site]); };
+  const uint32_t *m_we = mk(RAU_MASK_WE), *m_rnn = mk(RAU_MASK_RNN), *m_q = mk(RAU_MASK_Q),
+                 *m_x = mk(RAU_MASK_X), *m_mf = mk(RAU_MASK_MF);
+  const size_t BRq = (size_t)B * Rq;
+  auto gflop = [](double m, double n, double k) { return 2.0 * m * n * k; };
+
+  // ---------------- encoder, SS:443-462
+  if (TL > 0) {
+    const int rows = TL * B;
+    RUN("embed_fwd", 0, rows * E * 8.0,
+        embed_fwd(st, rows, E, ctx->grp[RAU_GROUP_EMBED].w, ctx->tokens, m_we, sc(RAU_MASK_WE),
+                  ctx->we));
+    for (int L = 0; L < 2; ++L) {
+      float* G = L == 0 ? ctx->G1 : ctx->G2;
+      float* cs = L == 0 ? ctx->c1 : ctx->c2;
+      float* hs = L == 0 ? ctx->h1 : ctx->h2;
+      float* tcs = L == 0 ? ctx->tc1 : ctx->tc2;
+      const float* xin = L == 0 ? ctx->we : ctx->x2;
+      const int kin = L == 0 ? E : Rq;
+      LinOpts o;
+      o.bias = ctx->i2h[L].b;
+      o.bias2 = ctx->h2h[L].b;
+      // input projection of every token at once (no recurrence in it)
+      RUN("enc_i2h_gemm", gflop(rows, 4 * Rq, kin), 0,
+          gemm_nt(st, rows, 4 * Rq, kin, xin, kin, ctx->i2h[L].W, kin, G, 4 * Rq, o));
+      for (int t = 1; t <= TL; ++t) {
+        float* Gt = G + (size_t)(t - 1) * B * 4 * Rq;
+        if (t > 1) {
+          LinOpts oa;
+          oa.accumulate = 1;
+          RUN("enc_h2h_gemm", gflop(B, 4 * Rq, Rq), 0,
+              gemm_nt(st, B, 4 * Rq, Rq, hs + (size_t)(t - 1) * BRq, Rq, ctx->h2h[L].W, Rq, Gt,
+                      4 * Rq, oa));
+        }
+        RUN("lstm_fwd", 0, BRq * 4.0 * 10,
+            lstm_fwd(st, GATES_DEEP, B, Rq, Gt, cs + (size_t)(t - 1) * BRq, Rq,
+                     cs + (size_t)t * BRq, Rq, hs + (size_t)t * BRq, Rq,
+                     tcs + (size_t)(t - 1) * BRq, L == 0 ? ctx->x2 + (size_t)(t - 1) * BRq : nullptr,
+                     m_rnn, (size_t)(t - 1) * BRq, sc(RAU_MASK_RNN)));
+      }
+    }
+  }
+  RUN("gather_q", 0, (double)B * Q * 8,
+      gather_q(st, B, Rq, TL, ctx->lens_d, ctx->c1, ctx->h1, ctx->c2, ctx->h2, ctx->q));
+
+  // ---------------- RAU hops, SS:467-520
+  const size_t BM_ = (size_t)B * M, BS_ = (size_t)B * S, BR_ = (size_t)B * R;
+  RUN("apply_mask", 0, (double)H * B * Q * 8,
+      apply_mask(st, (size_t)H * B * Q, (size_t)B * Q, ctx->q, m_q, sc(RAU_MASK_Q), ctx->qd));
+  {
+    LinOpts o;
+    o.bias = ctx->q_proj.b;
+    o.bias2 = ctx->h_proj.b;
+    RUN("q_proj_gemm", gflop(H * B, M, Q), 0,
+        gemm_nt(st, H * B, M, Q, ctx->qd, Q, ctx->q_proj.W, Q, ctx->Yq, M, o));
+  }
+  HIPC(hipMemsetAsync(ctx->cc, 0, BR_ * sizeof(float), st));  // att_c, att_h zeros SS:362-365
+  HIPC(hipMemsetAsync(ctx->hh, 0, BR_ * sizeof(float), st));
+  const int parts = conv_att_tiles(A);
+  for (int h = 0; h < H; ++h) {
+    const float* hp = ctx->hh + (size_t)h * BR_;
+    const float* cp = ctx->cc + (size_t)h * BR_;
+    float* qf = ctx->qf + (size_t)h * BM_;
+    float* Ih = ctx->I + (size_t)h * BM_ * S;
+    float* Th = ctx->T + (size_t)h * B * A * S;
+    float* ah = ctx->a + (size_t)h * BS_;
+    float* jh = ctx->j + (size_t)h * BM_;
+    float* g4 = ctx->g4 + (size_t)h * B * 4 * R;
+    float* mfh = ctx->mf + (size_t)h * BM_;
+    float* lg = ctx->logits + (size_t)h * B * K;
+    {  // q_embed SS:231-236
+      LinOpts o;
+      o.addend = ctx->Yq + (size_t)h * BM_;
+      o.add_rs = M;
+      o.act = 1;
+      RUN("small_gemm", gflop(B, M, R), 0, gemm_nt(st, B, M, R, hp, R, ctx->h_proj.W, R, qf, M, o));
+    }
+    // i_embed SS:238-242 (dropout applied while staging X)
+    RUN("conv_embed_fwd", gflop(M, (double)B * S, D), ((double)B * D * S + BM_ * S) * 4,
+        conv_embed_fwd(st, B, D, S, M, ctx->feats, m_x, (size_t)h * B * D * S, sc(RAU_MASK_X),
+                       ctx->i_embed.W, ctx->i_embed.b, Ih));
+    {  // attbycontent SS:244-252
+      LinOpts o;
+      o.bias = ctx->att_q.b;
+      RUN("small_gemm", gflop(B, A, M), 0, gemm_nt(st, B, A, M, qf, M, ctx->att_q.W, M, ctx->u, A, o));
+    }
+    RUN("conv_att_fwd", gflop(A, (double)B * S, M), (BM_ * S + (double)B * A * S) * 4,
+        conv_att_fwd(st, B, M, S, A, Ih, ctx->att_i.W, ctx->att_i.b, ctx->u, ctx->att_score.W, Th,
+                     ctx->e_part));
+    {  // attbymemory SS:285-290
+      LinOpts o;
+      o.bias = ctx->att_mem.b;
+      RUN("small_gemm", gflop(B, S, R), 0, gemm_nt(st, B, S, R, hp, R, ctx->att_mem.W, R, ctx->zm, S, o));
+    }
+    RUN("softmax_fwd", 0, BS_ * 16.0,
+        softmax_fwd(st, B, S, ctx->e_part, parts, (long)BS_, ctx->att_score.b, ctx->zm, ah));
+    // attselect SS:254-263 (+ qf, first CAddTable of SS:270)
+    RUN("attselect_fwd", 2.0 * BM_ * S, BM_ * S * 4.0,
+        attselect_fwd(st, B, M, S, Ih, ah, qf, ctx->jv));
+    {  // classifier SS:265-283
+      LinOpts o;
+      o.bias = ctx->feat_attprob.b;
+      o.addend = ctx->jv;
+      o.add_rs = M;
+      RUN("small_gemm", gflop(B, M, S), 0, gemm_nt(st, B, M, S, ah, S, ctx->feat_attprob.W, S, jh, M, o));
+    }
+    {
+      LinOpts o;
+      o.bias = ctx->lstm_i2h.b;
+      o.bias2 = ctx->lstm_h2h.b;
+      RUN("small_gemm", gflop(B, 4 * R, M), 0,
+          gemm_nt(st, B, 4 * R, M, jh, M, ctx->lstm_i2h.W, M, g4, 4 * R, o));
+      LinOpts oa;
+      oa.accumulate = 1;
+      RUN("small_gemm", gflop(B, 4 * R, R), 0,
+          gemm_nt(st, B, 4 * R, R, hp, R, ctx->lstm_h2h.W, R, g4, 4 * R, oa));
+    }
+    RUN("lstm_fwd", 0, BR_ * 4.0 * 10,
+        lstm_fwd(st, GATES_ATT, B, R, g4, cp, R, ctx->cc + (size_t)(h + 1) * BR_, R,
+                 ctx->hh + (size_t)(h + 1) * BR_, R, ctx->tc + (size_t)h * BR_, nullptr, nullptr, 0,
+                 1.f));
+    {
+      LinOpts o;
+      o.bias = ctx->lstm_out.b;
+      o.addend = jh;
+      o.add_rs = M;
+      o.emask = m_mf;
+      o.emask_e0 = (size_t)h * BM_;
+      o.emscale = sc(RAU_MASK_MF);
+      RUN("small_gemm", gflop(B, M, R), 0,
+          gemm_nt(st, B, M, R, ctx->hh + (size_t)(h + 1) * BR_, R, ctx->lstm_out.W, R, mfh, M, o));
+    }
+    {
+      LinOpts o;
+      o.bias = ctx->cls.b;
+      RUN("small_gemm", gflop(B, K, M), 0, gemm_nt(st, B, K, M, mfh, M, ctx->cls.W, M, lg, K, o));
+    }
+    RUN("ce_fwd", 0, (double)B * K * 12,
+        ce_fwd(st, B, K, M, lg, ctx->have_labels ? ctx->labels_d : nullptr, mfh, ctx->do_pred.W,
+               ctx->do_pred.b, ctx->dl + (size_t)h * B * K, ctx->lossrow + (size_t)h * B,
+               ctx->argmax_d + (size_t)h * B, ctx->dopred + (size_t)h * B));
+  }
+  if (ctx->have_labels)
+    RUN("loss_reduce", 0, 0, loss_reduce(st, H, B, ctx->lossrow, ctx->losses_d));
+  ctx->fwd_done = true;
+  return RAU_OK;
+}
+
+// =============================================================== backward
+int rau_backward(rau_ctx* ctx, const float* hop_w) {
+  NEED(ctx && hop_w, "null argument");
+  if (!ctx->fwd_done) return fail(RAU_ERR_STATE, "rau_backward: call rau_forward first");
+  if (!ctx->have_labels) return fail(RAU_ERR_STATE, "rau_backward: batch has no labels");
+  const rau_config& c = ctx->cfg;
+  const int B = c.B, E = c.E, Rq = c.Rq, D = c.D, S = c.S, M = c.M, A = c.A, R = c.R, K = c.K,
+            H = c.H, Q = ctx->Q;
+  const int TL = ctx->max_len;
+  hipStream_t st = ctx->st;
+  const bool tr = ctx->mode == RAU_MODE_TRAIN;
+  auto mk = [&](int site) -> const uint32_t* {
+    return (tr && ctx->mp[site] > 0.f) ? ctx->mbits[site] : nullptr;
+  };
+  auto sc = [&](int site) { return 1.f / (1.f - ctx->mp[site]); };
+  const uint32_t *m_we = mk(RAU_MASK_WE), *m_rnn = mk(RAU_MASK_RNN), *m_q = mk(RAU_MASK_Q),
+                 *m_x = mk(RAU_MASK_X), *m_mf = mk(RAU_MASK_MF);
+  auto gflop = [](double m, double n, double k) { return 2.0 * m * n * k; };
+  const size_t BM_ = (size_t)B * M, BS_ = (size_t)B * S, BR_ = (size_t)B * R;
+  const size_t BRq = (size_t)B * Rq;
+  ctx->fwd_done = false;  // dl is scaled in place below: one backward per forward
+
+  // dpred:mul(w[h])  SS:569 / MS:568-570 / Full:587-589
+  HIPC(hipMemcpyAsync(ctx->hopw_d, hop_w, H * sizeof(float), hipMemcpyHostToDevice, st));
+  RUN("scale_hops", 0, (double)H * B * K * 8, scale_hops(st, H, (size_t)B * K, ctx->hopw_d, ctx->dl));
+
+  // ---------------- RAU BPTT, SS:561-578
+  const float* dc_next = nullptr;  // grad_att_c / grad_att_h zeros, SS:561-562
+  const float* dh_next = nullptr;
+  const int chunks = (M + 63) / 64;
+  for (int h = H - 1; h >= 0; --h) {
+    const float* hp = ctx->hh + (size_t)h * BR_;
+    const float* cp = ctx->cc + (size_t)h * BR_;
+    const float* qf = ctx->qf + (size_t)h * BM_;
+    const float* Ih = ctx->I + (size_t)h * BM_ * S;
+    const float* Th = ctx->T + (size_t)h * B * A * S;
+    const float* ah = ctx->a + (size_t)h * BS_;
+    const float* g4 = ctx->g4 + (size_t)h * B * 4 * R;
+    float* dpre = ctx->dpre + (size_t)h * BM_;
+    float* dg4 = ctx->dg4 + (size_t)h * B * 4 * R;
+    float* djh = ctx->dj + (size_t)h * BM_;
+    float* dzh = ctx->dz + (size_t)h * BS_;
+    float* duh = ctx->du + (size_t)h * B * A;
+    float* dqt = ctx->dqt + (size_t)h * BM_;
+    float* dc_out = ctx->dcn[h & 1];
+    float* dh_out = ctx->dhp[h & 1];
+    {  // dmf = dlogits Wc ; dpre = dmf (.) mask   (do_pred grad is zero, SS:566)
+      LinOpts o;
+      o.emask = m_mf;
+      o.emask_e0 = (size_t)h * BM_;
+      o.emscale = sc(RAU_MASK_MF);
+      RUN("small_gemm", gflop(B, M, K), 0,
+          gemm_nn(st, B, M, K, ctx->dl + (size_t)h * B * K, K, ctx->cls.W, M, dpre, M, o));
+    }
+    {  // dhn = dpre Wo + dh_next
+      LinOpts o;
+      o.addend = dh_next;
+      o.add_rs = R;
+      RUN("small_gemm", gflop(B, R, M), 0, gemm_nn(st, B, R, M, dpre, M, ctx->lstm_out.W, R, ctx->dhn, R, o));
+    }
+    RUN("lstm_bwd", 0, BR_ * 4.0 * 12,
+        lstm_bwd(st, GATES_ATT, B, R, g4, cp, R, ctx->tc + (size_t)h * BR_, ctx->dhn, R, nullptr,
+                 dc_next, dg4, dc_out, nullptr, 0, nullptr, nullptr, 0));
+    {  // dj = dpre + dg Wx ; dh_prev = dg Wr
+      LinOpts o;
+      o.addend = dpre;
+      o.add_rs = M;
+      RUN("small_gemm", gflop(B, M, 4 * R), 0,
+          gemm_nn(st, B, M, 4 * R, dg4, 4 * R, ctx->lstm_i2h.W, M, djh, M, o));
+      LinOpts o2;
+      RUN("small_gemm", gflop(B, R, 4 * R), 0,
+          gemm_nn(st, B, R, 4 * R, dg4, 4 * R, ctx->lstm_h2h.W, R, dh_out, R, o2));
+    }
+    {  // da = dj Wf  (+ attselect term below)
+      LinOpts o;
+      RUN("small_gemm", gflop(B, S, M), 0,
+          gemm_nn(st, B, S, M, djh, M, ctx->feat_attprob.W, S, ctx->da_lin, S, o));
+    }
+    RUN("attselect_bwd", 2.0 * BM_ * S, BM_ * S * 4.0,
+        attselect_bwd(st, B, M, S, Ih, djh, ctx->da_part));
+    RUN("softmax_bwd", 0, BS_ * 4.0 * (chunks + 4),
+        softmax_bwd(st, B, S, ah, ctx->da_lin, ctx->da_part, chunks, (long)BS_, dzh));
+    {  // dh_prev += dz Wm
+      LinOpts o;
+      o.accumulate = 1;
+      RUN("small_gemm", gflop(B, R, S), 0, gemm_nn(st, B, R, S, dzh, S, ctx->att_mem.W, R, dh_out, R, o));
+    }
+    RUN("att_score_bwd", 4.0 * B * A * S, (double)B * A * S * 4,
+        att_score_bwd(st, B, A, S, Th, dzh, ctx->att_score.W, duh, ctx->dwsp + (size_t)h * B * A));
+    RUN("conv_att_dgrad", gflop(M, (double)B * S, A), ((double)B * A * S + 2.0 * BM_ * S) * 4,
+        conv_att_dgrad(st, B, M, S, A, Th, dzh, ctx->att_score.W, ctx->att_i.W, djh, ah, Ih, ctx->dZ));
+    RUN("conv_att_wgrad", gflop(A, M, (double)B * S), ((double)B * A * S + BM_ * S) * 4,
+        conv_att_wgrad(st, B, M, S, A, Th, dzh, ctx->att_score.W, Ih, ctx->att_i.dW, ctx->slab));
+    RUN("row_sums", 0, BM_ * S * 4.0, row_sums(st, B * M, S, ctx->dZ, ctx->rsum + (size_t)h * BM_));
+    RUN("conv_embed_wgrad", gflop(M, D, (double)B * S), (BM_ * S + (double)B * D * S) * 4,
+        conv_embed_wgrad(st, B, D, S, M, ctx->dZ, ctx->feats, m_x, (size_t)h * B * D * S,
+                         sc(RAU_MASK_X), ctx->i_embed.dW, ctx->slab));
+    {  // dq~ = (dj + du Wa) (1 - qf^2)
+      LinOpts o;
+      o.addend = djh;
+      o.add_rs = M;
+      o.ymul = qf;
+      o.y_rs = M;
+      RUN("small_gemm", gflop(B, M, A), 0, gemm_nn(st, B, M, A, duh, A, ctx->att_q.W, M, dqt, M, o));
+      LinOpts o2;
+      o2.accumulate = 1;
+      RUN("small_gemm", gflop(B, R, M), 0, gemm_nn(st, B, R, M, dqt, M, ctx->h_proj.W, R, dh_out, R, o2));
+    }
+    dc_next = dc_out;
+    dh_next = dh_out;
+  }
+  {  // dq = sum_h (dq~_h Wq) (.) mask_h     (ConcatTable backward, SS:579)
+    LinOpts o;
+    RUN("q_proj_dgrad", gflop(H * B, Q, M), 0,
+        gemm_nn(st, H * B, Q, M, ctx->dqt, M, ctx->q_proj.W, Q, ctx->dQD, Q, o));
+    RUN("dq_reduce", 0, (double)H * B * Q * 4,
+        dq_reduce(st, H, (size_t)B * Q, ctx->dQD, m_q, sc(RAU_MASK_Q), ctx->dq));
+  }
+  // ---------------- mult-group weight gradients, one GEMM per weight over all hops
+  {
+    const int rows = H * B;
+    const float* hprev = ctx->hh;            // h_{0..H-1}
+    const float* hnew = ctx->hh + BR_;       // h_{1..H}
+    struct WG { Lin* l; const float* dY; const float* X; };
+    const WG wgs[] = {
+        {&ctx->cls, ctx->dl, ctx->mf},           {&ctx->lstm_out, ctx->dpre, hnew},
+        {&ctx->lstm_i2h, ctx->dg4, ctx->j},      {&ctx->lstm_h2h, ctx->dg4, hprev},
+        {&ctx->feat_attprob, ctx->dj, ctx->a},   {&ctx->att_mem, ctx->dz, hprev},
+        {&ctx->att_q, ctx->du, ctx->qf},         {&ctx->q_proj, ctx->dqt, ctx->qd},
+        {&ctx->h_proj, ctx->dqt, hprev}};
+    for (const WG& w : wgs) {
+      RUN("wgrad_gemm", gflop(w.l->out, w.l->in, rows), 0,
+          gemm_tn_acc(st, w.l->out, w.l->in, rows, w.dY, w.l->out, w.X, w.l->in, w.l->dW, w.l->in,
+                      ctx->slab));
+      RUN("colsum", 0, (double)rows * w.l->out * 4,
+          colsum_acc(st, rows, w.l->out, w.dY, w.l->out, w.l->db, ctx->coltmp));
+    }
+    // att_score: dws = sum dz T ; dbs = sum dz.  att_i bias: sum dS.  i_embed bias: sum dZ.
+    RUN("colsum", 0, (double)rows * A * 4, colsum_acc(st, rows, A, ctx->dwsp, A, ctx->att_score.dW, ctx->coltmp));
+    HIPC(hipMemsetAsync(ctx->tmpS, 0, S * sizeof(float), st));
+    RUN("colsum", 0, (double)rows * S * 4, colsum_acc(st, rows, S, ctx->dz, S, ctx->tmpS, ctx->coltmp));
+    RUN("colsum", 0, S * 4.0, colsum_acc(st, S, 1, ctx->tmpS, 1, ctx->att_score.db, ctx->coltmp));
+    RUN("colsum", 0, (double)rows * A * 4, colsum_acc(st, rows, A, ctx->du, A, ctx->att_i.db, ctx->coltmp));
+    RUN("colsum", 0, (double)rows * M * 4, colsum_acc(st, rows, M, ctx->rsum, M, ctx->i_embed.db, ctx->coltmp));
+  }
+
+  // ---------------- encoder BPTT, SS:581-596
+  if (TL > 0) {
+    const int rows = TL * B;
+    for (int L = 1; L >= 0; --L) {
+      const float* G = L == 0 ? ctx->G1 : ctx->G2;
+      const float* cs = L == 0 ? ctx->c1 : ctx->c2;
+      const float* tcs = L == 0 ? ctx->tc1 : ctx->tc2;
+      float* dG = L == 0 ? ctx->dG1 : ctx->dG2;
+      const float* dc_n = nullptr;
+      const float* dh_rec = nullptr;
+      for (int t = TL; t >= 1; --t) {
+        float* dGt = dG + (size_t)(t - 1) * B * 4 * Rq;
+        float* dc_o = ctx->edc[L][t & 1];
+        RUN("lstm_bwd", 0, BRq * 4.0 * 12,
+            lstm_bwd(st, GATES_DEEP, B, Rq, G + (size_t)(t - 1) * B * 4 * Rq,
+                     cs + (size_t)(t - 1) * BRq, Rq, tcs + (size_t)(t - 1) * BRq, dh_rec, Rq,
+                     L == 0 ? ctx->dX2 + (size_t)(t - 1) * BRq : nullptr, dc_n, dGt, dc_o,
+                     ctx->lens_d, t, ctx->dq + 2 * L * Rq, ctx->dq + (2 * L + 1) * Rq, Q));
+        if (t > 1) {
+          LinOpts o;
+          RUN("enc_h2h_dgrad", gflop(B, Rq, 4 * Rq), 0,
+              gemm_nn(st, B, Rq, 4 * Rq, dGt, 4 * Rq, ctx->h2h[L].W, Rq, ctx->edh[L], Rq, o));
+        }
+        dc_n = dc_o;
+        dh_rec = ctx->edh[L];
+      }
+      if (L == 1) {  // gradient into layer 1's output through the inter-layer dropout
+        LinOpts o;
+        o.emask = m_rnn;
+        o.emask_e0 = 0;
+        o.emscale = sc(RAU_MASK_RNN);
+        RUN("enc_i2h_dgrad", gflop(rows, Rq, 4 * Rq), 0,
+            gemm_nn(st, rows, Rq, 4 * Rq, ctx->dG2, 4 * Rq, ctx->i2h[1].W, Rq, ctx->dX2, Rq, o));
+      } else {
+        LinOpts o;
+        RUN("enc_i2h_dgrad", gflop(rows, E, 4 * Rq), 0,
+            gemm_nn(st, rows, E, 4 * Rq, ctx->dG1, 4 * Rq, ctx->i2h[0].W, E, ctx->dwe, E, o));
+      }
+    }
+    RUN("embed_bwd", 0, (double)rows * E * 12,
+        embed_bwd(st, ctx->nuniq, E, ctx->utok, ctx->ustart, ctx->upos, ctx->dwe, ctx->we, m_we,
+                  sc(RAU_MASK_WE), ctx->grp[RAU_GROUP_EMBED].g));
+    struct WG { Lin* l; const float* dY; const float* X; };
+    const WG wgs[] = {{&ctx->i2h[0], ctx->dG1, ctx->we}, {&ctx->h2h[0], ctx->dG1, ctx->h1},
+                      {&ctx->i2h[1], ctx->dG2, ctx->x2}, {&ctx->h2h[1], ctx->dG2, ctx->h2}};
+    for (const WG& w : wgs) {
+      RUN("wgrad_gemm", gflop(w.l->out, w.l->in, rows), 0,
+          gemm_tn_acc(st, w.l->out, w.l->in, rows, w.dY, w.l->out, w.X, w.l->in, w.l->dW, w.l->in,
+                      ctx->slab));
+      RUN("colsum", 0, (double)rows * w.l->out * 4,
+          colsum_acc(st, rows, w.l->out, w.dY, w.l->out, w.l->db, ctx->coltmp));
+    }
+  }
+  return RAU_OK;
+}
+
+// ================================================================ results
+int rau_sync(rau_ctx* ctx) {
+  NEED(ctx, "null ctx");
+  HIPC(hipStreamSynchronize(ctx->st));
+  return RAU_OK;
+}
+static int d2h(rau_ctx* ctx, void* host, const void* dev, size_t bytes) {
+  NEED(ctx && host, "null argument");
+  HIPC(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, ctx->st));
+  HIPC(hipStreamSynchronize(ctx->st));
+  return RAU_OK;
+}
+int rau_get_losses(rau_ctx* ctx, float* losses) {
+  NEED(ctx, "null ctx");
+  return d2h(ctx, losses, ctx->losses_d, ctx->cfg.H * sizeof(float));
+}
+int rau_get_argmax(rau_ctx* ctx, int32_t* ans) {
+  NEED(ctx, "null ctx");
+  return d2h(ctx, ans, ctx->argmax_d, (size_t)ctx->cfg.H * ctx->cfg.B * 4);
+}
+int rau_get_logits(rau_ctx* ctx, float* logits) {
+  NEED(ctx, "null ctx");
+  return d2h(ctx, logits, ctx->logits, (size_t)ctx->cfg.H * ctx->cfg.B * ctx->cfg.K * 4);
+}
+int rau_get_dopred(rau_ctx* ctx, float* dopred) {
+  NEED(ctx, "null ctx");
+  return d2h(ctx, dopred, ctx->dopred, (size_t)ctx->cfg.H * ctx->cfg.B * 4);
+}
+int rau_get_attention(rau_ctx* ctx, float* att) {
+  NEED(ctx, "null ctx");
+  return d2h(ctx, att, ctx->a, (size_t)ctx->cfg.H * ctx->cfg.B * ctx->cfg.S * 4);
+}
+int rau_get_question_state(rau_ctx* ctx, float* q) {
+  NEED(ctx, "null ctx");
+  return d2h(ctx, q, ctx->q, (size_t)ctx->cfg.B * ctx->Q * 4);
+}
+int rau_get_att_state(rau_ctx* ctx, float* c, float* h) {
+  NEED(ctx, "null ctx");
+  const size_t BR_ = (size_t)ctx->cfg.B * ctx->cfg.R, n = (size_t)ctx->cfg.H * BR_;
+  if (c)
+    if (int rc = d2h(ctx, c, ctx->cc + BR_, n * 4)) return rc;
+  if (h)
+    if (int rc = d2h(ctx, h, ctx->hh + BR_, n * 4)) return rc;
+  return RAU_OK;
+}
+
+// ================================================================= update
+int rau_noise_clip_adam(rau_ctx* ctx, int64_t step_t, float lr, float mult_lr, float beta1,
+                        float beta2, float eps, float eta, float gamma, float clip,
+                        uint64_t noise_seed, float* out_norms) {
+  NEED(ctx, "null ctx");
+  NEED(step_t >= 0 && gamma > 0.f && eta >= 0.f && clip > 0.f, "bad update hyper-parameters");
+  hipStream_t st = ctx->st;
+  // SS:598-599: var = eta / ((step_t+1) * gamma)
+  const float nstd = eta > 0.f ? std::sqrt(eta / ((float)(step_t + 1) * gamma)) : 0.f;
+  for (int gi = 0; gi < 3; ++gi) {
+    Group& g = ctx->grp[gi];
+    if (!g.m) {
+      if (int rc = dalloc(ctx, &g.m, g.n)) return rc;
+      if (int rc = dalloc(ctx, &g.v, g.n)) return rc;
+    }
+    g.adam_t += 1;
+    const double bc1 = 1.0 - std::pow((double)beta1, (double)g.adam_t);
+    const double bc2 = 1.0 - std::pow((double)beta2, (double)g.adam_t);
+    const float group_lr = gi == RAU_GROUP_MULT ? mult_lr : lr;  // SS:770-772
+    const float stepsize = (float)(group_lr * std::sqrt(bc2) / bc1);
+    RUN("noise_sqnorm", 0, g.n * 8.0,
+        add_noise_sqnorm(st, g.n, g.g, nstd, noise_seed + (uint64_t)step_t * 3 + gi, (uint32_t)gi,
+                         ctx->npart));
+    RUN("finish_norm", 0, 0, finish_norm(st, 1024, ctx->npart, ctx->norms_d + gi));
+    RUN("clip_adam", 0, g.n * 28.0,
+        clip_adam(st, g.n, g.w, g.g, g.m, g.v, ctx->norms_d + gi, clip, stepsize, beta1, beta2, eps));
+  }
+  if (out_norms) return d2h(ctx, out_norms, ctx->norms_d, 3 * sizeof(float));
+  return RAU_OK;
+}
+
+// ================================================================= timing
+int rau_stream(rau_ctx* ctx, void** hip_stream) {
+  NEED(ctx && hip_stream, "null argument");
+  *hip_stream = (void*)ctx->st;
+  return RAU_OK;
+}
+int rau_timer_begin(rau_ctx* ctx) {
+  NEED(ctx, "null ctx");
+  HIPC(hipEventRecord(ctx->ev0, ctx->st));
+  return RAU_OK;
+}
+int rau_timer_end(rau_ctx* ctx, float* ms) {
+  NEED(ctx && ms, "null argument");
+  HIPC(hipEventRecord(ctx->ev1, ctx->st));
+  HIPC(hipEventSynchronize(ctx->ev1));
+  HIPC(hipEventElapsedTime(ms, ctx->ev0, ctx->ev1));
+  return RAU_OK;
+}
+int rau_prof_enable(rau_ctx* ctx, int on) {
+  NEED(ctx, "null ctx");
+  if (!on)
+    if (int rc = prof_collect(ctx)) return rc;
+  ctx->prof_on = on != 0;
+  return RAU_OK;
+}
+int rau_prof_reset(rau_ctx* ctx) {
+  NEED(ctx, "null ctx");
+  if (int rc = prof_collect(ctx)) return rc;
+  ctx->pcls.clear();
+  return RAU_OK;
+}
+int rau_prof_count(rau_ctx* ctx) {
+  if (!ctx) return fail(RAU_ERR_INVALID, "null ctx");
+  if (int rc = prof_collect(ctx)) return rc;
+  return (int)ctx->pcls.size();
+}
+int rau_prof_entry(rau_ctx* ctx, int index, const char** name, int64_t* launches, double* total_ms,
+                   double* flops, double* bytes) {
+  NEED(ctx, "null ctx");
+  NEED(index >= 0 && index < (int)ctx->pcls.size(), "prof index %d out of range", index);
+  const ProfCls& p = ctx->pcls[index];
+  if (name) *name = p.name.c_str();
+  if (launches) *launches = p.launches;
+  if (total_ms) *total_ms = p.ms;
+  if (flops) *flops = p.flops;
+  if (bytes) *bytes = p.bytes;
+  return RAU_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,87 @@
+"""GPU parity: librau.so (HIP, through the C ABI) against the CPU oracle.
+
+Bar (BASELINE.json north_star): integer answer indices bit-exact, fp32
+logits / gradients within 1e-4 relative (max-norm per tensor) of the oracle,
+here evaluated against the oracle in float64 on the same seeded inputs and the
+same explicit dropout masks.
+"""
+import numpy as np
+import pytest
+
+import oracle
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+
+
+def run_gpu(sh, batch, params, masks, hop_w, mode="train"):
+    from rau_vqa_amd.model import RAU, Config
+    cfg = Config(**{k: getattr(sh, k) for k in
+                    ("B", "T", "V", "E", "Rq", "D", "S", "M", "A", "R", "K", "H",
+                     "p_we", "p_rnn", "p_q", "p_x", "p_mf")})
+    m = RAU(cfg)
+    m.set_params(params)
+    if mode == "train":
+        m.training()
+        m.set_masks(masks)
+    else:
+        m.evaluate()
+    m.set_batch(batch["feats"], batch["tokens"], batch["lens"], batch["labels"])
+    m.zero_grads()
+    m.forward()
+    out = m.outputs()
+    m.backward(hop_w)
+    g = m.get_grads()
+    out.update({"g_embed": g["embed"], "g_rnn": g["rnn"], "g_mult": g["mult"]})
+    layouts = {k: m.layout(k) for k in ("embed", "rnn", "mult")}
+    m.close()
+    return out, layouts
+
+
+def check(sh, seed=123, lens="ragged", mode="train", hop_w=None, scale=None):
+    batch, params, masks = util.make_problem(sh, seed=seed, lens=lens, scale=scale)
+    if hop_w is None:
+        hop_w = np.full(sh.H, float(sh.H), np.float32)
+    ref = oracle.step(sh, params, batch["feats"], batch["tokens"], batch["lens"],
+                      batch["labels"], masks if mode == "train" else None, hop_w,
+                      dtype=np.float64)
+    got, layouts = run_gpu(sh, batch, params, masks, hop_w, mode)
+    errs = {}
+    for k in util.OUT_KEYS:
+        errs[k] = util.rel_err(got[k], ref[k])
+    for grp in ("embed", "rnn", "mult"):
+        for name, sl in util.layer_slices(layouts[grp]):
+            r = ref["g_" + grp][sl]
+            if np.max(np.abs(r)) < 1e-12:   # e.g. att_score bias grad == 0 analytically
+                errs[name] = float(np.max(np.abs(got["g_" + grp][sl] - r)))
+            else:
+                errs[name] = util.rel_err(got["g_" + grp][sl], r)
+    bad = {k: v for k, v in errs.items() if not v < TOL}
+    assert not bad, f"relative errors above {TOL}: {bad}\nall: {errs}"
+    ok, decided, total = util.argmax_margin_ok(ref["logits"], got["argmax"], ref["argmax"])
+    assert ok, "argmax mismatch on a decided row"
+    return errs
+
+
+def test_small_train():
+    check(util.shapes(util.SMALL), scale=0.5)
+
+
+def test_edge_minimal_dims():
+    check(util.shapes(util.EDGE), scale=0.5)
+
+
+def test_small_eval_mode():
+    check(util.shapes(util.SMALL), mode="eval", scale=0.5)
+
+
+def test_medium_ragged_s196_k1000():
+    check(util.shapes(util.MEDIUM), scale=0.2)
+
+
+def test_zero_length_rows_and_hop_gating():
+    sh = util.shapes(util.SMALL)
+    lens = np.array([0, 6, 1, 3, 6, 2, 0, 4], np.int32)
+    check(sh, lens=lens, hop_w=np.array([1.0, 0.0, 1.0], np.float32), scale=0.5)
