@@ -1,0 +1,221 @@
+#!/usr/bin/env python3
+"""bench.py -- QA-pairs/s of the RAU forward+backward on MI355X (BASELINE.json metric).
+
+  python bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1]): Ours_SS 8-step RAU, batch 256 PER GPU,
+14x14x512 features, 26-token questions (all full length), fp32, training mode
+(dropout active, Philox masks regenerated each step), SS hop weights (x nHop).
+One "step" = zero grads + rau_forward + rau_backward (every parameter gradient
+in the three flat buffers) [+ RCCL average of those buffers when N > 1].  Inputs
+are resident in HBM before the timed region.  Noise/clip/Adam is NOT in the
+metric; it is timed separately as step_incl_update.
+
+For N > 1 launch with torch.distributed.run, one rank per GPU (weak scaling:
+the per-GPU batch stays 256).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md, f32-input MFMA
+DOMINANT = "conv_embed_fwd"    # gemm_kernel<128,128,KC,RC_FLAT_MASK,CONV_TANH>
+
+
+def usable_cores():
+    """CPU share of this process: cgroup quota if set, else the affinity mask,
+    capped at 16 (the GPU box's per-GPU share; more threads only oversubscribe)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(per))))
+    except Exception:
+        pass
+    return max(1, min(n, 16))
+
+
+def cpu_baseline(cfgd, budget_s=15.0):
+    """Reference graph restated on PyTorch-CPU (oracle/ref_torch.py), fp32, all cores,
+    on a bounded sample of the same workload: batch 16 of the same shapes."""
+    import torch
+    import oracle
+    from oracle import ref_torch
+    from rau_vqa_amd import synth
+    d = dict(cfgd)
+    d["B"] = 16
+    sh = oracle.Shapes(**d)
+    ne, nr, nm = oracle.group_sizes(sh)
+    batch = synth.make_batch(sh.B, sh.T, sh.V, sh.D, sh.S, sh.K, lens="full")
+    params = synth.make_params({"embed": ne, "rnn": nr, "mult": nm})
+    masks = synth.make_masks(oracle.mask_shapes(sh), {k: 0.5 for k in oracle.MASK_SITES})
+    cores = usable_cores()
+    torch.set_num_threads(cores)
+    run = lambda: ref_torch.step(sh, params, batch["feats"], batch["tokens"], batch["lens"],
+                                 batch["labels"], masks, backward=True, dtype=torch.float32)
+    run()  # warm-up
+    t0 = time.time()
+    n = 0
+    while True:
+        run()
+        n += 1
+        if time.time() - t0 > budget_s or n >= 200:
+            break
+    dt = time.time() - t0
+    return {"value": sh.B * n / dt, "unit": "QA-pairs/s", "cores": cores, "kind": "port",
+            "sample": f"{n} fwd+bwd steps at batch {sh.B} of the same shapes "
+                      f"(PyTorch-CPU fp32 restatement of the reference graph, {dt:.1f}s)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=256, help="per-GPU batch")
+    ap.add_argument("--D", type=int, default=512)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nnodes=1 "
+                             f"--nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...")
+        raise SystemExit(f"--gpus {args.gpus} != WORLD_SIZE {world}")
+
+    import torch  # before librau.so, so both share one HIP runtime
+    import torch.distributed as dist
+    from rau_vqa_amd import synth
+    from rau_vqa_amd.model import RAU, Config, hop_weights
+
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    cfgd = dict(B=args.batch, T=26, V=14000, E=200, Rq=512, D=args.D, S=196, M=512, A=256,
+                R=512, K=1000, H=8)
+    cfg = Config(device_id=local_rank, **cfgd)
+    m = RAU(cfg)
+    m.init_uniform(seed=123)                      # uniform(-0.08, 0.08), SS:352-354
+    batch = synth.make_batch(cfg.B, cfg.T, cfg.V, cfg.D, cfg.S, cfg.K, seed=123 + rank,
+                             lens="full")
+    m.set_batch(**batch)                          # resident in HBM from here on
+    m.training()
+    hop_w = hop_weights("SS", cfg.H)
+    reducer = None
+    if world > 1:
+        from rau_vqa_amd.dist import GradAllReduce
+        reducer = GradAllReduce(m)
+
+    def step(i):
+        m.set_dropout_seed(123, i)
+        m.zero_grads()
+        m.forward()
+        m.backward(hop_w)
+        if reducer is not None:
+            reducer()
+
+    def fence():
+        m.sync()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    losses = m.losses()
+    assert np.all(np.isfinite(losses)), losses
+
+    extra = {}
+    if rank == 0:
+        # per-kernel-class device time (HIP events on the ctx stream, outside the timed region)
+        m.prof_reset()
+        m.prof_enable(True)
+        nprof = 3
+        for i in range(nprof):
+            step(1000 + i)
+        m.sync()
+        prof = m.prof()
+        m.prof_enable(False)
+        dom = prof[DOMINANT]
+        avg_ms = dom["ms"] / dom["launches"]
+        flops_per_launch = dom["flops"] / dom["launches"]
+        achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12
+        extra["roofline"] = {"bound": "mfma", "achieved": achieved, "peak": MFMA_F32_PEAK_TFLOPS,
+                             "unit": "TFLOP/s", "frac": achieved / MFMA_F32_PEAK_TFLOPS,
+                             "traffic": None, "kernel": DOMINANT,
+                             "avg_launch_ms": avg_ms,
+                             "flops_per_launch": flops_per_launch}
+        tot = sum(v["ms"] for v in prof.values())
+        extra["kernel_classes_ms_per_step"] = {
+            k: round(v["ms"] / nprof, 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}
+        extra["device_ms_per_step_profiled"] = tot / nprof
+        # whole-step useful FLOPs: 3.656 GFLOP/QA at D=512, 8.588 at D=2048
+        gf_per_qa = {512: 3.656, 2048: 8.588}.get(args.D)
+        if gf_per_qa:
+            extra["step_tflops_useful"] = gf_per_qa * cfg.B * world * args.steps / dt / 1e3
+        # update cost, reported separately (not part of the metric)
+        fence()
+        t1 = time.perf_counter()
+        for i in range(5):
+            step(2000 + i)
+            m.update(step_t=i)
+        fence()
+        extra["step_incl_update_ms"] = (time.perf_counter() - t1) / 5 * 1e3
+        if world == 1 and not args.no_cpu_baseline:
+            extra["cpu_baseline"] = cpu_baseline(cfgd)
+    elif world > 1:
+        # keep ranks in lock-step with rank 0's extra (collective-carrying) steps
+        for i in range(3):
+            step(1000 + i)
+        fence()
+        for i in range(5):
+            step(2000 + i)
+            m.update(step_t=i)
+        fence()
+
+    if rank == 0:
+        qa = cfg.B * world * args.steps / dt
+        line = {"metric": "QA-pairs/sec fwd+bwd, Ours_SS 8-step RAU, batch 256, 14x14x512",
+                "value": qa, "unit": "QA-pairs/s", "n_gpus": world, "steps": args.steps,
+                "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                "dtype": "f32", "data": "synthetic",
+                "config": {"workload": "Ours_SS 8-step RAU fwd+bwd (configs[1])",
+                           "batch_per_gpu": cfg.B, "global_batch": cfg.B * world, "T": cfg.T,
+                           "feature_map": f"14x14x{cfg.D}", "hops": cfg.H,
+                           "parallelism": f"dp{world}", "hop_weights": "SS (x nHop)",
+                           "dropout": "train mode, Philox masks per step"}}
+        line.update(extra)
+        print(json.dumps(line))
+    m.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
