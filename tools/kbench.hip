@@ -1,0 +1,81 @@
+// kbench.hip -- kernel micro-benchmark (development tool, not part of librau.so).
+// Times individual launchers of rau_vqa_amd/csrc on random data with HIP events.
+//   ./kbench [B]      prints avg us + TFLOP/s per kernel class
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <functional>
+#include <vector>
+#include "../rau_vqa_amd/csrc/kernels.h"
+using namespace rau;
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1);} } while (0)
+
+static float* dev_rand(size_t n, float scale = 1.f) {
+  std::vector<float> h(n);
+  for (size_t i = 0; i < n; ++i) h[i] = scale * ((rand() % 2001) / 1000.f - 1.f);
+  float* d; CK(hipMalloc(&d, n * 4)); CK(hipMemcpy(d, h.data(), n * 4, hipMemcpyHostToDevice));
+  return d;
+}
+static double timeit(hipStream_t st, int iters, const std::function<hipError_t()>& f) {
+  hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+  for (int i = 0; i < 3; ++i) CK(f());
+  CK(hipStreamSynchronize(st));
+  CK(hipEventRecord(a, st));
+  for (int i = 0; i < iters; ++i) CK(f());
+  CK(hipEventRecord(b, st));
+  CK(hipEventSynchronize(b));
+  float ms; CK(hipEventElapsedTime(&ms, a, b));
+  return ms * 1e3 / iters;
+}
+static void report(const char* name, double us, double flops) {
+  printf("%-28s %9.1f us  %7.1f TFLOP/s (%.0f%% of 157.3)\n", name, us, flops / us / 1e6,
+         flops / us / 1e6 / 157.3 * 100);
+}
+
+int main(int argc, char** argv) {
+  const int B = argc > 1 ? atoi(argv[1]) : 256;
+  const int D = 512, S = 196, M = 512, A = 256;
+  hipStream_t st; CK(hipStreamCreate(&st));
+  float* X = dev_rand((size_t)B * D * S);
+  float* Wi = dev_rand((size_t)M * D, 0.08f), *bi = dev_rand(M, 0.08f);
+  float* I; CK(hipMalloc(&I, (size_t)B * M * S * 4));
+  uint32_t* mask; CK(hipMalloc(&mask, (size_t)B * D * S / 8 + 64));
+  CK(fill_masks(st, 1, 3, 0, 0.5f, (size_t)B * D * S, mask));
+  float* Wp = dev_rand((size_t)A * M, 0.08f), *bp = dev_rand(A, 0.08f), *u = dev_rand((size_t)B * A, 0.1f);
+  float* ws = dev_rand(A, 0.08f);
+  float* T; CK(hipMalloc(&T, (size_t)B * A * S * 4));
+  float* epart; CK(hipMalloc(&epart, (size_t)2 * B * S * 4));
+  float* dz = dev_rand((size_t)B * S, 0.01f), *dj = dev_rand((size_t)B * M, 0.01f), *a = dev_rand((size_t)B * S, 0.01f);
+  float* dZ; CK(hipMalloc(&dZ, (size_t)B * M * S * 4));
+  float* dWp = dev_rand((size_t)A * M), *dWi = dev_rand((size_t)M * D);
+  size_t sl = conv_wgrad_slab_floats(B, M, D, S); if (conv_wgrad_slab_floats(B, A, M, S) > sl) sl = conv_wgrad_slab_floats(B, A, M, S);
+  float* slab; CK(hipMalloc(&slab, sl * 4 + (size_t)64 * 2048 * 512 * 4));
+  const double NS = (double)B * S;
+  report("conv_embed_fwd(mask)", timeit(st, 20, [&] { return conv_embed_fwd(st, B, D, S, M, X, mask, 0, 2.f, Wi, bi, I); }), 2.0 * M * NS * D);
+  report("conv_embed_fwd(nomask)", timeit(st, 20, [&] { return conv_embed_fwd(st, B, D, S, M, X, nullptr, 0, 2.f, Wi, bi, I); }), 2.0 * M * NS * D);
+  report("conv_att_fwd", timeit(st, 20, [&] { return conv_att_fwd(st, B, M, S, A, I, Wp, bp, u, ws, T, epart); }), 2.0 * A * NS * M);
+  report("conv_att_dgrad", timeit(st, 20, [&] { return conv_att_dgrad(st, B, M, S, A, T, dz, ws, Wp, dj, a, I, dZ); }), 2.0 * A * NS * M);
+  report("conv_att_wgrad", timeit(st, 20, [&] { return conv_att_wgrad(st, B, M, S, A, T, dz, ws, I, dWp, slab); }), 2.0 * A * NS * M);
+  report("conv_embed_wgrad(mask)", timeit(st, 20, [&] { return conv_embed_wgrad(st, B, D, S, M, dZ, X, mask, 0, 2.f, dWi, slab); }), 2.0 * M * NS * D);
+  // small GEMMs
+  float* h = dev_rand((size_t)B * 2048, 0.5f), *W = dev_rand((size_t)2048 * 2048, 0.08f);
+  float* C; CK(hipMalloc(&C, (size_t)8 * B * 2048 * 4));
+  LinOpts o;
+  struct Sh { const char* n; int N, Kd; };
+  const Sh nts[] = {{"nt N2048 K512", 2048, 512}, {"nt N512 K512", 512, 512}, {"nt N1000 K512", 1000, 512},
+                    {"nt N196 K512", 196, 512}, {"nt N512 K196", 512, 196}, {"nt N512 K2048", 512, 2048}};
+  for (auto& s : nts)
+    report(s.n, timeit(st, 50, [&] { return gemm_nt(st, B, s.N, s.Kd, h, s.Kd, W, s.Kd, C, s.N, o); }), 2.0 * B * s.N * s.Kd);
+  const Sh nns[] = {{"nn N512 K2048", 512, 2048}, {"nn N512 K1000", 512, 1000}, {"nn N512 K512", 512, 512},
+                    {"nn N196 K512", 196, 512}, {"nn N512 K256", 512, 256}, {"nn N2048 K512", 2048, 512}};
+  for (auto& s : nns)
+    report(s.n, timeit(st, 50, [&] { return gemm_nn(st, B, s.N, s.Kd, h, s.Kd, W, s.N, C, s.N, o); }), 2.0 * B * s.N * s.Kd);
+  const int rows = 8 * B;
+  float* dY = dev_rand((size_t)rows * 2048, 0.1f), *Xr = dev_rand((size_t)rows * 2048, 0.1f);
+  report("tn 2048x512 rows8B", timeit(st, 20, [&] { return gemm_tn_acc(st, 2048, 512, rows, dY, 2048, Xr, 512, W, 512, slab); }), 2.0 * 2048 * 512 * rows);
+  report("tn 1000x512 rows8B", timeit(st, 20, [&] { return gemm_tn_acc(st, 1000, 512, rows, dY, 1000, Xr, 512, W, 512, slab); }), 2.0 * 1000 * 512 * rows);
+  report("tn 512x2048 rows8B", timeit(st, 20, [&] { return gemm_tn_acc(st, 512, 2048, rows, dY, 512, Xr, 2048, W, 2048, slab); }), 2.0 * 2048 * 512 * rows);
+  CK(hipStreamSynchronize(st));
+  return 0;
+}
