@@ -51,6 +51,7 @@ struct GemmParams {
   const float* v2;     // a
   const float* I;      // saved I
   float* out2;         // e_part
+  int dbg;             // tools/kbench only: 1 = no global loads in the loop, 2 = no barriers
 };
 
 // ---------------------------------------------------------------- loaders
@@ -111,6 +112,7 @@ struct LoadRC {
   bool ok;
   int kr, c4, K;
   float4 v[NI];
+  float aux[NI];
   const uint32_t* mask;
   float mscale;
   const float* ws;
@@ -135,35 +137,42 @@ struct LoadRC {
     }
   }
   __device__ __forceinline__ void load(int step) {
+    // raw loads only: the dropout / dS transform happens in store(), so the
+    // global-load latency stays hidden behind the MFMA loop of the current tile
     const int k0 = step * BK;
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
       const int k = k0 + kr + i * RPP;
-      float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+      v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      aux[i] = 0.f;
       if (ok && k < K) {
-        x = *reinterpret_cast<const float4*>(p + (long)k * rs);
-        if (KIND == 1) {
-          const uint32_t nib = mask_nib(mask, eoff + (size_t)k * rs);
-          x.x = (nib & 1u) ? x.x * mscale : 0.f;
-          x.y = (nib & 2u) ? x.y * mscale : 0.f;
-          x.z = (nib & 4u) ? x.z * mscale : 0.f;
-          x.w = (nib & 8u) ? x.w * mscale : 0.f;
-        }
-        if (KIND == 2) {
-          const float w = ws[k];
-          x.x = dzv.x * w * (1.f - x.x * x.x);
-          x.y = dzv.y * w * (1.f - x.y * x.y);
-          x.z = dzv.z * w * (1.f - x.z * x.z);
-          x.w = dzv.w * w * (1.f - x.w * x.w);
-        }
+        v[i] = *reinterpret_cast<const float4*>(p + (long)k * rs);
+        if (KIND == 1)
+          aux[i] = __uint_as_float(mask_nib(mask, eoff + (size_t)k * rs));
+        if (KIND == 2) aux[i] = ws[k];
       }
-      v[i] = x;
     }
   }
   __device__ __forceinline__ void store(float* lds, int tid) const {
 #pragma unroll
-    for (int i = 0; i < NI; ++i)
-      *reinterpret_cast<float4*>(lds + (kr + i * RPP) * (BT + LPAD) + c4) = v[i];
+    for (int i = 0; i < NI; ++i) {
+      float4 x = v[i];
+      if (KIND == 1) {
+        const uint32_t nib = __float_as_uint(aux[i]);
+        x.x = (nib & 1u) ? x.x * mscale : 0.f;
+        x.y = (nib & 2u) ? x.y * mscale : 0.f;
+        x.z = (nib & 4u) ? x.z * mscale : 0.f;
+        x.w = (nib & 8u) ? x.w * mscale : 0.f;
+      }
+      if (KIND == 2) {
+        const float w = aux[i];
+        x.x = dzv.x * w * (1.f - x.x * x.x);
+        x.y = dzv.y * w * (1.f - x.y * x.y);
+        x.z = dzv.z * w * (1.f - x.z * x.z);
+        x.w = dzv.w * w * (1.f - x.w * x.w);
+      }
+      *reinterpret_cast<float4*>(lds + (kr + i * RPP) * (BT + LPAD) + c4) = x;
+    }
   }
 };
 
@@ -178,6 +187,8 @@ struct LoadSC {
   bool ok[NI];
   float wsr[NI];
   float4 v[NI];
+  uint32_t nibs[NI];
+  float4 dzv;
   const float* base;
   long bs;
   int kc, S, cps;
@@ -206,40 +217,42 @@ struct LoadSC {
     const int b = g / cps;
     const int s0 = (g - b * cps) * BK;
     const bool kin = s0 + kc < S;
-    float4 dzv = make_float4(0.f, 0.f, 0.f, 0.f);
+    dzv = make_float4(0.f, 0.f, 0.f, 0.f);
     if (KIND == 2 && kin) dzv = *reinterpret_cast<const float4*>(dz + (long)b * S + s0 + kc);
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
-      float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+      v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      nibs[i] = 0u;
       if (ok[i] && kin) {
         const long e = (long)b * bs + roff[i] + s0;
-        x = *reinterpret_cast<const float4*>(base + e);
-        if (KIND == 1) {
-          const uint32_t nib = mask_nib(mask, me0 + (size_t)e);
-          x.x = (nib & 1u) ? x.x * mscale : 0.f;
-          x.y = (nib & 2u) ? x.y * mscale : 0.f;
-          x.z = (nib & 4u) ? x.z * mscale : 0.f;
-          x.w = (nib & 8u) ? x.w * mscale : 0.f;
-        }
-        if (KIND == 2) {
-          x.x = dzv.x * wsr[i] * (1.f - x.x * x.x);
-          x.y = dzv.y * wsr[i] * (1.f - x.y * x.y);
-          x.z = dzv.z * wsr[i] * (1.f - x.z * x.z);
-          x.w = dzv.w * wsr[i] * (1.f - x.w * x.w);
-        }
+        v[i] = *reinterpret_cast<const float4*>(base + e);
+        if (KIND == 1) nibs[i] = mask_nib(mask, me0 + (size_t)e);
       }
-      v[i] = x;
     }
   }
   __device__ __forceinline__ void store(float* lds, int tid) const {
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
+      float4 x = v[i];
+      if (KIND == 1) {
+        const uint32_t nib = nibs[i];
+        x.x = (nib & 1u) ? x.x * mscale : 0.f;
+        x.y = (nib & 2u) ? x.y * mscale : 0.f;
+        x.z = (nib & 4u) ? x.z * mscale : 0.f;
+        x.w = (nib & 8u) ? x.w * mscale : 0.f;
+      }
+      if (KIND == 2) {
+        x.x = dzv.x * wsr[i] * (1.f - x.x * x.x);
+        x.y = dzv.y * wsr[i] * (1.f - x.y * x.y);
+        x.z = dzv.z * wsr[i] * (1.f - x.z * x.z);
+        x.w = dzv.w * wsr[i] * (1.f - x.w * x.w);
+      }
       const int r = (tid + i * 256) >> 2;
       float* d = lds + kc * (BT + LPAD) + r;
-      d[0] = v[i].x;
-      d[BT + LPAD] = v[i].y;
-      d[2 * (BT + LPAD)] = v[i].z;
-      d[3 * (BT + LPAD)] = v[i].w;
+      d[0] = x.x;
+      d[BT + LPAD] = x.y;
+      d[2 * (BT + LPAD)] = x.z;
+      d[3 * (BT + LPAD)] = x.w;
     }
   }
 };
@@ -304,7 +317,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams P) {
   constexpr int WM = BM / 2, WN = BN / 2;   // wave tile
   constexpr int IM = WM / 32, JN = WN / 32; // 32x32 blocks per wave
   constexpr int LDA = BM + LPAD, LDB = BN + LPAD;
-  __shared__ __attribute__((aligned(16))) float smem[2 * BK * LDA + 2 * BK * LDB + (EPI == EPI_ATT_SCORE ? 2 * BN : 0)];
+  constexpr int kStage = 2 * BK * LDA + 2 * BK * LDB;  // floats of operand staging
+  // epilogue scratch lives in the (then idle) staging area: per-row vectors,
+  // per-(sample,row) vectors of the samples this tile's columns touch, column sums
+  constexpr int kUCap = kStage - 2 * BM - 2 * BN;
+  __shared__ __attribute__((aligned(16))) float smem[kStage];
   float* As = smem;
   float* Bs = smem + 2 * BK * LDA;
 
@@ -347,42 +364,59 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams P) {
   for (int it = 0; it < nsteps; ++it) {
     const int cur = it & 1;
     const bool more = it + 1 < nsteps;
-    if (more) {
+    if (more && !(P.dbg & 1)) {
       LA.load(step0 + it + 1);
       LB.load(step0 + it + 1);
     }
     const float* as = As + cur * BK * LDA + fa;
     const float* bs = Bs + cur * BK * LDB + fb;
+    // fragments of k-step kk+1 are read from LDS before the MFMAs of k-step kk issue
+    // (the sched_group_barrier sequence pins that order; hipcc otherwise sinks the
+    // reads back behind the MFMAs and exposes the LDS latency on every k-step)
+    float a[2][IM], b[2][JN];
+#pragma unroll
+    for (int i = 0; i < IM; ++i) a[0][i] = as[i * 32];
+#pragma unroll
+    for (int j = 0; j < JN; ++j) b[0][j] = bs[j * 32];
 #pragma unroll
     for (int kk = 0; kk < BK / 2; ++kk) {
-      float a[IM], b[JN];
+      const int c = kk & 1, nx = c ^ 1;
+      if (kk + 1 < BK / 2) {
 #pragma unroll
-      for (int i = 0; i < IM; ++i) a[i] = as[kk * 2 * LDA + i * 32];
+        for (int i = 0; i < IM; ++i) a[nx][i] = as[(kk + 1) * 2 * LDA + i * 32];
 #pragma unroll
-      for (int j = 0; j < JN; ++j) b[j] = bs[kk * 2 * LDB + j * 32];
+        for (int j = 0; j < JN; ++j) b[nx][j] = bs[(kk + 1) * 2 * LDB + j * 32];
+      }
 #pragma unroll
       for (int i = 0; i < IM; ++i)
 #pragma unroll
         for (int j = 0; j < JN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c][i], b[c][j], acc[i][j], 0, 0, 0);
     }
-    if (more) {
+    constexpr int kRd = (IM + 1) / 2 + (JN + 1) / 2;  // ds_read2_b32 per k-step
+    __builtin_amdgcn_sched_group_barrier(0x100, 2 * kRd, 0);   // reads of k-steps 0 and 1
+#pragma unroll
+    for (int kk = 0; kk < BK / 2; ++kk) {
+      __builtin_amdgcn_sched_group_barrier(0x008, IM * JN, 0);  // MFMAs of k-step kk
+      if (kk + 2 < BK / 2) __builtin_amdgcn_sched_group_barrier(0x100, kRd, 0);  // reads kk+2
+    }
+    if (more && !(P.dbg & 1)) {
       LA.store(As + (cur ^ 1) * BK * LDA, tid);
       LB.store(Bs + (cur ^ 1) * BK * LDB, tid);
     }
-    __syncthreads();
+    if (!(P.dbg & 2)) __syncthreads();
   }
 
   // ------------------------------------------------------------ epilogue
   // accumulator element r of block (i,j): row = (r&3) + 8*(r>>2) + 4*(l>>5), col = l&31
-  const int rbase = m0 + wm * WM + 4 * (l >> 5);
-  const int cbase = n0 + wn * WN + (l & 31);
+  const int rloc = wm * WM + 4 * (l >> 5);   // row of (i=0, r=0) inside the tile
+  const int cloc = wn * WN + (l & 31);       // column of j=0 inside the tile
 
   if (EPI == EPI_LIN || EPI == EPI_SLAB) {
     float* C = P.C + (EPI == EPI_SLAB ? (long)blockIdx.z * P.slab_stride : 0);
 #pragma unroll
     for (int j = 0; j < JN; ++j) {
-      const int n = cbase + j * 32;
+      const int n = n0 + cloc + j * 32;
       if (n >= P.N) continue;
       float bsum = 0.f;
       if (EPI == EPI_LIN) {
@@ -393,7 +427,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams P) {
       for (int i = 0; i < IM; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int m = rbase + i * 32 + (r & 3) + 8 * (r >> 2);
+          const int m = m0 + rloc + i * 32 + (r & 3) + 8 * (r >> 2);
           if (m >= P.M) continue;
           float v = acc[i][j][r];
           const long ci = (long)m * P.c_rs + n;
@@ -413,43 +447,75 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams P) {
         }
     }
   } else {
-    // flattened-column epilogues: n -> (b, s)
+    // Flattened-column epilogues: n -> (sample b, position s).  Per-row vectors
+    // (bias, ws) and the per-(sample,row) vector (u or dj) of the few samples a
+    // tile's columns span are staged in LDS once, instead of one dependent
+    // global load per accumulator element.
+    float* rowv = smem;                 // [BM] bias
+    float* rowv2 = smem + BM;           // [BM] ws
+    float* red = smem + 2 * BM;         // [2][BN] column partial sums
+    float* uv = smem + 2 * BM + 2 * BN; // [nsamp][BM] u / dj
+    const int b0 = n0 / P.S;
+    int nlast = n0 + BN - 1;
+    if (nlast > P.N - 1) nlast = P.N - 1;
+    const int nsamp = nlast / P.S - b0 + 1;
+    const bool staged = nsamp * BM <= kUCap;
+    const float* pv = EPI == EPI_ATT_SCORE ? P.u : P.v1;  // [sample][M]
+    if (tid < BM) {
+      const int m = m0 + tid;
+      rowv[tid] = (EPI != EPI_DI && m < P.M) ? P.bias[m] : 0.f;
+      rowv2[tid] = (EPI == EPI_ATT_SCORE && m < P.M) ? P.v1[m] : 0.f;
+    }
+    if (EPI != EPI_CONV_TANH && staged)
+      for (int e = tid; e < nsamp * BM; e += 256) {
+        const int sb = e / BM, r = e - sb * BM;
+        uv[e] = (m0 + r < P.M) ? pv[(long)(b0 + sb) * P.M + m0 + r] : 0.f;
+      }
+    __syncthreads();
     float esum[JN];
 #pragma unroll
     for (int j = 0; j < JN; ++j) {
       esum[j] = 0.f;
-      const int n = cbase + j * 32;
-      if (n >= P.N) continue;
-      const int b = n / P.S, s = n - b * P.S;
+      const int n = n0 + cloc + j * 32;
+      const bool nok = n < P.N;
+      const int nn = nok ? n : P.N - 1;
+      const int b = nn / P.S, s = nn - b * P.S;
       const long cb = (long)b * P.c_bs + s;
+      const float* uvb = uv + (b - b0) * BM;
       float an = 0.f;
-      if (EPI == EPI_DI) an = P.v2[n];
+      if (EPI == EPI_DI) an = P.v2[nn];
 #pragma unroll
       for (int i = 0; i < IM; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int m = rbase + i * 32 + (r & 3) + 8 * (r >> 2);
-          if (m >= P.M) continue;
-          const long ci = cb + (long)m * P.S;
-          float v = acc[i][j][r];
+          const int rl = rloc + i * 32 + (r & 3) + 8 * (r >> 2);
+          const int m = m0 + rl;
+          const bool ok = nok && m < P.M;
+          const long ci = cb + (long)(m < P.M ? m : P.M - 1) * P.S;
+          const float v = acc[i][j][r];
+          float pvm = 0.f;
+          if (EPI != EPI_CONV_TANH)
+            pvm = staged ? uvb[rl] : (m < P.M ? pv[(long)b * P.M + m] : 0.f);
           if (EPI == EPI_CONV_TANH) {
-            P.C[ci] = tanhf(v + P.bias[m]);
+            const float t = tanhf(v + rowv[rl]);
+            if (ok) P.C[ci] = t;
           } else if (EPI == EPI_ATT_SCORE) {
-            const float t = tanhf(v + P.bias[m] + P.u[(long)b * P.M + m]);
-            P.C[ci] = t;
-            esum[j] += P.v1[m] * t;
+            const float t = tanhf(v + rowv[rl] + pvm);
+            if (ok) {
+              P.C[ci] = t;
+              esum[j] += rowv2[rl] * t;
+            }
           } else if (EPI == EPI_DI) {
             const float y = P.I[ci];
-            P.C[ci] = (v + P.v1[(long)b * P.M + m] * an) * (1.f - y * y);
+            if (ok) P.C[ci] = (v + pvm * an) * (1.f - y * y);
           }
         }
     }
     if (EPI == EPI_ATT_SCORE) {
       // reduce over the tile's BM rows: lane halves, then the two wm waves
-      float* red = smem + 2 * BK * LDA + 2 * BK * LDB;  // [2][BN]
 #pragma unroll
       for (int j = 0; j < JN; ++j) {
-        float v = esum[j] + __shfl_xor(esum[j], 32, 64);
+        const float v = esum[j] + __shfl_xor(esum[j], 32, 64);
         if (l < 32) red[wm * BN + wn * WN + j * 32 + l] = v;
       }
       __syncthreads();

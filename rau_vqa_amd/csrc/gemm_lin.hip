@@ -23,21 +23,45 @@ static GemmParams lin_params(int M, int N, int K, const float* A, long lda, cons
   return P;
 }
 
-// Tile choice: these GEMMs have few rows (batch) so 64x64 tiles keep more CUs busy.
-hipError_t gemm_nt(hipStream_t st, int M, int N, int K, const float* A, long lda,
-                   const float* W, long ldw, float* C, long ldc, const LinOpts& o) {
+// Skinny problems (few output tiles, long K) are latency-bound per workgroup, so
+// they are split over K across workgroups until the grid covers the chip; the
+// partials are combined by lin_reduce_epilogue in fixed order.
+static int skinny_splits(int M, int N, int K, const LinOpts& o) {
+  if (!o.slab) return 1;
+  const int tiles = ((M + 63) / 64) * ((N + 63) / 64);
+  const int nk = (K + BK - 1) / BK;
+  int s = (384 + tiles - 1) / tiles;
+  if (s > nk / 2) s = nk / 2;
+  if (s < 1) s = 1;
+  while (s > 1 && (size_t)s * M * N > o.slab_floats) --s;
+  const int per = (nk + s - 1) / s;
+  return (nk + per - 1) / per;
+}
+
+template <int ASRC, int BSRC>
+static hipError_t lin_gemm(hipStream_t st, int M, int N, int K, const float* A, long lda,
+                           const float* W, long ldw, float* C, long ldc, const LinOpts& o) {
   GemmParams P = lin_params(M, N, K, A, lda, W, ldw, C, ldc, o);
   if ((long)M * N >= 128L * 128 * 256)
-    return launch_gemm<128, 128, SRC_KC, SRC_KC, EPI_LIN>(st, P, 1);
-  return launch_gemm<64, 64, SRC_KC, SRC_KC, EPI_LIN>(st, P, 1);
+    return launch_gemm<128, 128, ASRC, BSRC, EPI_LIN>(st, P, 1);
+  const int s = skinny_splits(M, N, K, o);
+  if (s <= 1) return launch_gemm<64, 64, ASRC, BSRC, EPI_LIN>(st, P, 1);
+  P.C = o.slab;
+  P.c_rs = N;
+  P.slab_stride = (long)M * N;
+  hipError_t e = launch_gemm<64, 64, ASRC, BSRC, EPI_SLAB>(st, P, s);
+  if (e != hipSuccess) return e;
+  return lin_reduce_epilogue(st, M, N, s, o.slab, C, ldc, o);
+}
+
+hipError_t gemm_nt(hipStream_t st, int M, int N, int K, const float* A, long lda,
+                   const float* W, long ldw, float* C, long ldc, const LinOpts& o) {
+  return lin_gemm<SRC_KC, SRC_KC>(st, M, N, K, A, lda, W, ldw, C, ldc, o);
 }
 
 hipError_t gemm_nn(hipStream_t st, int M, int N, int K, const float* A, long lda,
                    const float* W, long ldw, float* C, long ldc, const LinOpts& o) {
-  GemmParams P = lin_params(M, N, K, A, lda, W, ldw, C, ldc, o);
-  if ((long)M * N >= 128L * 128 * 256)
-    return launch_gemm<128, 128, SRC_KC, SRC_RC, EPI_LIN>(st, P, 1);
-  return launch_gemm<64, 64, SRC_KC, SRC_RC, EPI_LIN>(st, P, 1);
+  return lin_gemm<SRC_KC, SRC_RC>(st, M, N, K, A, lda, W, ldw, C, ldc, o);
 }
 
 static int tn_splits(int M, int N, int K) {

@@ -21,6 +21,10 @@ struct LinOpts {
   size_t emask_e0 = 0;
   float emscale = 1.f;
   float alpha = 1.f;
+  // split-K workspace: when given, skinny problems are split over K across
+  // workgroups (partials to slab, then one fused reduce + epilogue kernel)
+  float* slab = nullptr;
+  size_t slab_floats = 0;
 };
 // C[M,N] = epi(A[M,K] * W[N,K]^T)      (Linear forward)
 hipError_t gemm_nt(hipStream_t st, int M, int N, int K, const float* A, long lda,
@@ -112,6 +116,9 @@ hipError_t embed_bwd(hipStream_t st, int nuniq, int E, const int32_t* utok, cons
                      const uint32_t* mask, float mscale, float* gE);
 hipError_t splitk_reduce_acc(hipStream_t st, size_t n, int splits, const float* slab,
                              size_t slab_stride, float* dst);
+// C = epilogue(sum_s slab[s]) with the LinOpts epilogue (bias, addend, tanh, ...)
+hipError_t lin_reduce_epilogue(hipStream_t st, int M, int N, int splits, const float* slab,
+                               float* C, long ldc, const LinOpts& o);
 hipError_t uniform_fill(hipStream_t st, uint64_t seed, uint32_t stream, size_t n, float lo,
                         float hi, float* x);
 // noise + norm + clip + adam (SS:597-630, optim_updates.lua:59-87)

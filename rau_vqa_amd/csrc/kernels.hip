@@ -602,6 +602,38 @@ hipError_t splitk_reduce_acc(hipStream_t st, size_t n, int splits, const float* 
   return hipGetLastError();
 }
 
+// Fused split-K reduction + Linear epilogue: C[m,n] = epi(sum_s slab[s][m,n]).
+// Partials are summed in split order, so the result is bitwise reproducible.
+__global__ void k_lin_reduce_epilogue(int M, int N, int splits, const float* __restrict__ slab,
+                                      float* __restrict__ C, long ldc, LinOpts o) {
+  const size_t total = (size_t)M * N;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const int m = (int)(i / N), n = (int)(i - (size_t)m * N);
+    float v = slab[i];
+    for (int s = 1; s < splits; ++s) v += slab[(size_t)s * total + i];
+    v *= o.alpha;
+    if (o.bias) v += o.bias[n];
+    if (o.bias2) v += o.bias2[n];
+    if (o.addend) v += o.addend[(long)m * o.add_rs + n];
+    const long ci = (long)m * ldc + n;
+    if (o.accumulate) v += C[ci];
+    if (o.act == 1) v = tanhf(v);
+    if (o.ymul) {
+      const float y = o.ymul[(long)m * o.y_rs + n];
+      v *= (1.f - y * y);
+    }
+    if (o.emask) v = mask_bit(o.emask, o.emask_e0 + i) ? v * o.emscale : 0.f;
+    C[ci] = v;
+  }
+}
+hipError_t lin_reduce_epilogue(hipStream_t st, int M, int N, int splits, const float* slab,
+                               float* C, long ldc, const LinOpts& o) {
+  hipLaunchKernelGGL(k_lin_reduce_epilogue, dim3(grid_for((size_t)M * N)), dim3(256), 0, st, M, N,
+                     splits, slab, C, ldc, o);
+  return hipGetLastError();
+}
+
 // --------------------------------------------------- noise / clip / Adam (next-1)
 __device__ __forceinline__ float2 box_muller(uint32_t a, uint32_t b) {
   const float u1 = ((a >> 8) + 1) * (1.0f / 16777216.0f);  // (0,1]

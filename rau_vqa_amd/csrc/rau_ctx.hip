@@ -32,6 +32,9 @@
 
 using namespace rau;
 
+// LinOpts pre-wired with the ctx's split-K workspace
+#define LINOPTS(name) LinOpts name; name.slab = ctx->slab; name.slab_floats = ctx->slab_floats
+
 // ------------------------------------------------------------------ errors
 static thread_local char g_err[512] = "";
 static int fail(int code, const char* fmt, ...) {
@@ -701,7 +704,7 @@ int rau_forward(rau_ctx* ctx) {
       float* tcs = L == 0 ? ctx->tc1 : ctx->tc2;
       const float* xin = L == 0 ? ctx->we : ctx->x2;
       const int kin = L == 0 ? E : Rq;
-      LinOpts o;
+      LINOPTS(o);
       o.bias = ctx->i2h[L].b;
       o.bias2 = ctx->h2h[L].b;
       // input projection of every token at once (no recurrence in it)
@@ -710,7 +713,7 @@ int rau_forward(rau_ctx* ctx) {
       for (int t = 1; t <= TL; ++t) {
         float* Gt = G + (size_t)(t - 1) * B * 4 * Rq;
         if (t > 1) {
-          LinOpts oa;
+          LINOPTS(oa);
           oa.accumulate = 1;
           RUN("enc_h2h_gemm", gflop(B, 4 * Rq, Rq), 0,
               gemm_nt(st, B, 4 * Rq, Rq, hs + (size_t)(t - 1) * BRq, Rq, ctx->h2h[L].W, Rq, Gt,
@@ -732,7 +735,7 @@ int rau_forward(rau_ctx* ctx) {
   RUN("apply_mask", 0, (double)H * B * Q * 8,
       apply_mask(st, (size_t)H * B * Q, (size_t)B * Q, ctx->q, m_q, sc(RAU_MASK_Q), ctx->qd));
   {
-    LinOpts o;
+    LINOPTS(o);
     o.bias = ctx->q_proj.b;
     o.bias2 = ctx->h_proj.b;
     RUN("q_proj_gemm", gflop(H * B, M, Q), 0,
@@ -753,7 +756,7 @@ int rau_forward(rau_ctx* ctx) {
     float* mfh = ctx->mf + (size_t)h * BM_;
     float* lg = ctx->logits + (size_t)h * B * K;
     {  // q_embed SS:231-236
-      LinOpts o;
+      LINOPTS(o);
       o.addend = ctx->Yq + (size_t)h * BM_;
       o.add_rs = M;
       o.act = 1;
@@ -764,7 +767,7 @@ int rau_forward(rau_ctx* ctx) {
         conv_embed_fwd(st, B, D, S, M, ctx->feats, m_x, (size_t)h * B * D * S, sc(RAU_MASK_X),
                        ctx->i_embed.W, ctx->i_embed.b, Ih));
     {  // attbycontent SS:244-252
-      LinOpts o;
+      LINOPTS(o);
       o.bias = ctx->att_q.b;
       RUN("small_gemm", gflop(B, A, M), 0, gemm_nt(st, B, A, M, qf, M, ctx->att_q.W, M, ctx->u, A, o));
     }
@@ -772,7 +775,7 @@ int rau_forward(rau_ctx* ctx) {
         conv_att_fwd(st, B, M, S, A, Ih, ctx->att_i.W, ctx->att_i.b, ctx->u, ctx->att_score.W, Th,
                      ctx->e_part));
     {  // attbymemory SS:285-290
-      LinOpts o;
+      LINOPTS(o);
       o.bias = ctx->att_mem.b;
       RUN("small_gemm", gflop(B, S, R), 0, gemm_nt(st, B, S, R, hp, R, ctx->att_mem.W, R, ctx->zm, S, o));
     }
@@ -782,19 +785,19 @@ int rau_forward(rau_ctx* ctx) {
     RUN("attselect_fwd", 2.0 * BM_ * S, BM_ * S * 4.0,
         attselect_fwd(st, B, M, S, Ih, ah, qf, ctx->jv));
     {  // classifier SS:265-283
-      LinOpts o;
+      LINOPTS(o);
       o.bias = ctx->feat_attprob.b;
       o.addend = ctx->jv;
       o.add_rs = M;
       RUN("small_gemm", gflop(B, M, S), 0, gemm_nt(st, B, M, S, ah, S, ctx->feat_attprob.W, S, jh, M, o));
     }
     {
-      LinOpts o;
+      LINOPTS(o);
       o.bias = ctx->lstm_i2h.b;
       o.bias2 = ctx->lstm_h2h.b;
       RUN("small_gemm", gflop(B, 4 * R, M), 0,
           gemm_nt(st, B, 4 * R, M, jh, M, ctx->lstm_i2h.W, M, g4, 4 * R, o));
-      LinOpts oa;
+      LINOPTS(oa);
       oa.accumulate = 1;
       RUN("small_gemm", gflop(B, 4 * R, R), 0,
           gemm_nt(st, B, 4 * R, R, hp, R, ctx->lstm_h2h.W, R, g4, 4 * R, oa));
@@ -804,7 +807,7 @@ int rau_forward(rau_ctx* ctx) {
                  ctx->hh + (size_t)(h + 1) * BR_, R, ctx->tc + (size_t)h * BR_, nullptr, nullptr, 0,
                  1.f));
     {
-      LinOpts o;
+      LINOPTS(o);
       o.bias = ctx->lstm_out.b;
       o.addend = jh;
       o.add_rs = M;
@@ -815,7 +818,7 @@ int rau_forward(rau_ctx* ctx) {
           gemm_nt(st, B, M, R, ctx->hh + (size_t)(h + 1) * BR_, R, ctx->lstm_out.W, R, mfh, M, o));
     }
     {
-      LinOpts o;
+      LINOPTS(o);
       o.bias = ctx->cls.b;
       RUN("small_gemm", gflop(B, K, M), 0, gemm_nt(st, B, K, M, mfh, M, ctx->cls.W, M, lg, K, o));
     }
@@ -877,7 +880,7 @@ int rau_backward(rau_ctx* ctx, const float* hop_w) {
     float* dc_out = ctx->dcn[h & 1];
     float* dh_out = ctx->dhp[h & 1];
     {  // dmf = dlogits Wc ; dpre = dmf (.) mask   (do_pred grad is zero, SS:566)
-      LinOpts o;
+      LINOPTS(o);
       o.emask = m_mf;
       o.emask_e0 = (size_t)h * BM_;
       o.emscale = sc(RAU_MASK_MF);
@@ -885,7 +888,7 @@ int rau_backward(rau_ctx* ctx, const float* hop_w) {
           gemm_nn(st, B, M, K, ctx->dl + (size_t)h * B * K, K, ctx->cls.W, M, dpre, M, o));
     }
     {  // dhn = dpre Wo + dh_next
-      LinOpts o;
+      LINOPTS(o);
       o.addend = dh_next;
       o.add_rs = R;
       RUN("small_gemm", gflop(B, R, M), 0, gemm_nn(st, B, R, M, dpre, M, ctx->lstm_out.W, R, ctx->dhn, R, o));
@@ -894,17 +897,17 @@ int rau_backward(rau_ctx* ctx, const float* hop_w) {
         lstm_bwd(st, GATES_ATT, B, R, g4, cp, R, ctx->tc + (size_t)h * BR_, ctx->dhn, R, nullptr,
                  dc_next, dg4, dc_out, nullptr, 0, nullptr, nullptr, 0));
     {  // dj = dpre + dg Wx ; dh_prev = dg Wr
-      LinOpts o;
+      LINOPTS(o);
       o.addend = dpre;
       o.add_rs = M;
       RUN("small_gemm", gflop(B, M, 4 * R), 0,
           gemm_nn(st, B, M, 4 * R, dg4, 4 * R, ctx->lstm_i2h.W, M, djh, M, o));
-      LinOpts o2;
+      LINOPTS(o2);
       RUN("small_gemm", gflop(B, R, 4 * R), 0,
           gemm_nn(st, B, R, 4 * R, dg4, 4 * R, ctx->lstm_h2h.W, R, dh_out, R, o2));
     }
     {  // da = dj Wf  (+ attselect term below)
-      LinOpts o;
+      LINOPTS(o);
       RUN("small_gemm", gflop(B, S, M), 0,
           gemm_nn(st, B, S, M, djh, M, ctx->feat_attprob.W, S, ctx->da_lin, S, o));
     }
@@ -913,7 +916,7 @@ int rau_backward(rau_ctx* ctx, const float* hop_w) {
     RUN("softmax_bwd", 0, BS_ * 4.0 * (chunks + 4),
         softmax_bwd(st, B, S, ah, ctx->da_lin, ctx->da_part, chunks, (long)BS_, dzh));
     {  // dh_prev += dz Wm
-      LinOpts o;
+      LINOPTS(o);
       o.accumulate = 1;
       RUN("small_gemm", gflop(B, R, S), 0, gemm_nn(st, B, R, S, dzh, S, ctx->att_mem.W, R, dh_out, R, o));
     }
@@ -928,13 +931,13 @@ int rau_backward(rau_ctx* ctx, const float* hop_w) {
         conv_embed_wgrad(st, B, D, S, M, ctx->dZ, ctx->feats, m_x, (size_t)h * B * D * S,
                          sc(RAU_MASK_X), ctx->i_embed.dW, ctx->slab));
     {  // dq~ = (dj + du Wa) (1 - qf^2)
-      LinOpts o;
+      LINOPTS(o);
       o.addend = djh;
       o.add_rs = M;
       o.ymul = qf;
       o.y_rs = M;
       RUN("small_gemm", gflop(B, M, A), 0, gemm_nn(st, B, M, A, duh, A, ctx->att_q.W, M, dqt, M, o));
-      LinOpts o2;
+      LINOPTS(o2);
       o2.accumulate = 1;
       RUN("small_gemm", gflop(B, R, M), 0, gemm_nn(st, B, R, M, dqt, M, ctx->h_proj.W, R, dh_out, R, o2));
     }
@@ -942,7 +945,7 @@ int rau_backward(rau_ctx* ctx, const float* hop_w) {
     dh_next = dh_out;
   }
   {  // dq = sum_h (dq~_h Wq) (.) mask_h     (ConcatTable backward, SS:579)
-    LinOpts o;
+    LINOPTS(o);
     RUN("q_proj_dgrad", gflop(H * B, Q, M), 0,
         gemm_nn(st, H * B, Q, M, ctx->dqt, M, ctx->q_proj.W, Q, ctx->dQD, Q, o));
     RUN("dq_reduce", 0, (double)H * B * Q * 4,
@@ -995,7 +998,7 @@ int rau_backward(rau_ctx* ctx, const float* hop_w) {
                      L == 0 ? ctx->dX2 + (size_t)(t - 1) * BRq : nullptr, dc_n, dGt, dc_o,
                      ctx->lens_d, t, ctx->dq + 2 * L * Rq, ctx->dq + (2 * L + 1) * Rq, Q));
         if (t > 1) {
-          LinOpts o;
+          LINOPTS(o);
           RUN("enc_h2h_dgrad", gflop(B, Rq, 4 * Rq), 0,
               gemm_nn(st, B, Rq, 4 * Rq, dGt, 4 * Rq, ctx->h2h[L].W, Rq, ctx->edh[L], Rq, o));
         }
@@ -1003,14 +1006,14 @@ int rau_backward(rau_ctx* ctx, const float* hop_w) {
         dh_rec = ctx->edh[L];
       }
       if (L == 1) {  // gradient into layer 1's output through the inter-layer dropout
-        LinOpts o;
+        LINOPTS(o);
         o.emask = m_rnn;
         o.emask_e0 = 0;
         o.emscale = sc(RAU_MASK_RNN);
         RUN("enc_i2h_dgrad", gflop(rows, Rq, 4 * Rq), 0,
             gemm_nn(st, rows, Rq, 4 * Rq, ctx->dG2, 4 * Rq, ctx->i2h[1].W, Rq, ctx->dX2, Rq, o));
       } else {
-        LinOpts o;
+        LINOPTS(o);
         RUN("enc_i2h_dgrad", gflop(rows, E, 4 * Rq), 0,
             gemm_nn(st, rows, E, 4 * Rq, ctx->dG1, 4 * Rq, ctx->i2h[0].W, E, ctx->dwe, E, o));
       }

@@ -6,8 +6,25 @@
 #include <cstdlib>
 #include <functional>
 #include <vector>
+#include "../rau_vqa_amd/csrc/gemm_core.h"
 #include "../rau_vqa_amd/csrc/kernels.h"
+#include <cstring>
 using namespace rau;
+
+// pure-MFMA calibration: 4 waves per block, NACC independent accumulators
+template <int NACC>
+__global__ __launch_bounds__(256) void k_mfma_peak(int iters, float* out) {
+  f32x16 acc[NACC];
+  for (int i = 0; i < NACC; ++i) for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+  float a = threadIdx.x * 1e-3f, b = blockIdx.x * 1e-3f + 0.5f;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i], 0, 0, 0);
+  }
+  float s = 0.f;
+  for (int i = 0; i < NACC; ++i) for (int r = 0; r < 16; ++r) s += acc[i][r];
+  if (s == 12345.678f) out[0] = s;
+}
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1);} } while (0)
 
@@ -52,6 +69,31 @@ int main(int argc, char** argv) {
   size_t sl = conv_wgrad_slab_floats(B, M, D, S); if (conv_wgrad_slab_floats(B, A, M, S) > sl) sl = conv_wgrad_slab_floats(B, A, M, S);
   float* slab; CK(hipMalloc(&slab, sl * 4 + (size_t)64 * 2048 * 512 * 4));
   const double NS = (double)B * S;
+  const char* only = argc > 2 ? argv[2] : "";
+  if (!strcmp(only, "peak") || !only[0]) {
+    for (int wgs : {256, 512, 1024}) {
+      char nm[64]; snprintf(nm, 64, "mfma_peak 4acc grid %d", wgs);
+      report(nm, timeit(st, 5, [&] { hipLaunchKernelGGL(k_mfma_peak<4>, dim3(wgs), dim3(256), 0, st, 4000, I); return hipGetLastError(); }), 4096.0 * 4 * 4000 * 4 * wgs);
+    }
+  }
+  if (!strcmp(only, "var") || !only[0]) {
+    // main-loop-only variants of the conv_embed_fwd GEMM (raw accumulator stores)
+    GemmParams P{};
+    P.M = M; P.N = B * S; P.K = D; P.nk = D / BK;
+    P.A = Wi; P.a_rs = D; P.B = X; P.b_rs = S; P.b_bs = (long)D * S; P.S = S;
+    P.C = I; P.c_rs = P.N; P.slab_stride = 0;
+    report("v: KC x RC_FLAT slab-store", timeit(st, 20, [&] { return launch_gemm<128, 128, SRC_KC, SRC_RC_FLAT, EPI_SLAB>(st, P, 1); }), 2.0 * M * NS * D);
+    for (int dbg : {1, 2, 3}) {
+      GemmParams D1 = P; D1.dbg = dbg;
+      char nm[64]; snprintf(nm, 64, "v: KC x RC_FLAT dbg=%d", dbg);
+      report(nm, timeit(st, 20, [&] { return launch_gemm<128, 128, SRC_KC, SRC_RC_FLAT, EPI_SLAB>(st, D1, 1); }), 2.0 * M * NS * D);
+    }
+    GemmParams Q = P; Q.B = X; Q.b_rs = P.N; // treat X as plain [K][N] row-major
+    report("v: KC x RC slab-store", timeit(st, 20, [&] { return launch_gemm<128, 128, SRC_KC, SRC_RC, EPI_SLAB>(st, Q, 1); }), 2.0 * M * NS * D);
+    GemmParams R2 = P; R2.A = X; R2.a_rs = M;  // A as [K][M] row-contig
+    report("v: RC x RC slab-store", timeit(st, 20, [&] { return launch_gemm<128, 128, SRC_RC, SRC_RC, EPI_SLAB>(st, R2, 1); }), 2.0 * M * NS * D);
+  }
+  if (only[0] && strcmp(only, "conv") && strcmp(only, "all")) return 0;
   report("conv_embed_fwd(mask)", timeit(st, 20, [&] { return conv_embed_fwd(st, B, D, S, M, X, mask, 0, 2.f, Wi, bi, I); }), 2.0 * M * NS * D);
   report("conv_embed_fwd(nomask)", timeit(st, 20, [&] { return conv_embed_fwd(st, B, D, S, M, X, nullptr, 0, 2.f, Wi, bi, I); }), 2.0 * M * NS * D);
   report("conv_att_fwd", timeit(st, 20, [&] { return conv_att_fwd(st, B, M, S, A, I, Wp, bp, u, ws, T, epart); }), 2.0 * A * NS * M);
@@ -61,7 +103,7 @@ int main(int argc, char** argv) {
   // small GEMMs
   float* h = dev_rand((size_t)B * 2048, 0.5f), *W = dev_rand((size_t)2048 * 2048, 0.08f);
   float* C; CK(hipMalloc(&C, (size_t)8 * B * 2048 * 4));
-  LinOpts o;
+  LinOpts o; o.slab = slab; o.slab_floats = sl;
   struct Sh { const char* n; int N, Kd; };
   const Sh nts[] = {{"nt N2048 K512", 2048, 512}, {"nt N512 K512", 512, 512}, {"nt N1000 K512", 1000, 512},
                     {"nt N196 K512", 196, 512}, {"nt N512 K196", 512, 196}, {"nt N512 K2048", 512, 2048}};
