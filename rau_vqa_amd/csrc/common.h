@@ -21,6 +21,14 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+// tanh to ~1e-7 absolute: odd polynomial below 1/8 (no cancellation), else
+// 1 - 2/(exp(2|x|)+1) on the hardware exp; saturates cleanly to +-1.
+__device__ __forceinline__ float tanh_fast(float x) {
+  const float ax = fabsf(x), x2 = x * x;
+  const float p = x * (1.f + x2 * (-0.33333334f + x2 * (0.13333334f + x2 * -0.053968254f)));
+  const float t = 1.f - 2.f / (__expf(2.f * ax) + 1.f);
+  return ax < 0.125f ? p : copysignf(t, x);
+}
 
 // Dropout keep-bit of flat element `e` of a bit-packed mask (bit e&31 of word e>>5).
 __device__ __forceinline__ uint32_t mask_bit(const uint32_t* __restrict__ bits, size_t e) {

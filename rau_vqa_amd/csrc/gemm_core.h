@@ -17,7 +17,6 @@
 
 namespace rau {
 
-constexpr int BK = 16;    // K-step per LDS stage
 constexpr int LPAD = 4;   // row padding (floats): keeps 16-B alignment
 
 // Superset of the arguments any loader/epilogue combination needs.
@@ -33,11 +32,7 @@ struct GemmParams {
   // flattened (sample, position) column space: n -> (n / S, n % S)
   int S;
   int cps;              // BK-chunks per sample (SC loaders)
-  // dropout mask applied by a masked loader
-  const uint32_t* mask; float mscale; size_t mask_e0;
-  // dS-on-the-fly loader: dS[b,k,s] = dz[b,s] * ws[k] * (1 - T[b,k,s]^2)
-  const float* dz; const float* ws;
-  // epilogue
+    // epilogue
   float* C; long c_rs; long c_bs; long slab_stride;
   const float* bias; const float* bias2;
   const float* addend; long add_rs;
@@ -56,29 +51,31 @@ struct GemmParams {
 
 // ---------------------------------------------------------------- loaders
 // Every loader: init(...), load(step) global->regs, store(lds) regs->LDS tile
-// [BK][BT+LPAD].
+// [BKT][BT+LPAD].  BKT = K-step per LDS stage.
 
 // Operand stored [rows][K], K contiguous.
-template <int BT>
+template <int BT, int BKT>
 struct LoadKC {
-  static constexpr int NI = BT * 4 / 256;
+  static constexpr int LPR = BKT / 4;          // lanes (float4) per row
+  static constexpr int RPP = 256 / LPR;        // rows per pass
+  static constexpr int NI = BT / RPP;
   const float* p[NI];
   bool ok[NI];
   float4 v[NI];
   int kc, K;
-  __device__ __forceinline__ void init(const float* base, long rs, int row0, int rows,
-                                       int K_, int tid) {
-    K = K_;
-    kc = (tid & 3) * 4;
+  __device__ __forceinline__ void init(const GemmParams& P, const float* base, long rs, long bs,
+                                       int row0, int rows, int tid) {
+    K = P.K;
+    kc = (tid % LPR) * 4;
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
-      const int r = (tid + i * 256) >> 2;
+      const int r = tid / LPR + i * RPP;
       ok[i] = row0 + r < rows;
       p[i] = base + (long)(row0 + r) * rs + kc;
     }
   }
   __device__ __forceinline__ void load(int step) {
-    const int k0 = step * BK;
+    const int k0 = step * BKT;
 #pragma unroll
     for (int i = 0; i < NI; ++i)
       v[i] = (ok[i] && k0 + kc < K) ? *reinterpret_cast<const float4*>(p[i] + k0)
@@ -87,7 +84,7 @@ struct LoadKC {
   __device__ __forceinline__ void store(float* lds, int tid) const {
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
-      const int r = (tid + i * 256) >> 2;
+      const int r = tid / LPR + i * RPP;
       float* d = lds + kc * (BT + LPAD) + r;
       d[0] = v[i].x;
       d[BT + LPAD] = v[i].y;
@@ -99,24 +96,16 @@ struct LoadKC {
 
 // Operand stored [K][cols], cols contiguous.  FLAT: cols are a flattened
 // (sample, position) index, element (k, n) at base + (n/S)*bs + k*rs + n%S.
-// KIND: 0 plain, 1 dropout-masked (bit index = element offset from base),
-//       2 dS on the fly from T (base = T), dz[n], ws[k].
-template <int BT, bool FLAT, int KIND>
+template <int BT, int BKT, bool FLAT>
 struct LoadRC {
   static constexpr int CPR = BT / 4;
   static constexpr int RPP = 256 / CPR;
-  static constexpr int NI = BK / RPP;
+  static constexpr int NI = BKT / RPP;
   const float* p;
   long rs;
-  size_t eoff;
   bool ok;
   int kr, c4, K;
   float4 v[NI];
-  float aux[NI];
-  const uint32_t* mask;
-  float mscale;
-  const float* ws;
-  float4 dzv;
   __device__ __forceinline__ void init(const GemmParams& P, const float* base, long rs_,
                                        long bs, int col0, int cols, int tid) {
     K = P.K;
@@ -129,130 +118,71 @@ struct LoadRC {
     if (FLAT) off = (long)(col / P.S) * bs + (col % P.S);
     if (!ok) off = 0;
     p = base + off;
-    eoff = (size_t)off;
-    if (KIND == 1) { mask = P.mask; mscale = P.mscale; eoff += P.mask_e0; }
-    if (KIND == 2) {
-      ws = P.ws;
-      dzv = ok ? *reinterpret_cast<const float4*>(P.dz + col) : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
   }
   __device__ __forceinline__ void load(int step) {
-    // raw loads only: the dropout / dS transform happens in store(), so the
-    // global-load latency stays hidden behind the MFMA loop of the current tile
-    const int k0 = step * BK;
+    const int k0 = step * BKT;
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
       const int k = k0 + kr + i * RPP;
-      v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-      aux[i] = 0.f;
-      if (ok && k < K) {
-        v[i] = *reinterpret_cast<const float4*>(p + (long)k * rs);
-        if (KIND == 1)
-          aux[i] = __uint_as_float(mask_nib(mask, eoff + (size_t)k * rs));
-        if (KIND == 2) aux[i] = ws[k];
-      }
+      v[i] = (ok && k < K) ? *reinterpret_cast<const float4*>(p + (long)k * rs)
+                           : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   }
   __device__ __forceinline__ void store(float* lds, int tid) const {
 #pragma unroll
-    for (int i = 0; i < NI; ++i) {
-      float4 x = v[i];
-      if (KIND == 1) {
-        const uint32_t nib = __float_as_uint(aux[i]);
-        x.x = (nib & 1u) ? x.x * mscale : 0.f;
-        x.y = (nib & 2u) ? x.y * mscale : 0.f;
-        x.z = (nib & 4u) ? x.z * mscale : 0.f;
-        x.w = (nib & 8u) ? x.w * mscale : 0.f;
-      }
-      if (KIND == 2) {
-        const float w = aux[i];
-        x.x = dzv.x * w * (1.f - x.x * x.x);
-        x.y = dzv.y * w * (1.f - x.y * x.y);
-        x.z = dzv.z * w * (1.f - x.z * x.z);
-        x.w = dzv.w * w * (1.f - x.w * x.w);
-      }
-      *reinterpret_cast<float4*>(lds + (kr + i * RPP) * (BT + LPAD) + c4) = x;
-    }
+    for (int i = 0; i < NI; ++i)
+      *reinterpret_cast<float4*>(lds + (kr + i * RPP) * (BT + LPAD) + c4) = v[i];
   }
 };
 
-// "Sample-chunk" loader for weight gradients of the 1x1 convolutions: operand
-// stored [sample][rows][S], reduction over (sample, position); step g covers
-// positions [16*(g % cps), +16) of sample g / cps, zero-filled past S.
-// KIND as in LoadRC (mask bit index = element offset; 2 = dS from T).
-template <int BT, int KIND>
+// "Sample-chunk" loader for the weight gradients of the 1x1 convolutions:
+// operand stored [sample][rows][S], reduction over (sample, position); step g
+// covers positions [BKT*(g % cps), +BKT) of sample g / cps, zero-filled past S.
+// 8 lanes per row (BKT <= 32); lanes whose chunk lies beyond BKT stay idle.
+template <int BT, int BKT>
 struct LoadSC {
-  static constexpr int NI = BT * 4 / 256;
+  static constexpr int LPR = 8;
+  static constexpr int RPP = 256 / LPR;
+  static constexpr int NI = BT / RPP;
   long roff[NI];
   bool ok[NI];
-  float wsr[NI];
   float4 v[NI];
-  uint32_t nibs[NI];
-  float4 dzv;
   const float* base;
   long bs;
   int kc, S, cps;
-  const uint32_t* mask;
-  float mscale;
-  size_t me0;
-  const float* dz;
-  __device__ __forceinline__ void init(const GemmParams& P, const float* base_, long bs_,
-                                       int row0, int rows, int tid) {
+  __device__ __forceinline__ void init(const GemmParams& P, const float* base_, long rs,
+                                       long bs_, int row0, int rows, int tid) {
     base = base_;
     bs = bs_;
     S = P.S;
     cps = P.cps;
-    kc = (tid & 3) * 4;
+    kc = (tid % LPR) * 4;
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
-      const int r = (tid + i * 256) >> 2;
+      const int r = tid / LPR + i * RPP;
       ok[i] = row0 + r < rows;
       roff[i] = (long)(row0 + r) * S + kc;
-      if (KIND == 2) wsr[i] = ok[i] ? P.ws[row0 + r] : 0.f;
     }
-    if (KIND == 1) { mask = P.mask; mscale = P.mscale; me0 = P.mask_e0; }
-    if (KIND == 2) dz = P.dz;
   }
   __device__ __forceinline__ void load(int g) {
     const int b = g / cps;
-    const int s0 = (g - b * cps) * BK;
-    const bool kin = s0 + kc < S;
-    dzv = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (KIND == 2 && kin) dzv = *reinterpret_cast<const float4*>(dz + (long)b * S + s0 + kc);
+    const int s0 = (g - b * cps) * BKT;
+    const bool kin = kc < BKT && s0 + kc < S;
 #pragma unroll
-    for (int i = 0; i < NI; ++i) {
-      v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-      nibs[i] = 0u;
-      if (ok[i] && kin) {
-        const long e = (long)b * bs + roff[i] + s0;
-        v[i] = *reinterpret_cast<const float4*>(base + e);
-        if (KIND == 1) nibs[i] = mask_nib(mask, me0 + (size_t)e);
-      }
-    }
+    for (int i = 0; i < NI; ++i)
+      v[i] = (ok[i] && kin) ? *reinterpret_cast<const float4*>(base + (long)b * bs + roff[i] + s0)
+                            : make_float4(0.f, 0.f, 0.f, 0.f);
   }
   __device__ __forceinline__ void store(float* lds, int tid) const {
+    if (kc >= BKT) return;
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
-      float4 x = v[i];
-      if (KIND == 1) {
-        const uint32_t nib = nibs[i];
-        x.x = (nib & 1u) ? x.x * mscale : 0.f;
-        x.y = (nib & 2u) ? x.y * mscale : 0.f;
-        x.z = (nib & 4u) ? x.z * mscale : 0.f;
-        x.w = (nib & 8u) ? x.w * mscale : 0.f;
-      }
-      if (KIND == 2) {
-        x.x = dzv.x * wsr[i] * (1.f - x.x * x.x);
-        x.y = dzv.y * wsr[i] * (1.f - x.y * x.y);
-        x.z = dzv.z * wsr[i] * (1.f - x.z * x.z);
-        x.w = dzv.w * wsr[i] * (1.f - x.w * x.w);
-      }
-      const int r = (tid + i * 256) >> 2;
+      const int r = tid / LPR + i * RPP;
       float* d = lds + kc * (BT + LPAD) + r;
-      d[0] = x.x;
-      d[BT + LPAD] = x.y;
-      d[2 * (BT + LPAD)] = x.z;
-      d[3 * (BT + LPAD)] = x.w;
+      d[0] = v[i].x;
+      d[BT + LPAD] = v[i].y;
+      d[2 * (BT + LPAD)] = v[i].z;
+      d[3 * (BT + LPAD)] = v[i].w;
     }
   }
 };
@@ -262,46 +192,13 @@ enum Src : int {
   SRC_KC = 0,        // [rows][K]
   SRC_RC = 1,        // [K][cols]
   SRC_RC_FLAT = 2,   // [sample][K][S], flattened columns
-  SRC_RC_FLAT_MASK = 3,
-  SRC_RC_FLAT_DS = 4,
-  SRC_SC = 5,        // [sample][rows][S], reduction over (sample, position)
-  SRC_SC_MASK = 6,
-  SRC_SC_DS = 7
+  SRC_SC = 3         // [sample][rows][S], reduction over (sample, position)
 };
-
-template <int BT, int SRC> struct LoaderOf;
-template <int BT> struct LoaderOf<BT, SRC_KC> {
-  using type = LoadKC<BT>;
-  static __device__ __forceinline__ void init(type& L, const GemmParams& P, const float* base,
-                                              long rs, long bs, int row0, int rows, int tid) {
-    L.init(base, rs, row0, rows, P.K, tid);
-  }
-};
-#define RAU_LOADER_RC(SRCV, FLATV, KINDV)                                                     \
-  template <int BT> struct LoaderOf<BT, SRCV> {                                               \
-    using type = LoadRC<BT, FLATV, KINDV>;                                                    \
-    static __device__ __forceinline__ void init(type& L, const GemmParams& P,                 \
-                                                const float* base, long rs, long bs,          \
-                                                int row0, int rows, int tid) {                \
-      L.init(P, base, rs, bs, row0, rows, tid);                                               \
-    }                                                                                         \
-  };
-RAU_LOADER_RC(SRC_RC, false, 0)
-RAU_LOADER_RC(SRC_RC_FLAT, true, 0)
-RAU_LOADER_RC(SRC_RC_FLAT_MASK, true, 1)
-RAU_LOADER_RC(SRC_RC_FLAT_DS, true, 2)
-#define RAU_LOADER_SC(SRCV, KINDV)                                                            \
-  template <int BT> struct LoaderOf<BT, SRCV> {                                               \
-    using type = LoadSC<BT, KINDV>;                                                           \
-    static __device__ __forceinline__ void init(type& L, const GemmParams& P,                 \
-                                                const float* base, long rs, long bs,          \
-                                                int row0, int rows, int tid) {                \
-      L.init(P, base, bs, row0, rows, tid);                                                   \
-    }                                                                                         \
-  };
-RAU_LOADER_SC(SRC_SC, 0)
-RAU_LOADER_SC(SRC_SC_MASK, 1)
-RAU_LOADER_SC(SRC_SC_DS, 2)
+template <int BT, int BKT, int SRC> struct LoaderOf;
+template <int BT, int BKT> struct LoaderOf<BT, BKT, SRC_KC> { using type = LoadKC<BT, BKT>; };
+template <int BT, int BKT> struct LoaderOf<BT, BKT, SRC_RC> { using type = LoadRC<BT, BKT, false>; };
+template <int BT, int BKT> struct LoaderOf<BT, BKT, SRC_RC_FLAT> { using type = LoadRC<BT, BKT, true>; };
+template <int BT, int BKT> struct LoaderOf<BT, BKT, SRC_SC> { using type = LoadSC<BT, BKT>; };
 
 // -------------------------------------------------------------- epilogues
 enum Epi : int {
@@ -312,8 +209,9 @@ enum Epi : int {
   EPI_DI = 4         // dZ = (acc + dj[b,m] a[n]) * (1 - I^2)
 };
 
-template <int BM, int BN, int ASRC, int BSRC, int EPI>
+template <int BM, int BN, int BKT, int ASRC, int BSRC, int EPI>
 __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams P) {
+  constexpr int BK = BKT;
   constexpr int WM = BM / 2, WN = BN / 2;   // wave tile
   constexpr int IM = WM / 32, JN = WN / 32; // 32x32 blocks per wave
   constexpr int LDA = BM + LPAD, LDB = BN + LPAD;
@@ -338,10 +236,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams P) {
   int nsteps = P.nk - step0;
   if (nsteps > P.nk_per_split) nsteps = P.nk_per_split;
 
-  typename LoaderOf<BM, ASRC>::type LA;
-  typename LoaderOf<BN, BSRC>::type LB;
-  LoaderOf<BM, ASRC>::init(LA, P, P.A, P.a_rs, P.a_bs, m0, P.M, tid);
-  LoaderOf<BN, BSRC>::init(LB, P, P.B, P.b_rs, P.b_bs, n0, P.N, tid);
+  typename LoaderOf<BM, BKT, ASRC>::type LA;
+  typename LoaderOf<BN, BKT, BSRC>::type LB;
+  LA.init(P, P.A, P.a_rs, P.a_bs, m0, P.M, tid);
+  LB.init(P, P.B, P.b_rs, P.b_bs, n0, P.N, tid);
 
   f32x16 acc[IM][JN];
 #pragma unroll
@@ -371,8 +269,6 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams P) {
     const float* as = As + cur * BK * LDA + fa;
     const float* bs = Bs + cur * BK * LDB + fb;
     // fragments of k-step kk+1 are read from LDS before the MFMAs of k-step kk issue
-    // (the sched_group_barrier sequence pins that order; hipcc otherwise sinks the
-    // reads back behind the MFMAs and exposes the LDS latency on every k-step)
     float a[2][IM], b[2][JN];
 #pragma unroll
     for (int i = 0; i < IM; ++i) a[0][i] = as[i * 32];
@@ -392,13 +288,6 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams P) {
 #pragma unroll
         for (int j = 0; j < JN; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c][i], b[c][j], acc[i][j], 0, 0, 0);
-    }
-    constexpr int kRd = (IM + 1) / 2 + (JN + 1) / 2;  // ds_read2_b32 per k-step
-    __builtin_amdgcn_sched_group_barrier(0x100, 2 * kRd, 0);   // reads of k-steps 0 and 1
-#pragma unroll
-    for (int kk = 0; kk < BK / 2; ++kk) {
-      __builtin_amdgcn_sched_group_barrier(0x008, IM * JN, 0);  // MFMAs of k-step kk
-      if (kk + 2 < BK / 2) __builtin_amdgcn_sched_group_barrier(0x100, kRd, 0);  // reads kk+2
     }
     if (more && !(P.dbg & 1)) {
       LA.store(As + (cur ^ 1) * BK * LDA, tid);
@@ -435,7 +324,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams P) {
             v = v * P.alpha + bsum;
             if (P.addend) v += P.addend[(long)m * P.add_rs + n];
             if (P.accumulate) v += C[ci];
-            if (P.act == 1) v = tanhf(v);
+            if (P.act == 1) v = tanh_fast(v);
             if (P.ymul) {
               const float y = P.ymul[(long)m * P.y_rs + n];
               v *= (1.f - y * y);
@@ -497,10 +386,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams P) {
           if (EPI != EPI_CONV_TANH)
             pvm = staged ? uvb[rl] : (m < P.M ? pv[(long)b * P.M + m] : 0.f);
           if (EPI == EPI_CONV_TANH) {
-            const float t = tanhf(v + rowv[rl]);
+            const float t = tanh_fast(v + rowv[rl]);
             if (ok) P.C[ci] = t;
           } else if (EPI == EPI_ATT_SCORE) {
-            const float t = tanhf(v + rowv[rl] + pvm);
+            const float t = tanh_fast(v + rowv[rl] + pvm);
             if (ok) {
               P.C[ci] = t;
               esum[j] += rowv2[rl] * t;
@@ -528,7 +417,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams P) {
 }
 
 // ------------------------------------------------------------ host launch
-template <int BM, int BN, int ASRC, int BSRC, int EPI>
+template <int BM, int BN, int BKT, int ASRC, int BSRC, int EPI>
 inline hipError_t launch_gemm(hipStream_t st, GemmParams P, int splits) {
   P.tiles_m = (P.M + BM - 1) / BM;
   P.tiles_n = (P.N + BN - 1) / BN;
@@ -537,7 +426,7 @@ inline hipError_t launch_gemm(hipStream_t st, GemmParams P, int splits) {
   P.nk_per_split = (P.nk + splits - 1) / splits;
   splits = P.nk_per_split > 0 ? (P.nk + P.nk_per_split - 1) / P.nk_per_split : 1;
   dim3 grid(P.tiles_m * P.tiles_n, 1, splits);
-  hipLaunchKernelGGL((gemm_kernel<BM, BN, ASRC, BSRC, EPI>), grid, dim3(256), 0, st, P);
+  hipLaunchKernelGGL((gemm_kernel<BM, BN, BKT, ASRC, BSRC, EPI>), grid, dim3(256), 0, st, P);
   return hipGetLastError();
 }
 

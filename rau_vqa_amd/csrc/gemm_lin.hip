@@ -6,6 +6,8 @@
 
 namespace rau {
 
+constexpr int BK = 32;  // K-step per LDS stage for the Linear GEMMs
+
 static GemmParams lin_params(int M, int N, int K, const float* A, long lda, const float* W,
                              long ldw, float* C, long ldc, const LinOpts& o) {
   GemmParams P{};
@@ -43,13 +45,13 @@ static hipError_t lin_gemm(hipStream_t st, int M, int N, int K, const float* A, 
                            const float* W, long ldw, float* C, long ldc, const LinOpts& o) {
   GemmParams P = lin_params(M, N, K, A, lda, W, ldw, C, ldc, o);
   if ((long)M * N >= 128L * 128 * 256)
-    return launch_gemm<128, 128, ASRC, BSRC, EPI_LIN>(st, P, 1);
+    return launch_gemm<128, 128, BK, ASRC, BSRC, EPI_LIN>(st, P, 1);
   const int s = skinny_splits(M, N, K, o);
-  if (s <= 1) return launch_gemm<64, 64, ASRC, BSRC, EPI_LIN>(st, P, 1);
+  if (s <= 1) return launch_gemm<64, 64, BK, ASRC, BSRC, EPI_LIN>(st, P, 1);
   P.C = o.slab;
   P.c_rs = N;
   P.slab_stride = (long)M * N;
-  hipError_t e = launch_gemm<64, 64, ASRC, BSRC, EPI_SLAB>(st, P, s);
+  hipError_t e = launch_gemm<64, 64, BK, ASRC, BSRC, EPI_SLAB>(st, P, s);
   if (e != hipSuccess) return e;
   return lin_reduce_epilogue(st, M, N, s, o.slab, C, ldc, o);
 }
@@ -84,12 +86,12 @@ hipError_t gemm_tn_acc(hipStream_t st, int M, int N, int K, const float* A, long
   const int s = tn_splits(M, N, K);
   if (s <= 1) {
     GemmParams P = lin_params(M, N, K, A, lda, B, ldb, C, ldc, o);
-    return launch_gemm<128, 128, SRC_RC, SRC_RC, EPI_LIN>(st, P, 1);
+    return launch_gemm<128, 128, BK, SRC_RC, SRC_RC, EPI_LIN>(st, P, 1);
   }
   if (ldc != N) return hipErrorInvalidValue;
   GemmParams P = lin_params(M, N, K, A, lda, B, ldb, slab, N, o);
   P.slab_stride = (long)M * N;
-  hipError_t e = launch_gemm<128, 128, SRC_RC, SRC_RC, EPI_SLAB>(st, P, s);
+  hipError_t e = launch_gemm<128, 128, BK, SRC_RC, SRC_RC, EPI_SLAB>(st, P, s);
   if (e != hipSuccess) return e;
   return splitk_reduce_acc(st, (size_t)M * N, s, slab, (size_t)M * N, C);
 }

@@ -39,29 +39,26 @@ hipError_t gemm_tn_acc(hipStream_t st, int M, int N, int K, const float* A, long
                        const float* B, long ldb, float* C, long ldc, float* slab);
 
 // ----------------------------------------------------------- conv GEMMs (gemm_conv.hip)
-// I[b,m,s] = tanh(sum_d Wi[m,d] * drop(X)[b,d,s] + bi[m])      (reference SS:238-242)
+// I[b,m,s] = tanh(sum_d Wi[m,d] * X'[b,d,s] + bi[m])   (reference SS:238-242; X' is the
+// feature map with dropout already applied, see dropout_features; nB may be H*B)
 hipError_t conv_embed_fwd(hipStream_t st, int nB, int D, int S, int M, const float* X,
-                          const uint32_t* mask, size_t mask_e0, float mscale, const float* Wi,
-                          const float* bi, float* I);
+                          const float* Wi, const float* bi, float* I);
 // T[b,k,s] = tanh(sum_m Wp[k,m] I[b,m,s] + bp[k] + u[b,k]); e_part[t][b*S+s] = partial
-// sum_k ws[k] T over the t-th 128-row tile (SS:244-252).  Returns tile count via *tiles.
+// sum_k ws[k] T over the t-th 128-row tile (SS:244-252).
 int conv_att_tiles(int A);
 hipError_t conv_att_fwd(hipStream_t st, int nB, int M, int S, int A, const float* I,
                         const float* Wp, const float* bp, const float* u, const float* ws,
                         float* T, float* e_part);
-// dZ[b,m,s] = (sum_k Wp[k,m] dS[b,k,s] + dj[b,m] a[b,s]) * (1 - I^2),
-// dS[b,k,s] = dz[b,s] ws[k] (1 - T^2) computed on the fly.
-hipError_t conv_att_dgrad(hipStream_t st, int nB, int M, int S, int A, const float* T,
-                          const float* dz, const float* ws, const float* Wp, const float* dj,
-                          const float* a, const float* I, float* dZ);
-// dWp[k,m] += sum_{b,s} dS[b,k,s] I[b,m,s]   and   dWi[m,d] += sum_{b,s} dZ[b,m,s] drop(X)[b,d,s]
+// dZ[b,m,s] = (sum_k Wp[k,m] dS[b,k,s] + dj[b,m] a[b,s]) * (1 - I^2)
+hipError_t conv_att_dgrad(hipStream_t st, int nB, int M, int S, int A, const float* dS,
+                          const float* Wp, const float* dj, const float* a, const float* I,
+                          float* dZ);
+// dWp[k,m] += sum_{b,s} dS[b,k,s] I[b,m,s]   and   dWi[m,d] += sum_{b,s} dZ[b,m,s] X'[b,d,s]
 size_t conv_wgrad_slab_floats(int nB, int rowsA, int rowsB, int S);
-hipError_t conv_att_wgrad(hipStream_t st, int nB, int M, int S, int A, const float* T,
-                          const float* dz, const float* ws, const float* I, float* dWp,
-                          float* slab);
+hipError_t conv_att_wgrad(hipStream_t st, int nB, int M, int S, int A, const float* dS,
+                          const float* I, float* dWp, float* slab);
 hipError_t conv_embed_wgrad(hipStream_t st, int nB, int D, int S, int M, const float* dZ,
-                            const float* X, const uint32_t* mask, size_t mask_e0, float mscale, float* dWi,
-                            float* slab);
+                            const float* X, float* dWi, float* slab);
 
 // --------------------------------------------------------- pointwise (kernels.hip)
 enum GateOrder { GATES_ATT = 0 /* i g f o, ATTLSTM.lua:12-19 */,
@@ -89,9 +86,12 @@ hipError_t attselect_bwd(hipStream_t st, int nB, int M, int S, const float* I, c
                          float* da_part /* [M/64][nB*S] */);
 hipError_t softmax_bwd(hipStream_t st, int rows, int S, const float* a, const float* da_lin,
                        const float* da_part, int parts, long part_stride, float* dz);
-// du[b,k] = ws[k] sum_s dz[b,s] (1-T^2);  dwsp[b,k] = sum_s dz[b,s] T[b,k,s]
-hipError_t att_score_bwd(hipStream_t st, int nB, int A, int S, const float* T, const float* dz,
+// In place T -> dS[b,k,s] = dz[b,s] ws[k] (1-T^2); du[b,k] = sum_s dS; dwsp[b,k] = sum_s dz T
+hipError_t att_score_bwd(hipStream_t st, int nB, int A, int S, float* T_to_dS, const float* dz,
                          const float* ws, float* du, float* dwsp);
+// xd[h][i] = X[i] * keep(h, i) * scale for h < H, i < per_hop (feature-map dropout, SS:239)
+hipError_t dropout_features(hipStream_t st, int H, size_t per_hop, const float* X,
+                            const uint32_t* mask, float mscale, float* xd);
 // rs[row] = sum_s X[row, s]
 hipError_t row_sums(hipStream_t st, int rows, int S, const float* X, float* rs);
 // dst[n] += sum_rows X[row*ld + n]   (two-stage, deterministic; tmp >= 32*N floats)

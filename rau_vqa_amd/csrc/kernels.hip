@@ -64,7 +64,7 @@ __global__ void k_embed_fwd(int rows, int E, const float* __restrict__ emb,
     const int row = (int)(i / E), e = (int)(i - (size_t)row * E);
     float v = emb[(size_t)(tokens[row] - 1) * E + e];
     if (mask) v = mask_bit(mask, i) ? v * mscale : 0.f;
-    we[i] = tanhf(v);
+    we[i] = tanh_fast(v);
   }
 }
 hipError_t embed_fwd(hipStream_t st, int rows, int E, const float* emb, const int32_t* tokens,
@@ -126,13 +126,13 @@ __global__ void k_lstm_fwd(int nB, int R, float* __restrict__ g4,
     const float gi = sigmoidf_(g[GS::I * R + r]);
     const float gf = sigmoidf_(g[GS::F * R + r]);
     const float go = sigmoidf_(g[GS::O * R + r]);
-    const float gg = tanhf(g[GS::G * R + r]);
+    const float gg = tanh_fast(g[GS::G * R + r]);
     g[GS::I * R + r] = gi;
     g[GS::F * R + r] = gf;
     g[GS::O * R + r] = go;
     g[GS::G * R + r] = gg;
     const float cn = gf * c_prev[(size_t)b * cp_rs + r] + gi * gg;
-    const float tc = tanhf(cn);
+    const float tc = tanh_fast(cn);
     const float hn = go * tc;
     c[(size_t)b * c_rs + r] = cn;
     h[(size_t)b * h_rs + r] = hn;
@@ -331,8 +331,8 @@ hipError_t softmax_bwd(hipStream_t st, int rows, int S, const float* a, const fl
   return hipGetLastError();
 }
 
-// one wave per (b,k) row of T
-__global__ void k_att_score_bwd(int nB, int A, int S, const float* __restrict__ T,
+// one wave per (b,k) row of T; T is overwritten by dS (T is dead after this point)
+__global__ void k_att_score_bwd(int nB, int A, int S, float* __restrict__ T,
                                 const float* __restrict__ dz, const float* __restrict__ ws,
                                 float* __restrict__ du, float* __restrict__ dwsp) {
   const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -340,26 +340,59 @@ __global__ void k_att_score_bwd(int nB, int A, int S, const float* __restrict__ 
   const int b = row / A, k = row - b * A;
   const int l = threadIdx.x & 63;
   const int S4 = S >> 2;
-  const float4* tr = reinterpret_cast<const float4*>(T + (size_t)row * S);
+  float4* tr = reinterpret_cast<float4*>(T + (size_t)row * S);
   const float4* dr = reinterpret_cast<const float4*>(dz + (size_t)b * S);
+  const float w = ws[k];
   float s1 = 0.f, s2 = 0.f;
   for (int q = l; q < S4; q += 64) {
     const float4 t = tr[q], d = dr[q];
-    s1 += d.x * (1.f - t.x * t.x) + d.y * (1.f - t.y * t.y) + d.z * (1.f - t.z * t.z) +
-          d.w * (1.f - t.w * t.w);
+    float4 o;
+    o.x = d.x * w * (1.f - t.x * t.x);
+    o.y = d.y * w * (1.f - t.y * t.y);
+    o.z = d.z * w * (1.f - t.z * t.z);
+    o.w = d.w * w * (1.f - t.w * t.w);
+    tr[q] = o;
+    s1 += (o.x + o.y) + (o.z + o.w);
     s2 += d.x * t.x + d.y * t.y + d.z * t.z + d.w * t.w;
   }
   s1 = wave_sum(s1);
   s2 = wave_sum(s2);
   if (l == 0) {
-    du[row] = ws[k] * s1;
+    du[row] = s1;
     dwsp[row] = s2;
   }
 }
-hipError_t att_score_bwd(hipStream_t st, int nB, int A, int S, const float* T, const float* dz,
+hipError_t att_score_bwd(hipStream_t st, int nB, int A, int S, float* T_to_dS, const float* dz,
                          const float* ws, float* du, float* dwsp) {
-  hipLaunchKernelGGL(k_att_score_bwd, dim3((nB * A + 3) / 4), dim3(256), 0, st, nB, A, S, T, dz,
-                     ws, du, dwsp);
+  hipLaunchKernelGGL(k_att_score_bwd, dim3((nB * A + 3) / 4), dim3(256), 0, st, nB, A, S, T_to_dS,
+                     dz, ws, du, dwsp);
+  return hipGetLastError();
+}
+
+// feature-map dropout for every hop in one pass (reference SS:239, one mask per clone)
+__global__ void k_dropout_features(int H, size_t per4, const float4* __restrict__ X,
+                                   const uint32_t* __restrict__ mask, float mscale,
+                                   float4* __restrict__ xd) {
+  for (size_t q = blockIdx.x * (size_t)blockDim.x + threadIdx.x; q < per4;
+       q += (size_t)gridDim.x * blockDim.x) {
+    const float4 x = X[q];
+    for (int h = 0; h < H; ++h) {
+      const size_t e = ((size_t)h * per4 + q) * 4;
+      const uint32_t nib = mask_nib(mask, e);
+      float4 o;
+      o.x = (nib & 1u) ? x.x * mscale : 0.f;
+      o.y = (nib & 2u) ? x.y * mscale : 0.f;
+      o.z = (nib & 4u) ? x.z * mscale : 0.f;
+      o.w = (nib & 8u) ? x.w * mscale : 0.f;
+      xd[(size_t)h * per4 + q] = o;
+    }
+  }
+}
+hipError_t dropout_features(hipStream_t st, int H, size_t per_hop, const float* X,
+                            const uint32_t* mask, float mscale, float* xd) {
+  hipLaunchKernelGGL(k_dropout_features, dim3(grid_for(per_hop / 4)), dim3(256), 0, st, H,
+                     per_hop / 4, reinterpret_cast<const float4*>(X), mask, mscale,
+                     reinterpret_cast<float4*>(xd));
   return hipGetLastError();
 }
 
@@ -618,7 +651,7 @@ __global__ void k_lin_reduce_epilogue(int M, int N, int splits, const float* __r
     if (o.addend) v += o.addend[(long)m * o.add_rs + n];
     const long ci = (long)m * ldc + n;
     if (o.accumulate) v += C[ci];
-    if (o.act == 1) v = tanhf(v);
+    if (o.act == 1) v = tanh_fast(v);
     if (o.ymul) {
       const float y = o.ymul[(long)m * o.y_rs + n];
       v *= (1.f - y * y);

@@ -119,6 +119,8 @@ struct rau_ctx {
   // encoder activations
   float *we, *G1, *G2, *c1, *h1, *c2, *h2, *tc1, *tc2, *x2, *q;
   // RAU activations
+  float *xd;          // [H][B][D][S] feature map after per-hop dropout (train mode)
+  bool I_shared = false;  // evaluate mode: i_embed output is hop-invariant, computed once
   float *qd, *Yq, *qf, *I, *T, *u, *e_part, *zm, *a, *jv, *j, *g4, *cc, *hh, *tc, *mf, *logits,
       *dl, *lossrow, *dopred, *losses_d, *hopw_d;
   int32_t* argmax_d;
@@ -391,6 +393,7 @@ int rau_create(const rau_config* cfg, rau_ctx** out) {
   CK(dalloc(ctx, &ctx->qd, HB * Q));
   CK(dalloc(ctx, &ctx->Yq, HB * M));
   CK(dalloc(ctx, &ctx->qf, HB * M));
+  CK(dalloc(ctx, &ctx->xd, HB * D * S));
   CK(dalloc(ctx, &ctx->I, HB * M * S));
   CK(dalloc(ctx, &ctx->T, HB * A * S));
   CK(dalloc(ctx, &ctx->u, (size_t)B * A));
@@ -425,13 +428,13 @@ int rau_create(const rau_config* cfg, rau_ctx** out) {
   CK(dalloc(ctx, &ctx->dz, HB * S));
   CK(dalloc(ctx, &ctx->du, HB * A));
   CK(dalloc(ctx, &ctx->dwsp, HB * A));
-  CK(dalloc(ctx, &ctx->dZ, (size_t)B * M * S));
+  CK(dalloc(ctx, &ctx->dZ, HB * M * S));
   CK(dalloc(ctx, &ctx->rsum, HB * M));
   CK(dalloc(ctx, &ctx->dqt, HB * M));
   CK(dalloc(ctx, &ctx->dQD, HB * Q));
   CK(dalloc(ctx, &ctx->dq, (size_t)B * Q));
   {
-    size_t sl = std::max(conv_wgrad_slab_floats(B, A, M, S), conv_wgrad_slab_floats(B, M, D, S));
+    size_t sl = std::max(conv_wgrad_slab_floats(B, A, M, S), conv_wgrad_slab_floats(H * B, M, D, S));
     const int rowsH = H * B, rowsT = T * B;
     const int shapes[][3] = {{K, M, rowsH},      {M, R, rowsH},      {4 * R, M, rowsH},
                              {4 * R, R, rowsH},  {M, S, rowsH},      {S, R, rowsH},
@@ -741,6 +744,20 @@ int rau_forward(rau_ctx* ctx) {
     RUN("q_proj_gemm", gflop(H * B, M, Q), 0,
         gemm_nt(st, H * B, M, Q, ctx->qd, Q, ctx->q_proj.W, Q, ctx->Yq, M, o));
   }
+  // i_embed SS:238-242 does not depend on the recurrence: all hops in one launch.
+  // Train mode: each hop clone has its own dropout mask on the feature map
+  // (SS:239, SS:343-347) -> xd[h] = X (.) mask_h, then one GEMM over H*B samples.
+  // Evaluate mode: dropout is the identity, so I is hop-invariant and computed once.
+  ctx->I_shared = (m_x == nullptr);
+  if (m_x) {
+    RUN("dropout_features", 0, (double)(H + 1) * B * D * S * 4,
+        dropout_features(st, H, (size_t)B * D * S, ctx->feats, m_x, sc(RAU_MASK_X), ctx->xd));
+    RUN("conv_embed_fwd", gflop(M, (double)H * B * S, D), ((double)H * B * D * S + (double)H * BM_ * S) * 4,
+        conv_embed_fwd(st, H * B, D, S, M, ctx->xd, ctx->i_embed.W, ctx->i_embed.b, ctx->I));
+  } else {
+    RUN("conv_embed_fwd", gflop(M, (double)B * S, D), ((double)B * D * S + BM_ * S) * 4,
+        conv_embed_fwd(st, B, D, S, M, ctx->feats, ctx->i_embed.W, ctx->i_embed.b, ctx->I));
+  }
   HIPC(hipMemsetAsync(ctx->cc, 0, BR_ * sizeof(float), st));  // att_c, att_h zeros SS:362-365
   HIPC(hipMemsetAsync(ctx->hh, 0, BR_ * sizeof(float), st));
   const int parts = conv_att_tiles(A);
@@ -748,7 +765,7 @@ int rau_forward(rau_ctx* ctx) {
     const float* hp = ctx->hh + (size_t)h * BR_;
     const float* cp = ctx->cc + (size_t)h * BR_;
     float* qf = ctx->qf + (size_t)h * BM_;
-    float* Ih = ctx->I + (size_t)h * BM_ * S;
+    float* Ih = ctx->I + (ctx->I_shared ? 0 : (size_t)h * BM_ * S);
     float* Th = ctx->T + (size_t)h * B * A * S;
     float* ah = ctx->a + (size_t)h * BS_;
     float* jh = ctx->j + (size_t)h * BM_;
@@ -762,10 +779,6 @@ int rau_forward(rau_ctx* ctx) {
       o.act = 1;
       RUN("small_gemm", gflop(B, M, R), 0, gemm_nt(st, B, M, R, hp, R, ctx->h_proj.W, R, qf, M, o));
     }
-    // i_embed SS:238-242 (dropout applied while staging X)
-    RUN("conv_embed_fwd", gflop(M, (double)B * S, D), ((double)B * D * S + BM_ * S) * 4,
-        conv_embed_fwd(st, B, D, S, M, ctx->feats, m_x, (size_t)h * B * D * S, sc(RAU_MASK_X),
-                       ctx->i_embed.W, ctx->i_embed.b, Ih));
     {  // attbycontent SS:244-252
       LINOPTS(o);
       o.bias = ctx->att_q.b;
@@ -849,7 +862,7 @@ int rau_backward(rau_ctx* ctx, const float* hop_w) {
   };
   auto sc = [&](int site) { return 1.f / (1.f - ctx->mp[site]); };
   const uint32_t *m_we = mk(RAU_MASK_WE), *m_rnn = mk(RAU_MASK_RNN), *m_q = mk(RAU_MASK_Q),
-                 *m_x = mk(RAU_MASK_X), *m_mf = mk(RAU_MASK_MF);
+                 *m_mf = mk(RAU_MASK_MF);
   auto gflop = [](double m, double n, double k) { return 2.0 * m * n * k; };
   const size_t BM_ = (size_t)B * M, BS_ = (size_t)B * S, BR_ = (size_t)B * R;
   const size_t BRq = (size_t)B * Rq;
@@ -864,11 +877,11 @@ int rau_backward(rau_ctx* ctx, const float* hop_w) {
   const float* dh_next = nullptr;
   const int chunks = (M + 63) / 64;
   for (int h = H - 1; h >= 0; --h) {
-    const float* hp = ctx->hh + (size_t)h * BR_;
     const float* cp = ctx->cc + (size_t)h * BR_;
     const float* qf = ctx->qf + (size_t)h * BM_;
-    const float* Ih = ctx->I + (size_t)h * BM_ * S;
-    const float* Th = ctx->T + (size_t)h * B * A * S;
+    const float* Ih = ctx->I + (ctx->I_shared ? 0 : (size_t)h * BM_ * S);
+    float* Th = ctx->T + (size_t)h * B * A * S;   // becomes dS in place
+    float* dZh = ctx->dZ + (size_t)h * BM_ * S;
     const float* ah = ctx->a + (size_t)h * BS_;
     const float* g4 = ctx->g4 + (size_t)h * B * 4 * R;
     float* dpre = ctx->dpre + (size_t)h * BM_;
@@ -920,16 +933,12 @@ int rau_backward(rau_ctx* ctx, const float* hop_w) {
       o.accumulate = 1;
       RUN("small_gemm", gflop(B, R, S), 0, gemm_nn(st, B, R, S, dzh, S, ctx->att_mem.W, R, dh_out, R, o));
     }
-    RUN("att_score_bwd", 4.0 * B * A * S, (double)B * A * S * 4,
+    RUN("att_score_bwd", 6.0 * B * A * S, (double)B * A * S * 8,
         att_score_bwd(st, B, A, S, Th, dzh, ctx->att_score.W, duh, ctx->dwsp + (size_t)h * B * A));
     RUN("conv_att_dgrad", gflop(M, (double)B * S, A), ((double)B * A * S + 2.0 * BM_ * S) * 4,
-        conv_att_dgrad(st, B, M, S, A, Th, dzh, ctx->att_score.W, ctx->att_i.W, djh, ah, Ih, ctx->dZ));
+        conv_att_dgrad(st, B, M, S, A, Th, ctx->att_i.W, djh, ah, Ih, dZh));
     RUN("conv_att_wgrad", gflop(A, M, (double)B * S), ((double)B * A * S + BM_ * S) * 4,
-        conv_att_wgrad(st, B, M, S, A, Th, dzh, ctx->att_score.W, Ih, ctx->att_i.dW, ctx->slab));
-    RUN("row_sums", 0, BM_ * S * 4.0, row_sums(st, B * M, S, ctx->dZ, ctx->rsum + (size_t)h * BM_));
-    RUN("conv_embed_wgrad", gflop(M, D, (double)B * S), (BM_ * S + (double)B * D * S) * 4,
-        conv_embed_wgrad(st, B, D, S, M, ctx->dZ, ctx->feats, m_x, (size_t)h * B * D * S,
-                         sc(RAU_MASK_X), ctx->i_embed.dW, ctx->slab));
+        conv_att_wgrad(st, B, M, S, A, Th, Ih, ctx->att_i.dW, ctx->slab));
     {  // dq~ = (dj + du Wa) (1 - qf^2)
       LINOPTS(o);
       o.addend = djh;
@@ -950,6 +959,18 @@ int rau_backward(rau_ctx* ctx, const float* hop_w) {
         gemm_nn(st, H * B, Q, M, ctx->dqt, M, ctx->q_proj.W, Q, ctx->dQD, Q, o));
     RUN("dq_reduce", 0, (double)H * B * Q * 4,
         dq_reduce(st, H, (size_t)B * Q, ctx->dQD, m_q, sc(RAU_MASK_Q), ctx->dq));
+  }
+  // i_embed weight gradient over all hops at once: dWi += sum_{h,b,s} dZ_h X'_h^T
+  // (the gradient w.r.t. the feature map itself is dead, SS:579, and never formed)
+  RUN("row_sums", 0, (double)H * BM_ * S * 4.0, row_sums(st, H * B * M, S, ctx->dZ, ctx->rsum));
+  if (!ctx->I_shared) {
+    RUN("conv_embed_wgrad", gflop(M, D, (double)H * B * S), ((double)H * BM_ * S + (double)H * B * D * S) * 4,
+        conv_embed_wgrad(st, H * B, D, S, M, ctx->dZ, ctx->xd, ctx->i_embed.dW, ctx->slab));
+  } else {
+    for (int h = 0; h < H; ++h)
+      RUN("conv_embed_wgrad", gflop(M, D, (double)B * S), (BM_ * S + (double)B * D * S) * 4,
+          conv_embed_wgrad(st, B, D, S, M, ctx->dZ + (size_t)h * BM_ * S, ctx->feats,
+                           ctx->i_embed.dW, ctx->slab));
   }
   // ---------------- mult-group weight gradients, one GEMM per weight over all hops
   {

@@ -66,7 +66,7 @@ int main(int argc, char** argv) {
   float* dz = dev_rand((size_t)B * S, 0.01f), *dj = dev_rand((size_t)B * M, 0.01f), *a = dev_rand((size_t)B * S, 0.01f);
   float* dZ; CK(hipMalloc(&dZ, (size_t)B * M * S * 4));
   float* dWp = dev_rand((size_t)A * M), *dWi = dev_rand((size_t)M * D);
-  size_t sl = conv_wgrad_slab_floats(B, M, D, S); if (conv_wgrad_slab_floats(B, A, M, S) > sl) sl = conv_wgrad_slab_floats(B, A, M, S);
+  size_t sl = conv_wgrad_slab_floats(8 * B, M, D, S); if (conv_wgrad_slab_floats(B, A, M, S) > sl) sl = conv_wgrad_slab_floats(B, A, M, S);
   float* slab; CK(hipMalloc(&slab, sl * 4 + (size_t)64 * 2048 * 512 * 4));
   const double NS = (double)B * S;
   const char* only = argc > 2 ? argv[2] : "";
@@ -79,27 +79,39 @@ int main(int argc, char** argv) {
   if (!strcmp(only, "var") || !only[0]) {
     // main-loop-only variants of the conv_embed_fwd GEMM (raw accumulator stores)
     GemmParams P{};
-    P.M = M; P.N = B * S; P.K = D; P.nk = D / BK;
+    P.M = M; P.N = B * S; P.K = D; P.nk = D / 32;
     P.A = Wi; P.a_rs = D; P.B = X; P.b_rs = S; P.b_bs = (long)D * S; P.S = S;
     P.C = I; P.c_rs = P.N; P.slab_stride = 0;
-    report("v: KC x RC_FLAT slab-store", timeit(st, 20, [&] { return launch_gemm<128, 128, SRC_KC, SRC_RC_FLAT, EPI_SLAB>(st, P, 1); }), 2.0 * M * NS * D);
+    report("v: KC x RC_FLAT slab-store", timeit(st, 20, [&] { return launch_gemm<128, 128, 32, SRC_KC, SRC_RC_FLAT, EPI_SLAB>(st, P, 1); }), 2.0 * M * NS * D);
     for (int dbg : {1, 2, 3}) {
       GemmParams D1 = P; D1.dbg = dbg;
       char nm[64]; snprintf(nm, 64, "v: KC x RC_FLAT dbg=%d", dbg);
-      report(nm, timeit(st, 20, [&] { return launch_gemm<128, 128, SRC_KC, SRC_RC_FLAT, EPI_SLAB>(st, D1, 1); }), 2.0 * M * NS * D);
+      report(nm, timeit(st, 20, [&] { return launch_gemm<128, 128, 32, SRC_KC, SRC_RC_FLAT, EPI_SLAB>(st, D1, 1); }), 2.0 * M * NS * D);
     }
     GemmParams Q = P; Q.B = X; Q.b_rs = P.N; // treat X as plain [K][N] row-major
-    report("v: KC x RC slab-store", timeit(st, 20, [&] { return launch_gemm<128, 128, SRC_KC, SRC_RC, EPI_SLAB>(st, Q, 1); }), 2.0 * M * NS * D);
+    report("v: KC x RC slab-store", timeit(st, 20, [&] { return launch_gemm<128, 128, 32, SRC_KC, SRC_RC, EPI_SLAB>(st, Q, 1); }), 2.0 * M * NS * D);
     GemmParams R2 = P; R2.A = X; R2.a_rs = M;  // A as [K][M] row-contig
-    report("v: RC x RC slab-store", timeit(st, 20, [&] { return launch_gemm<128, 128, SRC_RC, SRC_RC, EPI_SLAB>(st, R2, 1); }), 2.0 * M * NS * D);
+    report("v: RC x RC slab-store", timeit(st, 20, [&] { return launch_gemm<128, 128, 32, SRC_RC, SRC_RC, EPI_SLAB>(st, R2, 1); }), 2.0 * M * NS * D);
   }
   if (only[0] && strcmp(only, "conv") && strcmp(only, "all")) return 0;
-  report("conv_embed_fwd(mask)", timeit(st, 20, [&] { return conv_embed_fwd(st, B, D, S, M, X, mask, 0, 2.f, Wi, bi, I); }), 2.0 * M * NS * D);
-  report("conv_embed_fwd(nomask)", timeit(st, 20, [&] { return conv_embed_fwd(st, B, D, S, M, X, nullptr, 0, 2.f, Wi, bi, I); }), 2.0 * M * NS * D);
+  report("conv_embed_fwd", timeit(st, 20, [&] { return conv_embed_fwd(st, B, D, S, M, X, Wi, bi, I); }), 2.0 * M * NS * D);
+  {
+    const int H = 8;
+    float* xd; CK(hipMalloc(&xd, (size_t)H * B * D * S * 4));
+    float* I8; CK(hipMalloc(&I8, (size_t)H * B * M * S * 4));
+    uint32_t* m8; CK(hipMalloc(&m8, (size_t)H * B * D * S / 8 + 64));
+    CK(fill_masks(st, 1, 3, 0, 0.5f, (size_t)H * B * D * S, m8));
+    report("dropout_features x8", timeit(st, 10, [&] { return dropout_features(st, H, (size_t)B * D * S, X, m8, 2.f, xd); }), 0);
+    report("conv_embed_fwd x8 hops", timeit(st, 5, [&] { return conv_embed_fwd(st, H * B, D, S, M, xd, Wi, bi, I8); }), 2.0 * M * NS * D * H);
+    report("conv_embed_wgrad x8 hops", timeit(st, 5, [&] { return conv_embed_wgrad(st, H * B, D, S, M, I8, xd, dWi, slab); }), 2.0 * M * NS * D * H);
+    CK(hipFree(xd)); CK(hipFree(I8)); CK(hipFree(m8));
+  }
   report("conv_att_fwd", timeit(st, 20, [&] { return conv_att_fwd(st, B, M, S, A, I, Wp, bp, u, ws, T, epart); }), 2.0 * A * NS * M);
-  report("conv_att_dgrad", timeit(st, 20, [&] { return conv_att_dgrad(st, B, M, S, A, T, dz, ws, Wp, dj, a, I, dZ); }), 2.0 * A * NS * M);
-  report("conv_att_wgrad", timeit(st, 20, [&] { return conv_att_wgrad(st, B, M, S, A, T, dz, ws, I, dWp, slab); }), 2.0 * A * NS * M);
-  report("conv_embed_wgrad(mask)", timeit(st, 20, [&] { return conv_embed_wgrad(st, B, D, S, M, dZ, X, mask, 0, 2.f, dWi, slab); }), 2.0 * M * NS * D);
+  report("conv_att_dgrad", timeit(st, 20, [&] { return conv_att_dgrad(st, B, M, S, A, T, Wp, dj, a, I, dZ); }), 2.0 * A * NS * M);
+  report("conv_att_wgrad", timeit(st, 20, [&] { return conv_att_wgrad(st, B, M, S, A, T, I, dWp, slab); }), 2.0 * A * NS * M);
+  report("conv_embed_wgrad", timeit(st, 20, [&] { return conv_embed_wgrad(st, B, D, S, M, dZ, X, dWi, slab); }), 2.0 * M * NS * D);
+  { float* du; CK(hipMalloc(&du, (size_t)B * A * 8));
+    report("att_score_bwd", timeit(st, 20, [&] { return att_score_bwd(st, B, A, S, T, dz, ws, du, du + B * A); }), 0); }
   // small GEMMs
   float* h = dev_rand((size_t)B * 2048, 0.5f), *W = dev_rand((size_t)2048 * 2048, 0.08f);
   float* C; CK(hipMalloc(&C, (size_t)8 * B * 2048 * 4));
