@@ -21,23 +21,24 @@ hipError_t conv_embed_fwd(hipStream_t st, int nB, int D, int S, int M, const flo
   P.S = S;
   P.C = I; P.c_bs = (long)M * S;
   P.bias = bi;
-  return launch_gemm<128, 128, BK, SRC_KC, SRC_RC_FLAT, EPI_CONV_TANH>(st, P, 1);
+  P.act = 1;
+  return launch_gemm<128, 128, BK, SRC_KC, SRC_RC_FLAT, EPI_CONV>(st, P, 1);
 }
 
-int conv_att_tiles(int A) { return (A + 127) / 128; }
-
-// attbycontent, reference SS:244-252.
-hipError_t conv_att_fwd(hipStream_t st, int nB, int M, int S, int A, const float* I,
-                        const float* Wp, const float* bp, const float* u, const float* ws,
-                        float* T, float* e_part) {
+// P[b,k,s] = sum_m Wp[k,m] I[b,m,s] + bp[k]: the hop-invariant part of attbycontent's
+// pre-activation (reference SS:247-249); nB may be H*B.  The per-hop part
+// (+ u[b,k], tanh, score, softmax) is att_fwd_fused in kernels.hip.
+hipError_t conv_att_pre(hipStream_t st, int nB, int M, int S, int A, const float* I,
+                        const float* Wp, const float* bp, float* Pout) {
   GemmParams P{};
   P.M = A; P.N = nB * S; P.K = M; P.nk = (M + BK - 1) / BK;
   P.A = Wp; P.a_rs = M;
   P.B = I; P.b_rs = S; P.b_bs = (long)M * S;
   P.S = S;
-  P.C = T; P.c_bs = (long)A * S;
-  P.bias = bp; P.u = u; P.v1 = ws; P.out2 = e_part;
-  return launch_gemm<128, 128, BK, SRC_KC, SRC_RC_FLAT, EPI_ATT_SCORE>(st, P, 1);
+  P.C = Pout; P.c_bs = (long)A * S;
+  P.bias = bp;
+  P.act = 0;
+  return launch_gemm<128, 128, BK, SRC_KC, SRC_RC_FLAT, EPI_CONV>(st, P, 1);
 }
 
 // backward of attbycontent + attselect into the i_embed pre-activation gradient:

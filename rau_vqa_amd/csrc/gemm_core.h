@@ -41,11 +41,9 @@ struct GemmParams {
   int accumulate; int act;            // act: 0 none, 1 tanh
   float alpha;
   // conv epilogue extras
-  const float* u;      // [B, A]        (attention score epilogue)
-  const float* v1;     // ws / dj
-  const float* v2;     // a
+  const float* v1;     // dj [sample][M]
+  const float* v2;     // a  [sample][S]
   const float* I;      // saved I
-  float* out2;         // e_part
   int dbg;             // tools/kbench only: 1 = no global loads in the loop, 2 = no barriers
 };
 
@@ -204,9 +202,8 @@ template <int BT, int BKT> struct LoaderOf<BT, BKT, SRC_SC> { using type = LoadS
 enum Epi : int {
   EPI_LIN = 0,       // generic pointwise epilogue, row-major C
   EPI_SLAB = 1,      // split-K partial: raw accumulators to slab blockIdx.z
-  EPI_CONV_TANH = 2, // I = tanh(acc + bias[m]) in [sample][M][S]
-  EPI_ATT_SCORE = 3, // T = tanh(acc + bias[m] + u[b,m]); e_part[tm,n] = sum_m ws[m] T
-  EPI_DI = 4         // dZ = (acc + dj[b,m] a[n]) * (1 - I^2)
+  EPI_CONV = 2,      // C = act(acc + bias[m]) in [sample][M][S]   (act: 0 none, 1 tanh)
+  EPI_DI = 3         // dZ = (acc + dj[b,m] a[n]) * (1 - I^2)
 };
 
 template <int BM, int BN, int BKT, int ASRC, int BSRC, int EPI>
@@ -218,7 +215,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams P) {
   constexpr int kStage = 2 * BK * LDA + 2 * BK * LDB;  // floats of operand staging
   // epilogue scratch lives in the (then idle) staging area: per-row vectors,
   // per-(sample,row) vectors of the samples this tile's columns touch, column sums
-  constexpr int kUCap = kStage - 2 * BM - 2 * BN;
+  constexpr int kUCap = kStage - BM;
   __shared__ __attribute__((aligned(16))) float smem[kStage];
   float* As = smem;
   float* Bs = smem + 2 * BK * LDA;
@@ -336,35 +333,28 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams P) {
         }
     }
   } else {
-    // Flattened-column epilogues: n -> (sample b, position s).  Per-row vectors
-    // (bias, ws) and the per-(sample,row) vector (u or dj) of the few samples a
-    // tile's columns span are staged in LDS once, instead of one dependent
-    // global load per accumulator element.
+    // Flattened-column epilogues: n -> (sample b, position s).  The per-row bias and
+    // the per-(sample,row) vector dj of the few samples a tile's columns span are
+    // staged in LDS once, instead of one dependent global load per element.
     float* rowv = smem;                 // [BM] bias
-    float* rowv2 = smem + BM;           // [BM] ws
-    float* red = smem + 2 * BM;         // [2][BN] column partial sums
-    float* uv = smem + 2 * BM + 2 * BN; // [nsamp][BM] u / dj
+    float* uv = smem + BM;              // [nsamp][BM] dj
     const int b0 = n0 / P.S;
     int nlast = n0 + BN - 1;
     if (nlast > P.N - 1) nlast = P.N - 1;
     const int nsamp = nlast / P.S - b0 + 1;
     const bool staged = nsamp * BM <= kUCap;
-    const float* pv = EPI == EPI_ATT_SCORE ? P.u : P.v1;  // [sample][M]
     if (tid < BM) {
       const int m = m0 + tid;
-      rowv[tid] = (EPI != EPI_DI && m < P.M) ? P.bias[m] : 0.f;
-      rowv2[tid] = (EPI == EPI_ATT_SCORE && m < P.M) ? P.v1[m] : 0.f;
+      rowv[tid] = (EPI == EPI_CONV && m < P.M) ? P.bias[m] : 0.f;
     }
-    if (EPI != EPI_CONV_TANH && staged)
+    if (EPI == EPI_DI && staged)
       for (int e = tid; e < nsamp * BM; e += 256) {
         const int sb = e / BM, r = e - sb * BM;
-        uv[e] = (m0 + r < P.M) ? pv[(long)(b0 + sb) * P.M + m0 + r] : 0.f;
+        uv[e] = (m0 + r < P.M) ? P.v1[(long)(b0 + sb) * P.M + m0 + r] : 0.f;
       }
     __syncthreads();
-    float esum[JN];
 #pragma unroll
     for (int j = 0; j < JN; ++j) {
-      esum[j] = 0.f;
       const int n = n0 + cloc + j * 32;
       const bool nok = n < P.N;
       const int nn = nok ? n : P.N - 1;
@@ -382,36 +372,15 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams P) {
           const bool ok = nok && m < P.M;
           const long ci = cb + (long)(m < P.M ? m : P.M - 1) * P.S;
           const float v = acc[i][j][r];
-          float pvm = 0.f;
-          if (EPI != EPI_CONV_TANH)
-            pvm = staged ? uvb[rl] : (m < P.M ? pv[(long)b * P.M + m] : 0.f);
-          if (EPI == EPI_CONV_TANH) {
-            const float t = tanh_fast(v + rowv[rl]);
-            if (ok) P.C[ci] = t;
-          } else if (EPI == EPI_ATT_SCORE) {
-            const float t = tanh_fast(v + rowv[rl] + pvm);
-            if (ok) {
-              P.C[ci] = t;
-              esum[j] += rowv2[rl] * t;
-            }
-          } else if (EPI == EPI_DI) {
+          if (EPI == EPI_CONV) {
+            const float t = v + rowv[rl];
+            if (ok) P.C[ci] = P.act ? tanh_fast(t) : t;
+          } else {
+            const float pvm = staged ? uvb[rl] : (m < P.M ? P.v1[(long)b * P.M + m] : 0.f);
             const float y = P.I[ci];
             if (ok) P.C[ci] = (v + pvm * an) * (1.f - y * y);
           }
         }
-    }
-    if (EPI == EPI_ATT_SCORE) {
-      // reduce over the tile's BM rows: lane halves, then the two wm waves
-#pragma unroll
-      for (int j = 0; j < JN; ++j) {
-        const float v = esum[j] + __shfl_xor(esum[j], 32, 64);
-        if (l < 32) red[wm * BN + wn * WN + j * 32 + l] = v;
-      }
-      __syncthreads();
-      if (tid < BN) {
-        const int n = n0 + tid;
-        if (n < P.N) P.out2[(long)tm * P.N + n] = red[tid] + red[BN + tid];
-      }
     }
   }
 }

@@ -43,12 +43,9 @@ hipError_t gemm_tn_acc(hipStream_t st, int M, int N, int K, const float* A, long
 // feature map with dropout already applied, see dropout_features; nB may be H*B)
 hipError_t conv_embed_fwd(hipStream_t st, int nB, int D, int S, int M, const float* X,
                           const float* Wi, const float* bi, float* I);
-// T[b,k,s] = tanh(sum_m Wp[k,m] I[b,m,s] + bp[k] + u[b,k]); e_part[t][b*S+s] = partial
-// sum_k ws[k] T over the t-th 128-row tile (SS:244-252).
-int conv_att_tiles(int A);
-hipError_t conv_att_fwd(hipStream_t st, int nB, int M, int S, int A, const float* I,
-                        const float* Wp, const float* bp, const float* u, const float* ws,
-                        float* T, float* e_part);
+// P[b,k,s] = sum_m Wp[k,m] I[b,m,s] + bp[k]   (hop-invariant half of SS:244-252)
+hipError_t conv_att_pre(hipStream_t st, int nB, int M, int S, int A, const float* I,
+                        const float* Wp, const float* bp, float* P);
 // dZ[b,m,s] = (sum_k Wp[k,m] dS[b,k,s] + dj[b,m] a[b,s]) * (1 - I^2)
 hipError_t conv_att_dgrad(hipStream_t st, int nB, int M, int S, int A, const float* dS,
                           const float* Wp, const float* dj, const float* a, const float* I,
@@ -78,17 +75,17 @@ hipError_t lstm_bwd(hipStream_t st, int order, int nB, int R, const float* gates
                     long dh_rs, const float* dh2, const float* dc_next, float* dsum,
                     float* dc_prev, const int32_t* lens, int t, const float* dq_c,
                     const float* dq_h, long dq_rs);
-hipError_t softmax_fwd(hipStream_t st, int rows, int S, const float* e_part, int parts,
-                       long part_stride, const float* bs, const float* zm, float* a);
-hipError_t attselect_fwd(hipStream_t st, int nB, int M, int S, const float* I, const float* a,
-                         const float* qf, float* jv);
-hipError_t attselect_bwd(hipStream_t st, int nB, int M, int S, const float* I, const float* dj,
-                         float* da_part /* [M/64][nB*S] */);
-hipError_t softmax_bwd(hipStream_t st, int rows, int S, const float* a, const float* da_lin,
-                       const float* da_part, int parts, long part_stride, float* dz);
-// In place T -> dS[b,k,s] = dz[b,s] ws[k] (1-T^2); du[b,k] = sum_s dS; dwsp[b,k] = sum_s dz T
-hipError_t att_score_bwd(hipStream_t st, int nB, int A, int S, float* T_to_dS, const float* dz,
-                         const float* ws, float* du, float* dwsp);
+// One workgroup per sample: T = tanh(P + u[b,:,None]) (attbycontent, SS:250),
+// e = ws . T + bs (SS:251), a = softmax(e + zm) (attbymemory, SS:288-289),
+// jv = qf + sum_s I a (attselect SS:254-263 + first CAddTable SS:270).
+hipError_t att_fwd_fused(hipStream_t st, int nB, int M, int A, int S, const float* P,
+                         const float* u, const float* ws, const float* bs, const float* zm,
+                         const float* I, const float* qf, float* T, float* a, float* jv);
+// One workgroup per sample, backward of the above: da = da_lin + sum_m dj I;
+// dz = softmax'(da); T -> dS = dz ws (1-T^2) in place; du = sum_s dS; dwsp = sum_s dz T.
+hipError_t att_bwd_fused(hipStream_t st, int nB, int M, int A, int S, const float* I,
+                         const float* dj, const float* a, const float* da_lin,
+                         const float* ws, float* T_to_dS, float* dz, float* du, float* dwsp);
 // xd[h][i] = X[i] * keep(h, i) * scale for h < H, i < per_hop (feature-map dropout, SS:239)
 hipError_t dropout_features(hipStream_t st, int H, size_t per_hop, const float* X,
                             const uint32_t* mask, float mscale, float* xd);

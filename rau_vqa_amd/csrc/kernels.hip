@@ -209,163 +209,192 @@ hipError_t lstm_bwd(hipStream_t st, int order, int nB, int R, const float* gates
   return hipGetLastError();
 }
 
-// --------------------------------------------------- attention softmax / context
-// One wave per row; a = softmax(sum_parts e_part + bs + zm).  reference SS:285-290
-__global__ void k_softmax_fwd(int rows, int S, const float* __restrict__ e_part, int parts,
-                              long part_stride, const float* __restrict__ bs,
-                              const float* __restrict__ zm, float* __restrict__ a) {
-  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  if (row >= rows) return;
-  const int l = threadIdx.x & 63;
-  const float b0 = bs[0];
+// ------------------------------------------- fused per-sample attention kernels
+// One workgroup of kAttWaves waves per sample; everything a hop needs from the big
+// per-sample tiles P/T [A,S] and I [M,S] in one pass over them.  16 waves per
+// sample keep enough loads in flight to stream the ~0.8 MB a sample touches.
+// Wave w owns rows w, w+NW, ...; lane l owns the float4 column groups l, l+64, ...
+// Cross-wave sums go through LDS and are added in wave order (deterministic).
+constexpr int kAttWaves = 16;
+constexpr int kAttThreads = kAttWaves * 64;
+
+__device__ __forceinline__ float block_sum_ordered(const float* red, int S, int s) {
+  float v = red[s];
+#pragma unroll
+  for (int w = 1; w < kAttWaves; ++w) v += red[(size_t)w * S + s];
+  return v;
+}
+
+__global__ __launch_bounds__(kAttThreads) void k_att_fwd_fused(
+    int M, int A, int S, const float* __restrict__ P, const float* __restrict__ u,
+    const float* __restrict__ ws, const float* __restrict__ bs, const float* __restrict__ zm,
+    const float* __restrict__ I, const float* __restrict__ qf, float* __restrict__ T,
+    float* __restrict__ a, float* __restrict__ jv) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* red = sm;                     // [NW][S]
+  float* as = sm + kAttWaves * S;      // [S]
+  float* sc = as + S;                  // [2*NW] block scalars
+  const int b = blockIdx.x, tid = threadIdx.x, l = tid & 63, w = tid >> 6;
+  const int S4 = S >> 2;
+  const float* Pb = P + (size_t)b * A * S;
+  float* Tb = T + (size_t)b * A * S;
+  const float* ub = u + (size_t)b * A;
+  // ---- phase 1: T = tanh(P + u), e[s] = sum_k ws[k] T[k,s]
+  for (int q0 = 0; q0 < S4; q0 += 64) {
+    const int q = q0 + l;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (q < S4) {
+      for (int k = w; k < A; k += kAttWaves) {
+        const float4 p = reinterpret_cast<const float4*>(Pb + (size_t)k * S)[q];
+        const float uk = ub[k], wk = ws[k];
+        float4 t;
+        t.x = tanh_fast(p.x + uk); t.y = tanh_fast(p.y + uk);
+        t.z = tanh_fast(p.z + uk); t.w = tanh_fast(p.w + uk);
+        reinterpret_cast<float4*>(Tb + (size_t)k * S)[q] = t;
+        acc.x += wk * t.x; acc.y += wk * t.y; acc.z += wk * t.z; acc.w += wk * t.w;
+      }
+      reinterpret_cast<float4*>(red + (size_t)w * S)[q] = acc;
+    }
+  }
+  __syncthreads();
+  // ---- phase 2: a = softmax(e + bs + zm)
   float mx = -INFINITY;
-  for (int s = l; s < S; s += 64) {
-    float z = b0 + zm[(size_t)row * S + s];
-    for (int p = 0; p < parts; ++p) z += e_part[p * part_stride + (size_t)row * S + s];
-    a[(size_t)row * S + s] = z;
+  for (int s = tid; s < S; s += kAttThreads) {
+    const float z = block_sum_ordered(red, S, s) + bs[0] + zm[(size_t)b * S + s];
+    as[s] = z;
     mx = fmaxf(mx, z);
   }
   mx = wave_max(mx);
+  if (l == 0) sc[w] = mx;
+  __syncthreads();
+  mx = sc[0];
+#pragma unroll
+  for (int i = 1; i < kAttWaves; ++i) mx = fmaxf(mx, sc[i]);
   float den = 0.f;
-  for (int s = l; s < S; s += 64) {
-    const float ex = expf(a[(size_t)row * S + s] - mx);
-    a[(size_t)row * S + s] = ex;
+  for (int s = tid; s < S; s += kAttThreads) {
+    const float ex = expf(as[s] - mx);
+    as[s] = ex;
     den += ex;
   }
   den = wave_sum(den);
+  if (l == 0) sc[kAttWaves + w] = den;
+  __syncthreads();
+  den = sc[kAttWaves];
+#pragma unroll
+  for (int i = 1; i < kAttWaves; ++i) den += sc[kAttWaves + i];
   const float inv = 1.f / den;
-  for (int s = l; s < S; s += 64) a[(size_t)row * S + s] *= inv;
-}
-hipError_t softmax_fwd(hipStream_t st, int rows, int S, const float* e_part, int parts,
-                       long part_stride, const float* bs, const float* zm, float* a) {
-  hipLaunchKernelGGL(k_softmax_fwd, dim3((rows + 3) / 4), dim3(256), 0, st, rows, S, e_part, parts,
-                     part_stride, bs, zm, a);
-  return hipGetLastError();
-}
-
-// jv[b,m] = qf[b,m] + sum_s I[b,m,s] a[b,s]     (attselect SS:254-263 + CAddTable SS:270)
-// one wave per (b, m) row, float4 lanes; 8 rows per wave, 32 rows per block.
-__global__ void k_attselect_fwd(int nB, int M, int S, const float* __restrict__ I,
-                                const float* __restrict__ a, const float* __restrict__ qf,
-                                float* __restrict__ jv) {
-  const int mblocks = (M + 31) / 32;
-  const int b = blockIdx.x / mblocks;
-  const int mb = (blockIdx.x - b * mblocks) * 32 + (threadIdx.x >> 6) * 8;
-  const int l = threadIdx.x & 63;
-  const int S4 = S >> 2;
-  for (int r = 0; r < 8; ++r) {
-    const int m = mb + r;
-    if (m >= M) break;
-    const float4* row = reinterpret_cast<const float4*>(I + ((size_t)b * M + m) * S);
-    const float4* av = reinterpret_cast<const float4*>(a + (size_t)b * S);
-    float acc = 0.f;
-    for (int q = l; q < S4; q += 64) {
-      const float4 x = row[q], y = av[q];
-      acc += x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w;
-    }
-    acc = wave_sum(acc);
-    if (l == 0) jv[(size_t)b * M + m] = acc + qf[(size_t)b * M + m];
-  }
-}
-hipError_t attselect_fwd(hipStream_t st, int nB, int M, int S, const float* I, const float* a,
-                         const float* qf, float* jv) {
-  hipLaunchKernelGGL(k_attselect_fwd, dim3(nB * ((M + 31) / 32)), dim3(256), 0, st, nB, M, S, I,
-                     a, qf, jv);
-  return hipGetLastError();
-}
-
-// da_part[c][b,s] = sum_{m in chunk c of 64} dj[b,m] I[b,m,s]; lanes own float4 of s,
-// the block's 4 waves take 16 rows each and combine through LDS in wave order.
-__global__ void k_attselect_bwd(int nB, int M, int S, const float* __restrict__ I,
-                                const float* __restrict__ dj, float* __restrict__ da_part) {
-  extern __shared__ __attribute__((aligned(16))) float red[];  // [4][S]
-  const int chunks = (M + 63) / 64;
-  const int b = blockIdx.x / chunks, c = blockIdx.x - b * chunks;
-  const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
-  const int S4 = S >> 2;
-  for (int q = l; q < S4; q += 64) {
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int r = 0; r < 16; ++r) {
-      const int m = c * 64 + w * 16 + r;
-      if (m >= M) break;
-      const float d = dj[(size_t)b * M + m];
-      const float4 x = reinterpret_cast<const float4*>(I + ((size_t)b * M + m) * S)[q];
-      acc.x += d * x.x; acc.y += d * x.y; acc.z += d * x.z; acc.w += d * x.w;
-    }
-    reinterpret_cast<float4*>(red + (size_t)w * S)[q] = acc;
+  for (int s = tid; s < S; s += kAttThreads) {
+    const float v = as[s] * inv;
+    as[s] = v;
+    a[(size_t)b * S + s] = v;
   }
   __syncthreads();
-  for (int s = threadIdx.x; s < S; s += blockDim.x)
-    da_part[(size_t)c * nB * S + (size_t)b * S + s] =
-        ((red[s] + red[S + s]) + red[2 * S + s]) + red[3 * S + s];
+  // ---- phase 3: jv[m] = qf[m] + sum_s I[m,s] a[s]; one wave per row, 4 rows in flight
+  const float* Ib = I + (size_t)b * M * S;
+  for (int m0 = w * 4; m0 < M; m0 += kAttWaves * 4) {
+    float part[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int q = l; q < S4; q += 64) {
+      const float4 av = reinterpret_cast<const float4*>(as)[q];
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (m0 + r < M) {
+          const float4 x = reinterpret_cast<const float4*>(Ib + (size_t)(m0 + r) * S)[q];
+          part[r] += x.x * av.x + x.y * av.y + x.z * av.z + x.w * av.w;
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float v = wave_sum(part[r]);
+      if (l == 0 && m0 + r < M) jv[(size_t)b * M + m0 + r] = v + qf[(size_t)b * M + m0 + r];
+    }
+  }
 }
-hipError_t attselect_bwd(hipStream_t st, int nB, int M, int S, const float* I, const float* dj,
-                         float* da_part) {
-  hipLaunchKernelGGL(k_attselect_bwd, dim3(nB * ((M + 63) / 64)), dim3(256),
-                     4 * S * sizeof(float), st, nB, M, S, I, dj, da_part);
+hipError_t att_fwd_fused(hipStream_t st, int nB, int M, int A, int S, const float* P,
+                         const float* u, const float* ws, const float* bs, const float* zm,
+                         const float* I, const float* qf, float* T, float* a, float* jv) {
+  const size_t lds = ((size_t)(kAttWaves + 1) * S + 2 * kAttWaves) * sizeof(float);
+  hipLaunchKernelGGL(k_att_fwd_fused, dim3(nB), dim3(kAttThreads), lds, st, M, A, S, P, u, ws, bs,
+                     zm, I, qf, T, a, jv);
   return hipGetLastError();
 }
 
-// dz = a * (da - sum_s a da), da = da_lin + sum_parts da_part
-__global__ void k_softmax_bwd(int rows, int S, const float* __restrict__ a,
-                              const float* __restrict__ da_lin, const float* __restrict__ da_part,
-                              int parts, long part_stride, float* __restrict__ dz) {
-  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  if (row >= rows) return;
-  const int l = threadIdx.x & 63;
+__global__ __launch_bounds__(kAttThreads) void k_att_bwd_fused(
+    int M, int A, int S, const float* __restrict__ I, const float* __restrict__ dj,
+    const float* __restrict__ a, const float* __restrict__ da_lin, const float* __restrict__ ws,
+    float* __restrict__ T, float* __restrict__ dz, float* __restrict__ du,
+    float* __restrict__ dwsp) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* red = sm;                     // [NW][S]
+  float* dzs = sm + kAttWaves * S;     // [S]
+  float* sc = dzs + S;                 // [NW]
+  const int b = blockIdx.x, tid = threadIdx.x, l = tid & 63, w = tid >> 6;
+  const int S4 = S >> 2;
+  const float* Ib = I + (size_t)b * M * S;
+  const float* djb = dj + (size_t)b * M;
+  // ---- phase 1: da[s] = da_lin[s] + sum_m dj[m] I[m,s]
+  for (int q0 = 0; q0 < S4; q0 += 64) {
+    const int q = q0 + l;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (q < S4) {
+      for (int m = w; m < M; m += kAttWaves) {
+        const float d = djb[m];
+        const float4 x = reinterpret_cast<const float4*>(Ib + (size_t)m * S)[q];
+        acc.x += d * x.x; acc.y += d * x.y; acc.z += d * x.z; acc.w += d * x.w;
+      }
+      reinterpret_cast<float4*>(red + (size_t)w * S)[q] = acc;
+    }
+  }
+  __syncthreads();
+  // ---- phase 2: dz = a * (da - sum_s a da)
   float dot = 0.f;
-  for (int s = l; s < S; s += 64) {
-    float d = da_lin[(size_t)row * S + s];
-    for (int p = 0; p < parts; ++p) d += da_part[p * part_stride + (size_t)row * S + s];
-    dz[(size_t)row * S + s] = d;
-    dot += a[(size_t)row * S + s] * d;
+  for (int s = tid; s < S; s += kAttThreads) {
+    const float d = da_lin[(size_t)b * S + s] + block_sum_ordered(red, S, s);
+    dzs[s] = d;
+    dot += a[(size_t)b * S + s] * d;
   }
   dot = wave_sum(dot);
-  for (int s = l; s < S; s += 64)
-    dz[(size_t)row * S + s] = a[(size_t)row * S + s] * (dz[(size_t)row * S + s] - dot);
-}
-hipError_t softmax_bwd(hipStream_t st, int rows, int S, const float* a, const float* da_lin,
-                       const float* da_part, int parts, long part_stride, float* dz) {
-  hipLaunchKernelGGL(k_softmax_bwd, dim3((rows + 3) / 4), dim3(256), 0, st, rows, S, a, da_lin,
-                     da_part, parts, part_stride, dz);
-  return hipGetLastError();
-}
-
-// one wave per (b,k) row of T; T is overwritten by dS (T is dead after this point)
-__global__ void k_att_score_bwd(int nB, int A, int S, float* __restrict__ T,
-                                const float* __restrict__ dz, const float* __restrict__ ws,
-                                float* __restrict__ du, float* __restrict__ dwsp) {
-  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  if (row >= nB * A) return;
-  const int b = row / A, k = row - b * A;
-  const int l = threadIdx.x & 63;
-  const int S4 = S >> 2;
-  float4* tr = reinterpret_cast<float4*>(T + (size_t)row * S);
-  const float4* dr = reinterpret_cast<const float4*>(dz + (size_t)b * S);
-  const float w = ws[k];
-  float s1 = 0.f, s2 = 0.f;
-  for (int q = l; q < S4; q += 64) {
-    const float4 t = tr[q], d = dr[q];
-    float4 o;
-    o.x = d.x * w * (1.f - t.x * t.x);
-    o.y = d.y * w * (1.f - t.y * t.y);
-    o.z = d.z * w * (1.f - t.z * t.z);
-    o.w = d.w * w * (1.f - t.w * t.w);
-    tr[q] = o;
-    s1 += (o.x + o.y) + (o.z + o.w);
-    s2 += d.x * t.x + d.y * t.y + d.z * t.z + d.w * t.w;
+  if (l == 0) sc[w] = dot;
+  __syncthreads();
+  dot = sc[0];
+#pragma unroll
+  for (int i = 1; i < kAttWaves; ++i) dot += sc[i];
+  for (int s = tid; s < S; s += kAttThreads) {
+    const float v = a[(size_t)b * S + s] * (dzs[s] - dot);
+    dzs[s] = v;
+    dz[(size_t)b * S + s] = v;
   }
-  s1 = wave_sum(s1);
-  s2 = wave_sum(s2);
-  if (l == 0) {
-    du[row] = s1;
-    dwsp[row] = s2;
+  __syncthreads();
+  // ---- phase 3: T -> dS in place, du[k] = sum_s dS, dwsp[k] = sum_s dz T; wave per row
+  float* Tb = T + (size_t)b * A * S;
+  for (int k = w; k < A; k += kAttWaves) {
+    const float wk = ws[k];
+    float s1 = 0.f, s2 = 0.f;
+    for (int q = l; q < S4; q += 64) {
+      const float4 t = reinterpret_cast<const float4*>(Tb + (size_t)k * S)[q];
+      const float4 d = reinterpret_cast<const float4*>(dzs)[q];
+      float4 o;
+      o.x = d.x * wk * (1.f - t.x * t.x);
+      o.y = d.y * wk * (1.f - t.y * t.y);
+      o.z = d.z * wk * (1.f - t.z * t.z);
+      o.w = d.w * wk * (1.f - t.w * t.w);
+      reinterpret_cast<float4*>(Tb + (size_t)k * S)[q] = o;
+      s1 += (o.x + o.y) + (o.z + o.w);
+      s2 += d.x * t.x + d.y * t.y + d.z * t.z + d.w * t.w;
+    }
+    s1 = wave_sum(s1);
+    s2 = wave_sum(s2);
+    if (l == 0) {
+      du[(size_t)b * A + k] = s1;
+      dwsp[(size_t)b * A + k] = s2;
+    }
   }
 }
-hipError_t att_score_bwd(hipStream_t st, int nB, int A, int S, float* T_to_dS, const float* dz,
-                         const float* ws, float* du, float* dwsp) {
-  hipLaunchKernelGGL(k_att_score_bwd, dim3((nB * A + 3) / 4), dim3(256), 0, st, nB, A, S, T_to_dS,
-                     dz, ws, du, dwsp);
+hipError_t att_bwd_fused(hipStream_t st, int nB, int M, int A, int S, const float* I,
+                         const float* dj, const float* a, const float* da_lin,
+                         const float* ws, float* T_to_dS, float* dz, float* du, float* dwsp) {
+  const size_t lds = ((size_t)(kAttWaves + 1) * S + kAttWaves) * sizeof(float);
+  hipLaunchKernelGGL(k_att_bwd_fused, dim3(nB), dim3(kAttThreads), lds, st, M, A, S, I, dj, a,
+                     da_lin, ws, T_to_dS, dz, du, dwsp);
   return hipGetLastError();
 }
 

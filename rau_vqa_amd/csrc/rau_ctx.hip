@@ -92,7 +92,9 @@ struct ProfCls {
 struct rau_ctx {
   rau_config cfg;
   int Q;
-  hipStream_t st = nullptr;
+  hipStream_t st = nullptr;    // chain stream: recurrences, small GEMMs; what callers order against
+  hipStream_t st2 = nullptr;   // bulk stream: hop-batched 1x1-conv GEMMs, overlapped with the chain
+  hipEvent_t evA = nullptr, evB = nullptr, evC = nullptr, evD = nullptr;
   std::vector<void*> allocs;
   Group grp[3];
   // mult
@@ -121,12 +123,13 @@ struct rau_ctx {
   // RAU activations
   float *xd;          // [H][B][D][S] feature map after per-hop dropout (train mode)
   bool I_shared = false;  // evaluate mode: i_embed output is hop-invariant, computed once
-  float *qd, *Yq, *qf, *I, *T, *u, *e_part, *zm, *a, *jv, *j, *g4, *cc, *hh, *tc, *mf, *logits,
+  float *P0;          // [B][A][S] hop-invariant attention pre-activation (evaluate mode)
+  float *qd, *Yq, *qf, *I, *T, *u, *zm, *a, *jv, *j, *g4, *cc, *hh, *tc, *mf, *logits,
       *dl, *lossrow, *dopred, *losses_d, *hopw_d;
   int32_t* argmax_d;
   // backward temporaries
-  float *dpre, *dhn, *dg4, *dcn[2], *dhp[2], *dj, *da_lin, *da_part, *dz, *du, *dwsp, *dZ, *rsum,
-      *dqt, *dQD, *dq, *slab, *coltmp, *tmpS;
+  float *dpre, *dhn, *dg4, *dcn[2], *dhp[2], *dj, *da_lin, *dz, *du, *dwsp, *dZ, *rsum,
+      *dqt, *dQD, *dq, *slab, *slab2, *coltmp, *coltmp2, *tmpS;
   float *dG1, *dG2, *dX2, *dwe, *edc[2][2], *edh[2];
   size_t slab_floats = 0;
   // update
@@ -201,7 +204,8 @@ hipEvent_t prof_event(rau_ctx* c) {
 
 // Launch wrapper: counts launches/FLOPs/bytes per kernel class and, when
 // profiling is on, brackets the launch with HIP events on the ctx stream.
-#define RUN(cname, fl, by, expr)                                                          \
+#define RUN(cname, fl, by, expr) RUNS(ctx->st, cname, fl, by, expr)
+#define RUNS(rstream, cname, fl, by, expr)                                                \
   do {                                                                                    \
     ProfRec pr_;                                                                          \
     int pc_ = -1;                                                                         \
@@ -213,11 +217,11 @@ hipEvent_t prof_event(rau_ctx* c) {
       pr_.cls = pc_;                                                                      \
       pr_.a = prof_event(ctx);                                                            \
       pr_.b = prof_event(ctx);                                                            \
-      hipEventRecord(pr_.a, ctx->st);                                                     \
+      hipEventRecord(pr_.a, rstream);                                                     \
     }                                                                                     \
     hipError_t e_ = (expr);                                                               \
     if (pc_ >= 0) {                                                                       \
-      hipEventRecord(pr_.b, ctx->st);                                                     \
+      hipEventRecord(pr_.b, rstream);                                                     \
       ctx->precs.push_back(pr_);                                                          \
     }                                                                                     \
     if (e_ != hipSuccess)                                                                 \
@@ -228,6 +232,7 @@ hipEvent_t prof_event(rau_ctx* c) {
 static int prof_collect(rau_ctx* ctx) {
   if (ctx->precs.empty()) return 0;
   HIPC(hipStreamSynchronize(ctx->st));
+  HIPC(hipStreamSynchronize(ctx->st2));
   for (auto& r : ctx->precs) {
     float ms = 0.f;
     hipEventElapsedTime(&ms, r.a, r.b);
@@ -305,7 +310,13 @@ int rau_create(const rau_config* cfg, rau_ctx** out) {
     }                        \
   } while (0)
   {
-    hipError_t es = hipStreamCreateWithFlags(&ctx->st, hipStreamNonBlocking);
+    // the chain stream outranks the bulk stream: its short kernels are the critical
+    // path and must not queue behind the bulk GEMMs' workgroups
+    int prio_lo = 0, prio_hi = 0;
+    hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+    hipError_t es = hipStreamCreateWithPriority(&ctx->st, hipStreamNonBlocking, prio_hi);
+    if (es == hipSuccess)
+      es = hipStreamCreateWithPriority(&ctx->st2, hipStreamNonBlocking, prio_lo);
     if (es != hipSuccess) {
       delete ctx;
       return fail(RAU_ERR_DEVICE, "hipStreamCreate: %s", hipGetErrorString(es));
@@ -313,6 +324,8 @@ int rau_create(const rau_config* cfg, rau_ctx** out) {
   }
   hipEventCreate(&ctx->ev0);
   hipEventCreate(&ctx->ev1);
+  for (hipEvent_t* e : {&ctx->evA, &ctx->evB, &ctx->evC, &ctx->evD})
+    hipEventCreateWithFlags(e, hipEventDisableTiming);
 
   const int B = c.B, T = c.T, E = c.E, Rq = c.Rq, D = c.D, S = c.S, M = c.M, A = c.A, R = c.R,
             K = c.K, H = c.H, Q = ctx->Q;
@@ -397,7 +410,7 @@ int rau_create(const rau_config* cfg, rau_ctx** out) {
   CK(dalloc(ctx, &ctx->I, HB * M * S));
   CK(dalloc(ctx, &ctx->T, HB * A * S));
   CK(dalloc(ctx, &ctx->u, (size_t)B * A));
-  CK(dalloc(ctx, &ctx->e_part, (size_t)conv_att_tiles(A) * B * S));
+  CK(dalloc(ctx, &ctx->P0, (size_t)B * A * S));
   CK(dalloc(ctx, &ctx->zm, (size_t)B * S));
   CK(dalloc(ctx, &ctx->a, HB * S));
   CK(dalloc(ctx, &ctx->jv, (size_t)B * M));
@@ -424,7 +437,6 @@ int rau_create(const rau_config* cfg, rau_ctx** out) {
   }
   CK(dalloc(ctx, &ctx->dj, HB * M));
   CK(dalloc(ctx, &ctx->da_lin, (size_t)B * S));
-  CK(dalloc(ctx, &ctx->da_part, (size_t)((M + 63) / 64) * B * S));
   CK(dalloc(ctx, &ctx->dz, HB * S));
   CK(dalloc(ctx, &ctx->du, HB * A));
   CK(dalloc(ctx, &ctx->dwsp, HB * A));
@@ -434,12 +446,16 @@ int rau_create(const rau_config* cfg, rau_ctx** out) {
   CK(dalloc(ctx, &ctx->dQD, HB * Q));
   CK(dalloc(ctx, &ctx->dq, (size_t)B * Q));
   {
-    size_t sl = std::max(conv_wgrad_slab_floats(B, A, M, S), conv_wgrad_slab_floats(H * B, M, D, S));
+    // split-K workspaces: one per stream (the two streams run concurrently)
+    const size_t sl2 = std::max(conv_wgrad_slab_floats(H * B, A, M, S),
+                                conv_wgrad_slab_floats(H * B, M, D, S));
+    CK(dalloc(ctx, &ctx->slab2, sl2));
     const int rowsH = H * B, rowsT = T * B;
     const int shapes[][3] = {{K, M, rowsH},      {M, R, rowsH},      {4 * R, M, rowsH},
                              {4 * R, R, rowsH},  {M, S, rowsH},      {S, R, rowsH},
                              {A, M, rowsH},      {M, Q, rowsH},      {4 * Rq, E, rowsT},
                              {4 * Rq, Rq, rowsT}};
+    size_t sl = (size_t)16 * B * std::max({4 * R, 4 * Rq, K, Q});  // skinny split-K partials
     for (auto& s : shapes) sl = std::max(sl, gemm_tn_slab_floats(s[0], s[1], s[2]));
     ctx->slab_floats = sl;
     CK(dalloc(ctx, &ctx->slab, sl));
@@ -447,6 +463,7 @@ int rau_create(const rau_config* cfg, rau_ctx** out) {
   {
     const int widest = std::max({4 * R, 4 * Rq, K, M, S, A, Q});
     CK(dalloc(ctx, &ctx->coltmp, (size_t)32 * widest));
+    CK(dalloc(ctx, &ctx->coltmp2, (size_t)32 * widest));
     CK(dalloc(ctx, &ctx->tmpS, (size_t)S));
   }
   CK(dalloc(ctx, &ctx->dG1, TB * 4 * Rq));
@@ -475,6 +492,7 @@ int rau_create(const rau_config* cfg, rau_ctx** out) {
 void rau_destroy(rau_ctx* ctx) {
   if (!ctx) return;
   if (ctx->st) hipStreamSynchronize(ctx->st);
+  if (ctx->st2) hipStreamSynchronize(ctx->st2);
   for (void* p : ctx->allocs) hipFree(p);
   for (auto& r : ctx->precs) {
     hipEventDestroy(r.a);
@@ -483,6 +501,9 @@ void rau_destroy(rau_ctx* ctx) {
   for (auto e : ctx->evpool) hipEventDestroy(e);
   if (ctx->ev0) hipEventDestroy(ctx->ev0);
   if (ctx->ev1) hipEventDestroy(ctx->ev1);
+  for (hipEvent_t e : {ctx->evA, ctx->evB, ctx->evC, ctx->evD})
+    if (e) hipEventDestroy(e);
+  if (ctx->st2) hipStreamDestroy(ctx->st2);
   if (ctx->st) hipStreamDestroy(ctx->st);
   delete ctx;
 }
@@ -694,6 +715,35 @@ int rau_forward(rau_ctx* ctx) {
   const size_t BRq = (size_t)B * Rq;
   auto gflop = [](double m, double n, double k) { return 2.0 * m * n * k; };
 
+  // ---------------- bulk stream: everything about the feature map that does not
+  // depend on the recurrence, for all hops at once (overlaps the encoder below).
+  // i_embed SS:238-242: in train mode each hop clone has its own dropout mask on
+  // the feature map (SS:239, SS:343-347) -> xd[h] = X (.) mask_h, one GEMM over
+  // H*B samples; in evaluate mode I is hop-invariant and computed once.
+  // attbycontent's ifeatproj (SS:247-249) is hop-invariant given I: P = Wp I + bp;
+  // the per-hop half (+u, tanh, score, softmax, context) is att_fwd_fused.
+  {
+    hipStream_t sb = ctx->st2;
+    HIPC(hipEventRecord(ctx->evA, st));
+    HIPC(hipStreamWaitEvent(sb, ctx->evA, 0));
+    ctx->I_shared = (m_x == nullptr);
+    const int nBI = ctx->I_shared ? B : H * B;
+    const float* xin_feats = ctx->feats;
+    if (m_x) {
+      RUNS(sb, "dropout_features", 0, (double)(H + 1) * B * D * S * 4,
+           dropout_features(sb, H, (size_t)B * D * S, ctx->feats, m_x, sc(RAU_MASK_X), ctx->xd));
+      xin_feats = ctx->xd;
+    }
+    RUNS(sb, "conv_embed_fwd", gflop(M, (double)nBI * S, D),
+         ((double)nBI * D * S + (double)nBI * M * S) * 4,
+         conv_embed_fwd(sb, nBI, D, S, M, xin_feats, ctx->i_embed.W, ctx->i_embed.b, ctx->I));
+    float* Pall = ctx->I_shared ? ctx->P0 : ctx->T;
+    RUNS(sb, "conv_att_pre", gflop(A, (double)nBI * S, M),
+         ((double)nBI * M * S + (double)nBI * A * S) * 4,
+         conv_att_pre(sb, nBI, M, S, A, ctx->I, ctx->att_i.W, ctx->att_i.b, Pall));
+    HIPC(hipEventRecord(ctx->evB, sb));
+  }
+
   // ---------------- encoder, SS:443-462
   if (TL > 0) {
     const int rows = TL * B;
@@ -748,19 +798,9 @@ int rau_forward(rau_ctx* ctx) {
   // Train mode: each hop clone has its own dropout mask on the feature map
   // (SS:239, SS:343-347) -> xd[h] = X (.) mask_h, then one GEMM over H*B samples.
   // Evaluate mode: dropout is the identity, so I is hop-invariant and computed once.
-  ctx->I_shared = (m_x == nullptr);
-  if (m_x) {
-    RUN("dropout_features", 0, (double)(H + 1) * B * D * S * 4,
-        dropout_features(st, H, (size_t)B * D * S, ctx->feats, m_x, sc(RAU_MASK_X), ctx->xd));
-    RUN("conv_embed_fwd", gflop(M, (double)H * B * S, D), ((double)H * B * D * S + (double)H * BM_ * S) * 4,
-        conv_embed_fwd(st, H * B, D, S, M, ctx->xd, ctx->i_embed.W, ctx->i_embed.b, ctx->I));
-  } else {
-    RUN("conv_embed_fwd", gflop(M, (double)B * S, D), ((double)B * D * S + BM_ * S) * 4,
-        conv_embed_fwd(st, B, D, S, M, ctx->feats, ctx->i_embed.W, ctx->i_embed.b, ctx->I));
-  }
+  HIPC(hipStreamWaitEvent(st, ctx->evB, 0));  // I and P for every hop are ready
   HIPC(hipMemsetAsync(ctx->cc, 0, BR_ * sizeof(float), st));  // att_c, att_h zeros SS:362-365
   HIPC(hipMemsetAsync(ctx->hh, 0, BR_ * sizeof(float), st));
-  const int parts = conv_att_tiles(A);
   for (int h = 0; h < H; ++h) {
     const float* hp = ctx->hh + (size_t)h * BR_;
     const float* cp = ctx->cc + (size_t)h * BR_;
@@ -784,19 +824,15 @@ int rau_forward(rau_ctx* ctx) {
       o.bias = ctx->att_q.b;
       RUN("small_gemm", gflop(B, A, M), 0, gemm_nt(st, B, A, M, qf, M, ctx->att_q.W, M, ctx->u, A, o));
     }
-    RUN("conv_att_fwd", gflop(A, (double)B * S, M), (BM_ * S + (double)B * A * S) * 4,
-        conv_att_fwd(st, B, M, S, A, Ih, ctx->att_i.W, ctx->att_i.b, ctx->u, ctx->att_score.W, Th,
-                     ctx->e_part));
-    {  // attbymemory SS:285-290
+    {  // attbymemory SS:285-290 (linear part)
       LINOPTS(o);
       o.bias = ctx->att_mem.b;
       RUN("small_gemm", gflop(B, S, R), 0, gemm_nt(st, B, S, R, hp, R, ctx->att_mem.W, R, ctx->zm, S, o));
     }
-    RUN("softmax_fwd", 0, BS_ * 16.0,
-        softmax_fwd(st, B, S, ctx->e_part, parts, (long)BS_, ctx->att_score.b, ctx->zm, ah));
-    // attselect SS:254-263 (+ qf, first CAddTable of SS:270)
-    RUN("attselect_fwd", 2.0 * BM_ * S, BM_ * S * 4.0,
-        attselect_fwd(st, B, M, S, Ih, ah, qf, ctx->jv));
+    // tanh(P+u), score, softmax, attention-weighted sum: one pass per sample
+    RUN("att_fwd_fused", 2.0 * B * S * (A + M), ((double)B * A * S * 2 + BM_ * S) * 4,
+        att_fwd_fused(st, B, M, A, S, ctx->I_shared ? ctx->P0 : Th, ctx->u, ctx->att_score.W,
+                      ctx->att_score.b, ctx->zm, Ih, qf, Th, ah, ctx->jv));
     {  // classifier SS:265-283
       LINOPTS(o);
       o.bias = ctx->feat_attprob.b;
@@ -875,13 +911,11 @@ int rau_backward(rau_ctx* ctx, const float* hop_w) {
   // ---------------- RAU BPTT, SS:561-578
   const float* dc_next = nullptr;  // grad_att_c / grad_att_h zeros, SS:561-562
   const float* dh_next = nullptr;
-  const int chunks = (M + 63) / 64;
   for (int h = H - 1; h >= 0; --h) {
     const float* cp = ctx->cc + (size_t)h * BR_;
     const float* qf = ctx->qf + (size_t)h * BM_;
     const float* Ih = ctx->I + (ctx->I_shared ? 0 : (size_t)h * BM_ * S);
     float* Th = ctx->T + (size_t)h * B * A * S;   // becomes dS in place
-    float* dZh = ctx->dZ + (size_t)h * BM_ * S;
     const float* ah = ctx->a + (size_t)h * BS_;
     const float* g4 = ctx->g4 + (size_t)h * B * 4 * R;
     float* dpre = ctx->dpre + (size_t)h * BM_;
@@ -924,21 +958,14 @@ int rau_backward(rau_ctx* ctx, const float* hop_w) {
       RUN("small_gemm", gflop(B, S, M), 0,
           gemm_nn(st, B, S, M, djh, M, ctx->feat_attprob.W, S, ctx->da_lin, S, o));
     }
-    RUN("attselect_bwd", 2.0 * BM_ * S, BM_ * S * 4.0,
-        attselect_bwd(st, B, M, S, Ih, djh, ctx->da_part));
-    RUN("softmax_bwd", 0, BS_ * 4.0 * (chunks + 4),
-        softmax_bwd(st, B, S, ah, ctx->da_lin, ctx->da_part, chunks, (long)BS_, dzh));
+    RUN("att_bwd_fused", 2.0 * B * S * (A + M), ((double)B * A * S * 2 + BM_ * S) * 4,
+        att_bwd_fused(st, B, M, A, S, Ih, djh, ah, ctx->da_lin, ctx->att_score.W, Th, dzh, duh,
+                      ctx->dwsp + (size_t)h * B * A));
     {  // dh_prev += dz Wm
       LINOPTS(o);
       o.accumulate = 1;
       RUN("small_gemm", gflop(B, R, S), 0, gemm_nn(st, B, R, S, dzh, S, ctx->att_mem.W, R, dh_out, R, o));
     }
-    RUN("att_score_bwd", 6.0 * B * A * S, (double)B * A * S * 8,
-        att_score_bwd(st, B, A, S, Th, dzh, ctx->att_score.W, duh, ctx->dwsp + (size_t)h * B * A));
-    RUN("conv_att_dgrad", gflop(M, (double)B * S, A), ((double)B * A * S + 2.0 * BM_ * S) * 4,
-        conv_att_dgrad(st, B, M, S, A, Th, ctx->att_i.W, djh, ah, Ih, dZh));
-    RUN("conv_att_wgrad", gflop(A, M, (double)B * S), ((double)B * A * S + BM_ * S) * 4,
-        conv_att_wgrad(st, B, M, S, A, Th, Ih, ctx->att_i.dW, ctx->slab));
     {  // dq~ = (dj + du Wa) (1 - qf^2)
       LINOPTS(o);
       o.addend = djh;
@@ -960,17 +987,42 @@ int rau_backward(rau_ctx* ctx, const float* hop_w) {
     RUN("dq_reduce", 0, (double)H * B * Q * 4,
         dq_reduce(st, H, (size_t)B * Q, ctx->dQD, m_q, sc(RAU_MASK_Q), ctx->dq));
   }
-  // i_embed weight gradient over all hops at once: dWi += sum_{h,b,s} dZ_h X'_h^T
-  // (the gradient w.r.t. the feature map itself is dead, SS:579, and never formed)
-  RUN("row_sums", 0, (double)H * BM_ * S * 4.0, row_sums(st, H * B * M, S, ctx->dZ, ctx->rsum));
-  if (!ctx->I_shared) {
-    RUN("conv_embed_wgrad", gflop(M, D, (double)H * B * S), ((double)H * BM_ * S + (double)H * B * D * S) * 4,
-        conv_embed_wgrad(st, H * B, D, S, M, ctx->dZ, ctx->xd, ctx->i_embed.dW, ctx->slab));
-  } else {
-    for (int h = 0; h < H; ++h)
-      RUN("conv_embed_wgrad", gflop(M, D, (double)B * S), (BM_ * S + (double)B * D * S) * 4,
-          conv_embed_wgrad(st, B, D, S, M, ctx->dZ + (size_t)h * BM_ * S, ctx->feats,
-                           ctx->i_embed.dW, ctx->slab));
+  // ---------------- bulk stream: the 1x1-conv gradients are off the recurrence's
+  // critical path (dZ only feeds weight gradients; the feature-map gradient is dead,
+  // SS:579), so they run once over all hops, concurrently with the encoder BPTT:
+  // dZ = (Wp^T dS + dj (x) a)(1 - I^2); dWp += dS I^T; dWi += dZ X'^T; dbi += sum dZ.
+  {
+    hipStream_t sb = ctx->st2;
+    HIPC(hipEventRecord(ctx->evC, st));
+    HIPC(hipStreamWaitEvent(sb, ctx->evC, 0));
+    if (!ctx->I_shared) {
+      const int nH = H * B;
+      RUNS(sb, "conv_att_dgrad", gflop(M, (double)nH * S, A),
+           ((double)nH * A * S + 2.0 * nH * M * S) * 4,
+           conv_att_dgrad(sb, nH, M, S, A, ctx->T, ctx->att_i.W, ctx->dj, ctx->a, ctx->I, ctx->dZ));
+      RUNS(sb, "conv_att_wgrad", gflop(A, M, (double)nH * S),
+           ((double)nH * A * S + (double)nH * M * S) * 4,
+           conv_att_wgrad(sb, nH, M, S, A, ctx->T, ctx->I, ctx->att_i.dW, ctx->slab2));
+      RUNS(sb, "conv_embed_wgrad", gflop(M, D, (double)nH * S),
+           ((double)nH * M * S + (double)nH * D * S) * 4,
+           conv_embed_wgrad(sb, nH, D, S, M, ctx->dZ, ctx->xd, ctx->i_embed.dW, ctx->slab2));
+    } else {
+      for (int h = 0; h < H; ++h) {
+        float* Th = ctx->T + (size_t)h * B * A * S;
+        float* dZh = ctx->dZ + (size_t)h * BM_ * S;
+        RUNS(sb, "conv_att_dgrad", gflop(M, (double)B * S, A), ((double)B * A * S + 2.0 * BM_ * S) * 4,
+             conv_att_dgrad(sb, B, M, S, A, Th, ctx->att_i.W, ctx->dj + (size_t)h * BM_,
+                            ctx->a + (size_t)h * BS_, ctx->I, dZh));
+        RUNS(sb, "conv_att_wgrad", gflop(A, M, (double)B * S), ((double)B * A * S + BM_ * S) * 4,
+             conv_att_wgrad(sb, B, M, S, A, Th, ctx->I, ctx->att_i.dW, ctx->slab2));
+        RUNS(sb, "conv_embed_wgrad", gflop(M, D, (double)B * S), (BM_ * S + (double)B * D * S) * 4,
+             conv_embed_wgrad(sb, B, D, S, M, dZh, ctx->feats, ctx->i_embed.dW, ctx->slab2));
+      }
+    }
+    RUNS(sb, "row_sums", 0, (double)H * BM_ * S * 4.0, row_sums(sb, H * B * M, S, ctx->dZ, ctx->rsum));
+    RUNS(sb, "colsum", 0, (double)H * B * M * 4,
+         colsum_acc(sb, H * B, M, ctx->rsum, M, ctx->i_embed.db, ctx->coltmp2));
+    HIPC(hipEventRecord(ctx->evD, sb));
   }
   // ---------------- mult-group weight gradients, one GEMM per weight over all hops
   {
@@ -997,7 +1049,6 @@ int rau_backward(rau_ctx* ctx, const float* hop_w) {
     RUN("colsum", 0, (double)rows * S * 4, colsum_acc(st, rows, S, ctx->dz, S, ctx->tmpS, ctx->coltmp));
     RUN("colsum", 0, S * 4.0, colsum_acc(st, S, 1, ctx->tmpS, 1, ctx->att_score.db, ctx->coltmp));
     RUN("colsum", 0, (double)rows * A * 4, colsum_acc(st, rows, A, ctx->du, A, ctx->att_i.db, ctx->coltmp));
-    RUN("colsum", 0, (double)rows * M * 4, colsum_acc(st, rows, M, ctx->rsum, M, ctx->i_embed.db, ctx->coltmp));
   }
 
   // ---------------- encoder BPTT, SS:581-596
@@ -1053,6 +1104,7 @@ int rau_backward(rau_ctx* ctx, const float* hop_w) {
           colsum_acc(st, rows, w.l->out, w.dY, w.l->out, w.l->db, ctx->coltmp));
     }
   }
+  HIPC(hipStreamWaitEvent(st, ctx->evD, 0));  // join: every gradient is ordered on st
   return RAU_OK;
 }
 

@@ -106,12 +106,14 @@ int main(int argc, char** argv) {
     report("conv_embed_wgrad x8 hops", timeit(st, 5, [&] { return conv_embed_wgrad(st, H * B, D, S, M, I8, xd, dWi, slab); }), 2.0 * M * NS * D * H);
     CK(hipFree(xd)); CK(hipFree(I8)); CK(hipFree(m8));
   }
-  report("conv_att_fwd", timeit(st, 20, [&] { return conv_att_fwd(st, B, M, S, A, I, Wp, bp, u, ws, T, epart); }), 2.0 * A * NS * M);
+  report("conv_att_pre", timeit(st, 20, [&] { return conv_att_pre(st, B, M, S, A, I, Wp, bp, T); }), 2.0 * A * NS * M);
+  { float* jv; CK(hipMalloc(&jv, (size_t)B * M * 4));
+    report("att_fwd_fused", timeit(st, 20, [&] { return att_fwd_fused(st, B, M, A, S, T, u, ws, bp, dz, I, dj, T, a, jv); }), 0);
+    float* du; CK(hipMalloc(&du, (size_t)B * A * 8));
+    report("att_bwd_fused", timeit(st, 20, [&] { return att_bwd_fused(st, B, M, A, S, I, dj, a, dz, ws, T, epart, du, du + B * A); }), 0); }
   report("conv_att_dgrad", timeit(st, 20, [&] { return conv_att_dgrad(st, B, M, S, A, T, Wp, dj, a, I, dZ); }), 2.0 * A * NS * M);
   report("conv_att_wgrad", timeit(st, 20, [&] { return conv_att_wgrad(st, B, M, S, A, T, I, dWp, slab); }), 2.0 * A * NS * M);
   report("conv_embed_wgrad", timeit(st, 20, [&] { return conv_embed_wgrad(st, B, D, S, M, dZ, X, dWi, slab); }), 2.0 * M * NS * D);
-  { float* du; CK(hipMalloc(&du, (size_t)B * A * 8));
-    report("att_score_bwd", timeit(st, 20, [&] { return att_score_bwd(st, B, A, S, T, dz, ws, du, du + B * A); }), 0); }
   // small GEMMs
   float* h = dev_rand((size_t)B * 2048, 0.5f), *W = dev_rand((size_t)2048 * 2048, 0.08f);
   float* C; CK(hipMalloc(&C, (size_t)8 * B * 2048 * 4));
