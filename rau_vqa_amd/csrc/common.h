@@ -10,6 +10,11 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kWave = 64;  // CDNA wavefront width
 
+// Kernels of the latency-bound recurrence chain run next to the bulk GEMMs of the
+// other stream; instruction arbitration on a SIMD is by priority, then age, and the
+// bulk waves are always older.  Chain kernels therefore raise their wave priority.
+#define RAU_CHAIN_PRIO() __builtin_amdgcn_s_setprio(3)
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -209,6 +209,7 @@ enum Epi : int {
 template <int BM, int BN, int BKT, int ASRC, int BSRC, int EPI>
 __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams P) {
   constexpr int BK = BKT;
+  if (BM < 128) RAU_CHAIN_PRIO();  // skinny tiles = chain-stream GEMMs
   constexpr int WM = BM / 2, WN = BN / 2;   // wave tile
   constexpr int IM = WM / 32, JN = WN / 32; // 32x32 blocks per wave
   constexpr int LDA = BM + LPAD, LDB = BN + LPAD;

@@ -6,13 +6,17 @@
 
 namespace rau {
 
-constexpr int BK = 32;  // K-step per LDS stage for the Linear GEMMs
+constexpr int BK = 32;   // K-step per LDS stage, 128x128 tiles
+// Skinny (64x64-tile) GEMMs run on the chain stream next to two resident bulk-GEMM
+// workgroups (2 x 67.6 KB of the CU's 160 KB LDS): a 16-deep stage keeps them at
+// 17.4 KB so they can co-reside instead of waiting for a bulk workgroup to retire.
+constexpr int BKS = 16;
 
 static GemmParams lin_params(int M, int N, int K, const float* A, long lda, const float* W,
                              long ldw, float* C, long ldc, const LinOpts& o) {
   GemmParams P{};
   P.M = M; P.N = N; P.K = K;
-  P.nk = (K + BK - 1) / BK;
+  P.nk = (K + BK - 1) / BK;   // callers using another K-step overwrite nk
   P.A = A; P.a_rs = lda;
   P.B = W; P.b_rs = ldw;
   P.C = C; P.c_rs = ldc;
@@ -31,7 +35,7 @@ static GemmParams lin_params(int M, int N, int K, const float* A, long lda, cons
 static int skinny_splits(int M, int N, int K, const LinOpts& o) {
   if (!o.slab) return 1;
   const int tiles = ((M + 63) / 64) * ((N + 63) / 64);
-  const int nk = (K + BK - 1) / BK;
+  const int nk = (K + BKS - 1) / BKS;
   int s = (384 + tiles - 1) / tiles;
   if (s > nk / 2) s = nk / 2;
   if (s < 1) s = 1;
@@ -46,12 +50,13 @@ static hipError_t lin_gemm(hipStream_t st, int M, int N, int K, const float* A, 
   GemmParams P = lin_params(M, N, K, A, lda, W, ldw, C, ldc, o);
   if ((long)M * N >= 128L * 128 * 256)
     return launch_gemm<128, 128, BK, ASRC, BSRC, EPI_LIN>(st, P, 1);
+  P.nk = (K + BKS - 1) / BKS;
   const int s = skinny_splits(M, N, K, o);
-  if (s <= 1) return launch_gemm<64, 64, BK, ASRC, BSRC, EPI_LIN>(st, P, 1);
+  if (s <= 1) return launch_gemm<64, 64, BKS, ASRC, BSRC, EPI_LIN>(st, P, 1);
   P.C = o.slab;
   P.c_rs = N;
   P.slab_stride = (long)M * N;
-  hipError_t e = launch_gemm<64, 64, BK, ASRC, BSRC, EPI_SLAB>(st, P, s);
+  hipError_t e = launch_gemm<64, 64, BKS, ASRC, BSRC, EPI_SLAB>(st, P, s);
   if (e != hipSuccess) return e;
   return lin_reduce_epilogue(st, M, N, s, o.slab, C, ldc, o);
 }

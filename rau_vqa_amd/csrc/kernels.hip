@@ -18,6 +18,7 @@ static inline int grid_for(size_t n, int block = 256, int cap = 256 * 8) {
 // ------------------------------------------------------------- dropout masks
 __global__ void k_fill_masks(uint64_t seed, uint32_t site, uint32_t step, uint32_t thr,
                              size_t nwords, uint32_t* __restrict__ bits) {
+  RAU_CHAIN_PRIO();
   for (size_t w = blockIdx.x * (size_t)blockDim.x + threadIdx.x; w < nwords;
        w += (size_t)gridDim.x * blockDim.x) {
     const uint32_t lo = philox_keep16(seed, site, step, 2 * w, thr);
@@ -36,6 +37,7 @@ hipError_t fill_masks(hipStream_t st, uint64_t seed, uint32_t site, uint32_t ste
 
 __global__ void k_uniform_fill(uint64_t seed, uint32_t stream, size_t n, float lo, float hi,
                                float* __restrict__ x) {
+  RAU_CHAIN_PRIO();
   for (size_t q = blockIdx.x * (size_t)blockDim.x + threadIdx.x; q * 4 < n;
        q += (size_t)gridDim.x * blockDim.x) {
     const Philox4 o = philox4x32_10((uint32_t)q, (uint32_t)(q >> 32), stream, 0x55AAu,
@@ -58,6 +60,7 @@ __global__ void k_embed_fwd(int rows, int E, const float* __restrict__ emb,
                             const int32_t* __restrict__ tokens,
                             const uint32_t* __restrict__ mask, float mscale,
                             float* __restrict__ we) {
+  RAU_CHAIN_PRIO();
   const size_t n = (size_t)rows * E;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n;
        i += (size_t)gridDim.x * blockDim.x) {
@@ -81,6 +84,7 @@ __global__ void k_embed_bwd(int E, const int32_t* __restrict__ utok,
                             const int32_t* __restrict__ upos, const float* __restrict__ dwe,
                             const float* __restrict__ we, const uint32_t* __restrict__ mask,
                             float mscale, float* __restrict__ gE) {
+  RAU_CHAIN_PRIO();
   const int u = blockIdx.x;
   const int tok = utok[u];
   const int p0 = ustart[u], p1 = ustart[u + 1];
@@ -117,6 +121,7 @@ __global__ void k_lstm_fwd(int nB, int R, float* __restrict__ g4,
                            long c_rs, float* __restrict__ h, long h_rs,
                            float* __restrict__ tanhc, float* __restrict__ drop_out,
                            const uint32_t* __restrict__ mask, size_t mask_e0, float mscale) {
+  RAU_CHAIN_PRIO();
   using GS = GateSlots<ORDER>;
   const size_t n = (size_t)nB * R;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n;
@@ -166,6 +171,7 @@ __global__ void k_lstm_bwd(int nB, int R, const float* __restrict__ gates,
                            float* __restrict__ dc_prev, const int32_t* __restrict__ lens, int t,
                            const float* __restrict__ dq_c, const float* __restrict__ dq_h,
                            long dq_rs) {
+  RAU_CHAIN_PRIO();
   using GS = GateSlots<ORDER>;
   const size_t n = (size_t)nB * R;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n;
@@ -230,6 +236,7 @@ __global__ __launch_bounds__(kAttThreads) void k_att_fwd_fused(
     const float* __restrict__ ws, const float* __restrict__ bs, const float* __restrict__ zm,
     const float* __restrict__ I, const float* __restrict__ qf, float* __restrict__ T,
     float* __restrict__ a, float* __restrict__ jv) {
+  RAU_CHAIN_PRIO();
   extern __shared__ __attribute__((aligned(16))) float sm[];
   float* red = sm;                     // [NW][S]
   float* as = sm + kAttWaves * S;      // [S]
@@ -323,6 +330,7 @@ __global__ __launch_bounds__(kAttThreads) void k_att_bwd_fused(
     const float* __restrict__ a, const float* __restrict__ da_lin, const float* __restrict__ ws,
     float* __restrict__ T, float* __restrict__ dz, float* __restrict__ du,
     float* __restrict__ dwsp) {
+  RAU_CHAIN_PRIO();
   extern __shared__ __attribute__((aligned(16))) float sm[];
   float* red = sm;                     // [NW][S]
   float* dzs = sm + kAttWaves * S;     // [S]
@@ -448,6 +456,7 @@ hipError_t row_sums(hipStream_t st, int rows, int S, const float* X, float* rs) 
 constexpr int kColChunks = 32;
 __global__ void k_colsum_stage1(int rows, int N, const float* __restrict__ X, long ld,
                                 float* __restrict__ tmp) {
+  RAU_CHAIN_PRIO();
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
   if (n >= N) return;
   const int per = (rows + kColChunks - 1) / kColChunks;
@@ -459,6 +468,7 @@ __global__ void k_colsum_stage1(int rows, int N, const float* __restrict__ X, lo
   tmp[(size_t)blockIdx.y * N + n] = acc;
 }
 __global__ void k_colsum_stage2(int N, const float* __restrict__ tmp, float* __restrict__ dst) {
+  RAU_CHAIN_PRIO();
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
   if (n >= N) return;
   float acc = 0.f;
@@ -481,6 +491,7 @@ __global__ void k_ce_fwd(int nB, int K, int M, const float* __restrict__ logits,
                          const float* __restrict__ wd, const float* __restrict__ bd,
                          float* __restrict__ dl, float* __restrict__ lossrow,
                          int32_t* __restrict__ argmax, float* __restrict__ dopred) {
+  RAU_CHAIN_PRIO();
   __shared__ float s_val[4];
   __shared__ int s_idx[4];
   __shared__ float s_sum[4];
@@ -543,6 +554,7 @@ hipError_t ce_fwd(hipStream_t st, int nB, int K, int M, const float* logits,
 
 __global__ void k_loss_reduce(int nB, const float* __restrict__ lossrow,
                               float* __restrict__ losses) {
+  RAU_CHAIN_PRIO();
   const int h = blockIdx.x;
   float acc = 0.f;
   for (int b = threadIdx.x; b < nB; b += 64) acc += lossrow[(size_t)h * nB + b];
@@ -556,6 +568,7 @@ hipError_t loss_reduce(hipStream_t st, int H, int nB, const float* lossrow, floa
 
 __global__ void k_scale_hops(size_t per_hop, size_t n, const float* __restrict__ w,
                              float* __restrict__ x) {
+  RAU_CHAIN_PRIO();
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n;
        i += (size_t)gridDim.x * blockDim.x)
     x[i] *= w[i / per_hop];
@@ -571,6 +584,7 @@ __global__ void k_gather_q(int nB, int Rq, const int32_t* __restrict__ lens,
                            const float* __restrict__ c1, const float* __restrict__ h1,
                            const float* __restrict__ c2, const float* __restrict__ h2,
                            float* __restrict__ q) {
+  RAU_CHAIN_PRIO();
   const size_t n = (size_t)nB * 4 * Rq;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n;
        i += (size_t)gridDim.x * blockDim.x) {
@@ -593,6 +607,7 @@ hipError_t gather_q(hipStream_t st, int nB, int Rq, int T, const int32_t* lens, 
 __global__ void k_apply_mask(size_t n, size_t period, const float* __restrict__ x,
                              const uint32_t* __restrict__ mask, float mscale,
                              float* __restrict__ y) {
+  RAU_CHAIN_PRIO();
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n;
        i += (size_t)gridDim.x * blockDim.x) {
     const float v = x[i % period];
@@ -609,6 +624,7 @@ hipError_t apply_mask(hipStream_t st, size_t n, size_t period, const float* x,
 __global__ void k_dq_reduce(int H, size_t n, const float* __restrict__ dQD,
                             const uint32_t* __restrict__ mask, float mscale,
                             float* __restrict__ dq) {
+  RAU_CHAIN_PRIO();
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n;
        i += (size_t)gridDim.x * blockDim.x) {
     float acc = 0.f;
@@ -629,6 +645,7 @@ hipError_t dq_reduce(hipStream_t st, int H, size_t n, const float* dQD, const ui
 
 __global__ void k_splitk_reduce_acc(size_t n4, int splits, const float4* __restrict__ slab,
                                     size_t stride4, float4* __restrict__ dst) {
+  RAU_CHAIN_PRIO();
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4;
        i += (size_t)gridDim.x * blockDim.x) {
     float4 acc = slab[i];
@@ -643,6 +660,7 @@ __global__ void k_splitk_reduce_acc(size_t n4, int splits, const float4* __restr
 }
 __global__ void k_splitk_reduce_acc1(size_t n, int splits, const float* __restrict__ slab,
                                      size_t stride, float* __restrict__ dst) {
+  RAU_CHAIN_PRIO();
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n;
        i += (size_t)gridDim.x * blockDim.x) {
     float acc = slab[i];
@@ -668,6 +686,7 @@ hipError_t splitk_reduce_acc(hipStream_t st, size_t n, int splits, const float* 
 // Partials are summed in split order, so the result is bitwise reproducible.
 __global__ void k_lin_reduce_epilogue(int M, int N, int splits, const float* __restrict__ slab,
                                       float* __restrict__ C, long ldc, LinOpts o) {
+  RAU_CHAIN_PRIO();
   const size_t total = (size_t)M * N;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total;
        i += (size_t)gridDim.x * blockDim.x) {
@@ -707,6 +726,7 @@ __device__ __forceinline__ float2 box_muller(uint32_t a, uint32_t b) {
 }
 __global__ void k_add_noise_sqnorm(size_t n, float* __restrict__ g, float nstd, uint64_t seed,
                                    uint32_t stream, float* __restrict__ partial) {
+  RAU_CHAIN_PRIO();
   __shared__ float s_sum[4];
   float acc = 0.f;
   for (size_t q = blockIdx.x * (size_t)blockDim.x + threadIdx.x; q * 4 < n;
@@ -739,6 +759,7 @@ hipError_t add_noise_sqnorm(hipStream_t st, size_t n, float* g, float nstd, uint
 }
 __global__ void k_finish_norm(int nparts, const float* __restrict__ partial,
                               float* __restrict__ norm_out) {
+  RAU_CHAIN_PRIO();
   __shared__ float s_sum[4];
   float acc = 0.f;
   for (int i = threadIdx.x; i < nparts; i += 256) acc += partial[i];
@@ -755,6 +776,7 @@ __global__ void k_clip_adam(size_t n, float* __restrict__ x, float* __restrict__
                             float* __restrict__ m, float* __restrict__ v,
                             const float* __restrict__ norm, float clip, float stepsize,
                             float beta1, float beta2, float eps) {
+  RAU_CHAIN_PRIO();
   const float nv = norm[0];
   const float sc = nv > clip ? clip / nv : 1.f;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n;
