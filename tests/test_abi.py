@@ -1,0 +1,77 @@
+"""The C-ABI library loads and exports exactly what include/rau.h declares."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "rau.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(rau_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_header_declares_the_boundary():
+    syms = declared_symbols()
+    for need in ("rau_create", "rau_destroy", "rau_params", "rau_set_batch", "rau_forward",
+                 "rau_backward", "rau_noise_clip_adam", "rau_last_error"):
+        assert need in syms
+
+
+def test_library_exports_every_declared_symbol():
+    from rau_vqa_amd import _lib
+    lib = C.CDLL(_lib.LIB_PATH)
+    missing = [s for s in declared_symbols() if not hasattr(lib, s)]
+    assert not missing, missing
+    # and the ctypes binding table covers the same set
+    assert sorted(_lib._SIGS) == declared_symbols()
+
+
+def test_abi_version_and_defaults():
+    from rau_vqa_amd import _lib
+    l = _lib.lib()
+    assert l.rau_abi_version() == 1
+    cfg = _lib.RauConfig()
+    l.rau_default_config(C.byref(cfg))
+    # the reference's hard-coded locals, SS:202-229, and opt.batch_size default SS:48
+    assert (cfg.E, cfg.Rq, cfg.D, cfg.S, cfg.M, cfg.A, cfg.R, cfg.K, cfg.H) == \
+        (200, 512, 512, 196, 512, 256, 512, 1000, 8)
+    assert cfg.B == 100 and abs(cfg.p_x - 0.5) < 1e-7
+
+
+def test_create_rejects_bad_config_or_missing_device():
+    """Invalid shapes are rejected before touching the device; with no GPU the
+    library must fail loudly (there is no CPU fallback)."""
+    from rau_vqa_amd import _lib
+    l = _lib.lib()
+    cfg = _lib.RauConfig()
+    l.rau_default_config(C.byref(cfg))
+    cfg.S = 195  # not a multiple of 4
+    h = C.c_void_p()
+    assert l.rau_create(C.byref(cfg), C.byref(h)) == -1
+    assert b"multiple of 4" in l.rau_last_error()
+    try:
+        import torch
+        has_gpu = torch.cuda.is_available()
+    except Exception:
+        has_gpu = False
+    if not has_gpu:
+        l.rau_default_config(C.byref(cfg))
+        rc = l.rau_create(C.byref(cfg), C.byref(h))
+        assert rc == -2 and b"no CPU fallback" in l.rau_last_error()
+
+
+def test_product_path_never_imports_the_oracle():
+    """rau_vqa_amd/ (python + csrc) must not reference oracle/ in any way."""
+    pkg = os.path.join(ROOT, "rau_vqa_amd")
+    for d, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cc", "Makefile")):
+                text = open(os.path.join(d, f)).read()
+                code = "\n".join(l for l in text.splitlines()
+                                 if not l.lstrip().startswith(("//", "#", "*", "/*")))
+                assert "import oracle" not in code and "from oracle" not in code, f
+                assert "rau_oracle" not in code or f == "philox.h", f

@@ -1,0 +1,169 @@
+"""GPU tests at BASELINE.json's full sizes and on the device-side RNG.
+
+The CPU oracle cannot run config 2 forward+backward in seconds, so at full size
+the checks are (a) size-independent properties of the outputs, (b) exact
+re-computation of the cheap tail (cross-entropy, argmax) on the host from the
+returned logits, (c) the 1000-sample answer-index parity set of BASELINE.md
+section 2.1 against the oracle's FORWARD pass (integer indices, bit-exact where
+the reference top-2 margin is decidable in fp32)."""
+import numpy as np
+import pytest
+
+import oracle
+from rau_vqa_amd import synth
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+FULL = dict(B=256, T=26, V=14000, E=200, Rq=512, D=512, S=196, M=512, A=256, R=512, K=1000, H=8)
+
+
+def make(dims, **kw):
+    from rau_vqa_amd.model import RAU, Config
+    return RAU(Config(**dims, **kw))
+
+
+def test_device_philox_masks_equal_oracle_bit_exact():
+    dims = dict(B=6, T=5, V=40, E=24, Rq=20, D=12, S=28, M=36, A=16, R=20, K=16, H=3)
+    sh = util.shapes(dims)
+    m = make(dims)
+    m.training()
+    for seed, step in [(7, 0), (2 ** 35 + 11, 123456)]:
+        m.set_dropout_seed(seed, step)
+        ref = oracle.philox_masks(sh, seed, step)
+        for site in ("we", "rnn", "q", "x", "mf"):
+            assert np.array_equal(m.get_mask(site), ref[site]), (site, seed, step)
+    m.close()
+
+
+def test_seeded_step_matches_oracle_with_regenerated_masks():
+    """Perf-mode dropout (masks generated on device from (seed, step)) against the
+    oracle fed with the same Philox stream."""
+    dims = util.SMALL
+    sh = util.shapes(dims)
+    batch, params, _ = util.make_problem(sh, scale=0.5)
+    masks = oracle.philox_masks(sh, seed=99, step=5)
+    ref = oracle.step(sh, params, batch["feats"], batch["tokens"], batch["lens"],
+                      batch["labels"], masks, dtype=np.float64)
+    m = make(dims)
+    m.set_params(params)
+    m.training()
+    m.set_dropout_seed(99, 5)
+    m.set_batch(**batch)
+    m.zero_grads()
+    m.forward()
+    out = m.outputs()
+    m.backward(np.full(sh.H, float(sh.H), np.float32))
+    g = m.get_grads()
+    m.close()
+    assert util.rel_err(out["logits"], ref["logits"]) < 1e-4
+    for k in ("embed", "rnn", "mult"):
+        assert util.rel_err(g[k], ref["g_" + k]) < 1e-4, k
+
+
+def test_full_size_properties_and_determinism():
+    m = make(FULL)
+    m.init_uniform(seed=123)
+    batch = synth.make_batch(FULL["B"], FULL["T"], FULL["V"], FULL["D"], FULL["S"], FULL["K"],
+                             lens="ragged")
+    m.set_batch(**batch)
+    m.training()
+    hop_w = np.full(8, 8.0, np.float32)
+
+    def run():
+        m.set_dropout_seed(5, 1)
+        m.zero_grads()
+        m.forward()
+        out = m.outputs()
+        m.backward(hop_w)
+        return out, m.get_grads()
+
+    out, g = run()
+    out2, g2 = run()
+    # bitwise reproducible (no float atomics anywhere on the path)
+    for k in out:
+        assert np.array_equal(out[k], out2[k]), k
+    for k in g:
+        assert np.array_equal(g[k], g2[k]), k
+    # attention rows are probability vectors
+    assert np.all(out["att"] >= 0) and np.allclose(out["att"].sum(-1), 1.0, atol=1e-5)
+    # host re-computation of the loss head from the returned logits
+    lg = out["logits"].astype(np.float64)
+    y = batch["labels"] - 1
+    lse = np.log(np.exp(lg - lg.max(-1, keepdims=True)).sum(-1)) + lg.max(-1)
+    loss = (lse - np.take_along_axis(lg, y[None, :, None].repeat(8, 0), 2)[..., 0]).mean(-1)
+    assert np.allclose(out["losses"], loss, rtol=1e-5)
+    assert np.array_equal(out["argmax"], lg.astype(np.float32).argmax(-1) + 1)  # first max, 1-based
+    assert np.all(np.isfinite(g["mult"])) and np.all(np.isfinite(g["rnn"]))
+    # gradients accumulate: a second backward pass into non-zeroed buffers doubles them
+    m.set_dropout_seed(5, 1)
+    m.forward()
+    m.backward(hop_w)
+    g3 = m.get_grads()
+    for k in g:
+        assert util.rel_err(g3[k], 2.0 * g[k].astype(np.float64)) < 1e-5, k
+    # out_do_pred receives no gradient (d_do_pred * 0, SS:566)
+    lay = dict((n, (o, r * c)) for n, o, r, c in m.layout("mult"))
+    o, n = lay["classifier.out_do_pred.weight"]
+    assert np.all(g["mult"][o:o + n] == 0)
+    # rows past the question length contribute nothing: pad-token embedding grad is zero
+    assert np.all(g["embed"][:FULL["E"]] == 0)
+    m.close()
+
+
+def test_samples_are_independent_in_eval_mode():
+    """Forward of a sample does not depend on its batch mates (sharding property)."""
+    dims = dict(FULL, B=64, H=2)
+    small = dict(FULL, B=16, H=2)
+    batch = synth.make_batch(64, 26, FULL["V"], 512, 196, 1000, lens="ragged")
+    a = make(dims)
+    a.init_uniform(seed=3)
+    params = a.get_params()
+    a.evaluate()
+    a.set_batch(**batch)
+    a.forward()
+    big = a.logits()
+    a.close()
+    b = make(small)
+    b.set_params(params)
+    b.evaluate()
+    sub = {"feats": batch["feats"][16:32], "tokens": batch["tokens"][:, 16:32],
+           "lens": batch["lens"][16:32], "labels": batch["labels"][16:32]}
+    b.set_batch(**sub)
+    b.forward()
+    small_out = b.logits()
+    b.close()
+    assert util.rel_err(small_out, big[:, 16:32]) < 1e-5
+
+
+def test_answer_index_parity_1k_samples():
+    """BASELINE.md 2.1 parity set: 1000 samples, seed 123, config-2 shapes, run as
+    4 x 250; per-hop and 'uni' argmax against the oracle forward (eval mode)."""
+    dims = dict(FULL, B=250)
+    sh = util.shapes(dims)
+    m = make(dims)
+    m.init_uniform(seed=123)
+    params = m.get_params()
+    m.evaluate()
+    mism = undecided = total = 0
+    for chunk in range(4):
+        batch = synth.make_batch(250, 26, FULL["V"], 512, 196, 1000, seed=123 + chunk,
+                                 lens="ragged")
+        m.set_batch(**batch)
+        m.forward()
+        got_idx, got_lg = m.argmax(), m.logits()
+        ref = oracle.step(sh, params, batch["feats"], batch["tokens"], batch["lens"],
+                          batch["labels"], None, backward=False, dtype=np.float32)
+        assert util.rel_err(got_lg, ref["logits"]) < 1e-4
+        # per-hop answers, and the "uni" merge (mean of hop logits, SS:522-526 / SS:699)
+        cands = [(ref["logits"], got_idx, ref["argmax"]),
+                 (ref["logits"].mean(0, keepdims=True), got_lg.mean(0).argmax(-1)[None] + 1,
+                  ref["logits"].mean(0).argmax(-1)[None] + 1)]
+        for rl, gi, ri in cands:
+            srt = np.sort(rl, axis=-1)
+            decided = (srt[..., -1] - srt[..., -2]) > 1e-5 * np.maximum(1.0, np.abs(srt[..., -1]))
+            mism += int(np.sum((gi != ri) & decided))
+            undecided += int(np.sum(~decided))
+            total += gi.size
+    m.close()
+    assert mism == 0, f"{mism} decided answer indices differ (of {total}, {undecided} undecided)"
