@@ -1,0 +1,140 @@
+--[[ rau.lua -- LuaJIT FFI shim over librau.so (include/rau.h).
+
+Presents the reference's nn.Module call surface for the RAU hot path so that
+experiments/Ours_*/LstmAttCtrlGradNoiseDontSelect.lua keeps its structure:
+  :training() / :evaluate()          (SS:449-450, 479, 648-649, 676)
+  :getParameters()                   (SS:322-324)  -> flat param / grad handles
+  feval's tensor half                (SS:428-596)  -> rau:forward() / rau:backward(w)
+  adam(x, dx, lr, ...) x 3 + noise + clip (SS:597-630, 770-772) -> rau:update(...)
+
+No LuaJIT/Torch7 toolchain exists in the build image, so this file is shipped as
+source and is NOT exercised by the tests; the Python ctypes binding
+(rau_vqa_amd/_lib.py) is the executable proof of the identical ABI.
+INTEGRATION.md shows the reference-side patch that uses this file.
+]]
+local ffi = require 'ffi'
+
+ffi.cdef[[
+typedef struct rau_config {
+  int32_t B, T, V, E, Rq, D, S, M, A, R, K, H;
+  float p_we, p_rnn, p_q, p_x, p_mf;
+  int32_t dtype, device_id;
+} rau_config;
+typedef struct rau_ctx rau_ctx;
+void rau_default_config(rau_config* cfg);
+const char* rau_last_error(void);
+int rau_abi_version(void);
+int rau_create(const rau_config* cfg, rau_ctx** out);
+void rau_destroy(rau_ctx* ctx);
+int rau_params(rau_ctx* ctx, int group, float** weights, float** grads, size_t* n);
+int rau_layout_count(const rau_ctx* ctx, int group);
+int rau_layout_entry(const rau_ctx* ctx, int group, int index, const char** name,
+                     size_t* offset, int32_t* rows, int32_t* cols);
+int rau_set_params(rau_ctx* ctx, int group, const float* host, size_t n);
+int rau_get_params(rau_ctx* ctx, int group, float* host, size_t n);
+int rau_get_grads(rau_ctx* ctx, int group, float* host, size_t n);
+int rau_set_grads(rau_ctx* ctx, int group, const float* host, size_t n);
+int rau_init_uniform(rau_ctx* ctx, uint64_t seed, float lo, float hi);
+int rau_zero_grads(rau_ctx* ctx);
+int rau_set_mode(rau_ctx* ctx, int mode);
+int rau_set_dropout_seed(rau_ctx* ctx, uint64_t seed, uint32_t step);
+int rau_set_mask(rau_ctx* ctx, int site, const uint8_t* keep, size_t n);
+int rau_get_mask(rau_ctx* ctx, int site, uint8_t* keep, size_t n);
+int rau_set_batch(rau_ctx* ctx, const float* feats, const int32_t* tokens,
+                  const int32_t* lens, const int32_t* labels);
+int rau_batch_feats(rau_ctx* ctx, float** feats_dev);
+int rau_forward(rau_ctx* ctx);
+int rau_backward(rau_ctx* ctx, const float* hop_w);
+int rau_sync(rau_ctx* ctx);
+int rau_get_losses(rau_ctx* ctx, float* losses);
+int rau_get_argmax(rau_ctx* ctx, int32_t* ans);
+int rau_get_logits(rau_ctx* ctx, float* logits);
+int rau_get_dopred(rau_ctx* ctx, float* dopred);
+int rau_get_attention(rau_ctx* ctx, float* att);
+int rau_get_question_state(rau_ctx* ctx, float* q);
+int rau_get_att_state(rau_ctx* ctx, float* c, float* h);
+int rau_noise_clip_adam(rau_ctx* ctx, int64_t step_t, float lr, float mult_lr,
+                        float beta1, float beta2, float eps, float eta, float gamma,
+                        float clip, uint64_t noise_seed, float* out_norms);
+int rau_stream(rau_ctx* ctx, void** hip_stream);
+int rau_timer_begin(rau_ctx* ctx);
+int rau_timer_end(rau_ctx* ctx, float* ms);
+]]
+
+local C = ffi.load(os.getenv('RAU_LIB') or 'librau.so')
+local GROUP = { embed = 0, rnn = 1, mult = 2 }
+
+local function check(rc)
+  if rc ~= 0 then error('librau: ' .. ffi.string(C.rau_last_error()), 3) end
+end
+
+local RAU = {}
+RAU.__index = RAU
+
+-- opt: the reference's hard-coded locals (SS:202-229) plus data-defined sizes
+function RAU.new(opt)
+  local cfg = ffi.new('rau_config[1]')
+  C.rau_default_config(cfg)
+  for k, v in pairs(opt) do cfg[0][k] = v end
+  local h = ffi.new('rau_ctx*[1]')
+  check(C.rau_create(cfg, h))
+  local self = setmetatable({ h = ffi.gc(h[0], C.rau_destroy), cfg = cfg[0] }, RAU)
+  return self
+end
+
+-- nn.Module surface ----------------------------------------------------------
+function RAU:training() check(C.rau_set_mode(self.h, 0)); return self end
+function RAU:evaluate() check(C.rau_set_mode(self.h, 1)); return self end
+
+-- m:getParameters(): returns {ptr=device float*, grad=device float*, n=count}
+function RAU:getParameters(group)
+  local w, g, n = ffi.new('float*[1]'), ffi.new('float*[1]'), ffi.new('size_t[1]')
+  check(C.rau_params(self.h, GROUP[group], w, g, n))
+  return { ptr = w[0], grad = g[0], n = tonumber(n[0]) }
+end
+
+-- param:uniform(-0.08, 0.08), SS:352-354
+function RAU:reset(seed, lo, hi) check(C.rau_init_uniform(self.h, seed or 123, lo or -0.08, hi or 0.08)) end
+
+-- feats: FloatTensor [B,D,W,H]; x: IntTensor [T,B]; x_len, y: IntTensor [B]  (loader.lua:1009)
+function RAU:setBatch(feats, x, x_len, y)
+  check(C.rau_set_batch(self.h, feats:data(), x:data(), x_len:data(), y and y:data() or nil))
+end
+
+-- forward half of feval (SS:443-520); returns per-hop losses as a Lua table
+function RAU:forward(seed, step)
+  if seed then check(C.rau_set_dropout_seed(self.h, seed, step or 0)) end
+  check(C.rau_forward(self.h))
+  local H = self.cfg.H
+  local l = ffi.new('float[?]', H)
+  check(C.rau_get_losses(self.h, l))
+  local t = {}
+  for i = 1, H do t[i] = l[i - 1] end
+  return t
+end
+
+-- backward half (SS:561-596); hop_w = per-hop criterion-gradient scale (SS:569 / Full:587-589)
+function RAU:backward(hop_w)
+  local H = self.cfg.H
+  local w = ffi.new('float[?]', H)
+  for i = 1, H do w[i - 1] = hop_w[i] end
+  check(C.rau_backward(self.h, w))
+end
+
+function RAU:zeroGradParameters() check(C.rau_zero_grads(self.h)) end
+
+-- noise + clip + adam x 3 groups (SS:597-630, 770-772)
+function RAU:update(step_t, lr, mult_lr, eta, gamma, clip, seed)
+  local norms = ffi.new('float[3]')
+  check(C.rau_noise_clip_adam(self.h, step_t, lr, mult_lr, 0.9, 0.999, 1e-8, eta or 0.01,
+                              gamma or 0.55, clip or 0.1, seed or 0, norms))
+  return norms[0], norms[1], norms[2]
+end
+
+-- answers: IntTensor [H,B] of 1-based class ids (torch.max first-max rule, SS:488)
+function RAU:answers(out) check(C.rau_get_argmax(self.h, out:data())); return out end
+function RAU:logits(out) check(C.rau_get_logits(self.h, out:data())); return out end
+function RAU:attention(out) check(C.rau_get_attention(self.h, out:data())); return out end
+function RAU:sync() check(C.rau_sync(self.h)) end
+
+return RAU
