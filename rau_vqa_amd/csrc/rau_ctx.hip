@@ -94,7 +94,10 @@ struct rau_ctx {
   int Q;
   hipStream_t st = nullptr;    // chain stream: recurrences, small GEMMs; what callers order against
   hipStream_t st2 = nullptr;   // bulk stream: hop-batched 1x1-conv GEMMs, overlapped with the chain
-  hipEvent_t evA = nullptr, evB = nullptr, evC = nullptr, evD = nullptr;
+  hipEvent_t evA = nullptr, evD = nullptr;
+  std::vector<hipEvent_t> evF, evK;  // per hop group: forward bulk done / backward chain done
+  int cur_group = 1;                 // group size used by the last forward
+  int hop_group = 1;                 // hops per bulk launch (pipelines bulk GEMMs with the hop loops)
   std::vector<void*> allocs;
   Group grp[3];
   // mult
@@ -324,8 +327,14 @@ int rau_create(const rau_config* cfg, rau_ctx** out) {
   }
   hipEventCreate(&ctx->ev0);
   hipEventCreate(&ctx->ev1);
-  for (hipEvent_t* e : {&ctx->evA, &ctx->evB, &ctx->evC, &ctx->evD})
-    hipEventCreateWithFlags(e, hipEventDisableTiming);
+  for (hipEvent_t* e : {&ctx->evA, &ctx->evD}) hipEventCreateWithFlags(e, hipEventDisableTiming);
+  ctx->hop_group = (c.H % 2 == 0) ? 2 : 1;
+  ctx->evF.resize(c.H);
+  ctx->evK.resize(c.H);
+  for (int i = 0; i < c.H; ++i) {
+    hipEventCreateWithFlags(&ctx->evF[i], hipEventDisableTiming);
+    hipEventCreateWithFlags(&ctx->evK[i], hipEventDisableTiming);
+  }
 
   const int B = c.B, T = c.T, E = c.E, Rq = c.Rq, D = c.D, S = c.S, M = c.M, A = c.A, R = c.R,
             K = c.K, H = c.H, Q = ctx->Q;
@@ -501,8 +510,10 @@ void rau_destroy(rau_ctx* ctx) {
   for (auto e : ctx->evpool) hipEventDestroy(e);
   if (ctx->ev0) hipEventDestroy(ctx->ev0);
   if (ctx->ev1) hipEventDestroy(ctx->ev1);
-  for (hipEvent_t e : {ctx->evA, ctx->evB, ctx->evC, ctx->evD})
+  for (hipEvent_t e : {ctx->evA, ctx->evD})
     if (e) hipEventDestroy(e);
+  for (hipEvent_t e : ctx->evF) hipEventDestroy(e);
+  for (hipEvent_t e : ctx->evK) hipEventDestroy(e);
   if (ctx->st2) hipStreamDestroy(ctx->st2);
   if (ctx->st) hipStreamDestroy(ctx->st);
   delete ctx;
@@ -716,32 +727,38 @@ int rau_forward(rau_ctx* ctx) {
   auto gflop = [](double m, double n, double k) { return 2.0 * m * n * k; };
 
   // ---------------- bulk stream: everything about the feature map that does not
-  // depend on the recurrence, for all hops at once (overlaps the encoder below).
+  // depend on the recurrence (overlaps the encoder and the hop loop below).
   // i_embed SS:238-242: in train mode each hop clone has its own dropout mask on
-  // the feature map (SS:239, SS:343-347) -> xd[h] = X (.) mask_h, one GEMM over
-  // H*B samples; in evaluate mode I is hop-invariant and computed once.
+  // the feature map (SS:239, SS:343-347) -> xd[h] = X (.) mask_h, then GEMMs over
+  // groups of hops; in evaluate mode I is hop-invariant and computed once.
   // attbycontent's ifeatproj (SS:247-249) is hop-invariant given I: P = Wp I + bp;
   // the per-hop half (+u, tanh, score, softmax, context) is att_fwd_fused.
+  // Hops are launched in groups of `hop_group` so hop h's chain can start as soon
+  // as its group is done while the bulk stream works on the later groups.
+  ctx->I_shared = (m_x == nullptr);
+  const int GH = ctx->I_shared ? H : ctx->hop_group;   // hops per bulk launch
+  ctx->cur_group = GH;
   {
     hipStream_t sb = ctx->st2;
     HIPC(hipEventRecord(ctx->evA, st));
     HIPC(hipStreamWaitEvent(sb, ctx->evA, 0));
-    ctx->I_shared = (m_x == nullptr);
-    const int nBI = ctx->I_shared ? B : H * B;
-    const float* xin_feats = ctx->feats;
-    if (m_x) {
+    if (m_x)
       RUNS(sb, "dropout_features", 0, (double)(H + 1) * B * D * S * 4,
            dropout_features(sb, H, (size_t)B * D * S, ctx->feats, m_x, sc(RAU_MASK_X), ctx->xd));
-      xin_feats = ctx->xd;
+    for (int h0 = 0; h0 < H; h0 += GH) {
+      const int nBI = ctx->I_shared ? B : GH * B;
+      const size_t hb = ctx->I_shared ? 0 : (size_t)h0 * B;  // first (hop, sample) row
+      const float* xin = m_x ? ctx->xd + hb * D * S : ctx->feats;
+      float* Ig = ctx->I + hb * M * S;
+      float* Pg = ctx->I_shared ? ctx->P0 : ctx->T + hb * A * S;
+      RUNS(sb, "conv_embed_fwd", gflop(M, (double)nBI * S, D),
+           ((double)nBI * D * S + (double)nBI * M * S) * 4,
+           conv_embed_fwd(sb, nBI, D, S, M, xin, ctx->i_embed.W, ctx->i_embed.b, Ig));
+      RUNS(sb, "conv_att_pre", gflop(A, (double)nBI * S, M),
+           ((double)nBI * M * S + (double)nBI * A * S) * 4,
+           conv_att_pre(sb, nBI, M, S, A, Ig, ctx->att_i.W, ctx->att_i.b, Pg));
+      HIPC(hipEventRecord(ctx->evF[h0], sb));
     }
-    RUNS(sb, "conv_embed_fwd", gflop(M, (double)nBI * S, D),
-         ((double)nBI * D * S + (double)nBI * M * S) * 4,
-         conv_embed_fwd(sb, nBI, D, S, M, xin_feats, ctx->i_embed.W, ctx->i_embed.b, ctx->I));
-    float* Pall = ctx->I_shared ? ctx->P0 : ctx->T;
-    RUNS(sb, "conv_att_pre", gflop(A, (double)nBI * S, M),
-         ((double)nBI * M * S + (double)nBI * A * S) * 4,
-         conv_att_pre(sb, nBI, M, S, A, ctx->I, ctx->att_i.W, ctx->att_i.b, Pall));
-    HIPC(hipEventRecord(ctx->evB, sb));
   }
 
   // ---------------- encoder, SS:443-462
@@ -798,10 +815,10 @@ int rau_forward(rau_ctx* ctx) {
   // Train mode: each hop clone has its own dropout mask on the feature map
   // (SS:239, SS:343-347) -> xd[h] = X (.) mask_h, then one GEMM over H*B samples.
   // Evaluate mode: dropout is the identity, so I is hop-invariant and computed once.
-  HIPC(hipStreamWaitEvent(st, ctx->evB, 0));  // I and P for every hop are ready
   HIPC(hipMemsetAsync(ctx->cc, 0, BR_ * sizeof(float), st));  // att_c, att_h zeros SS:362-365
   HIPC(hipMemsetAsync(ctx->hh, 0, BR_ * sizeof(float), st));
   for (int h = 0; h < H; ++h) {
+    if (h % GH == 0) HIPC(hipStreamWaitEvent(st, ctx->evF[h], 0));  // this group's I and P are ready
     const float* hp = ctx->hh + (size_t)h * BR_;
     const float* cp = ctx->cc + (size_t)h * BR_;
     float* qf = ctx->qf + (size_t)h * BM_;
@@ -891,6 +908,7 @@ int rau_backward(rau_ctx* ctx, const float* hop_w) {
   const int B = c.B, E = c.E, Rq = c.Rq, D = c.D, S = c.S, M = c.M, A = c.A, R = c.R, K = c.K,
             H = c.H, Q = ctx->Q;
   const int TL = ctx->max_len;
+  const int GH = ctx->cur_group;
   hipStream_t st = ctx->st;
   const bool tr = ctx->mode == RAU_MODE_TRAIN;
   auto mk = [&](int site) -> const uint32_t* {
@@ -979,6 +997,44 @@ int rau_backward(rau_ctx* ctx, const float* hop_w) {
     }
     dc_next = dc_out;
     dh_next = dh_out;
+    // ---------------- bulk stream: the 1x1-conv gradients are off the recurrence's
+    // critical path (dZ only feeds weight gradients; the feature-map gradient is dead,
+    // SS:579, never formed).  As soon as a hop group's chain is done its conv gradients
+    // start on the bulk stream, overlapping the remaining hops and the encoder BPTT:
+    // dZ = (Wp^T dS + dj (x) a)(1 - I^2); dWp += dS I^T; dWi += dZ X'^T.
+    if (h % GH == 0) {
+      hipStream_t sb = ctx->st2;
+      HIPC(hipEventRecord(ctx->evK[h], st));
+      HIPC(hipStreamWaitEvent(sb, ctx->evK[h], 0));
+      if (!ctx->I_shared) {
+        const int nH = GH * B;
+        const size_t hb = (size_t)h * B;
+        RUNS(sb, "conv_att_dgrad", gflop(M, (double)nH * S, A),
+             ((double)nH * A * S + 2.0 * nH * M * S) * 4,
+             conv_att_dgrad(sb, nH, M, S, A, ctx->T + hb * A * S, ctx->att_i.W, ctx->dj + hb * M,
+                            ctx->a + hb * S, ctx->I + hb * M * S, ctx->dZ + hb * M * S));
+        RUNS(sb, "conv_att_wgrad", gflop(A, M, (double)nH * S),
+             ((double)nH * A * S + (double)nH * M * S) * 4,
+             conv_att_wgrad(sb, nH, M, S, A, ctx->T + hb * A * S, ctx->I + hb * M * S,
+                            ctx->att_i.dW, ctx->slab2));
+        RUNS(sb, "conv_embed_wgrad", gflop(M, D, (double)nH * S),
+             ((double)nH * M * S + (double)nH * D * S) * 4,
+             conv_embed_wgrad(sb, nH, D, S, M, ctx->dZ + hb * M * S, ctx->xd + hb * D * S,
+                              ctx->i_embed.dW, ctx->slab2));
+      } else {
+        for (int hh2 = 0; hh2 < H; ++hh2) {  // evaluate mode: I (and X) shared by all hops
+          float* Th2 = ctx->T + (size_t)hh2 * B * A * S;
+          float* dZh = ctx->dZ + (size_t)hh2 * BM_ * S;
+          RUNS(sb, "conv_att_dgrad", gflop(M, (double)B * S, A), ((double)B * A * S + 2.0 * BM_ * S) * 4,
+               conv_att_dgrad(sb, B, M, S, A, Th2, ctx->att_i.W, ctx->dj + (size_t)hh2 * BM_,
+                              ctx->a + (size_t)hh2 * BS_, ctx->I, dZh));
+          RUNS(sb, "conv_att_wgrad", gflop(A, M, (double)B * S), ((double)B * A * S + BM_ * S) * 4,
+               conv_att_wgrad(sb, B, M, S, A, Th2, ctx->I, ctx->att_i.dW, ctx->slab2));
+          RUNS(sb, "conv_embed_wgrad", gflop(M, D, (double)B * S), (BM_ * S + (double)B * D * S) * 4,
+               conv_embed_wgrad(sb, B, D, S, M, dZh, ctx->feats, ctx->i_embed.dW, ctx->slab2));
+        }
+      }
+    }
   }
   {  // dq = sum_h (dq~_h Wq) (.) mask_h     (ConcatTable backward, SS:579)
     LINOPTS(o);
@@ -987,38 +1043,9 @@ int rau_backward(rau_ctx* ctx, const float* hop_w) {
     RUN("dq_reduce", 0, (double)H * B * Q * 4,
         dq_reduce(st, H, (size_t)B * Q, ctx->dQD, m_q, sc(RAU_MASK_Q), ctx->dq));
   }
-  // ---------------- bulk stream: the 1x1-conv gradients are off the recurrence's
-  // critical path (dZ only feeds weight gradients; the feature-map gradient is dead,
-  // SS:579), so they run once over all hops, concurrently with the encoder BPTT:
-  // dZ = (Wp^T dS + dj (x) a)(1 - I^2); dWp += dS I^T; dWi += dZ X'^T; dbi += sum dZ.
+  // bulk stream tail: i_embed bias gradient over all hops, then the join event
   {
     hipStream_t sb = ctx->st2;
-    HIPC(hipEventRecord(ctx->evC, st));
-    HIPC(hipStreamWaitEvent(sb, ctx->evC, 0));
-    if (!ctx->I_shared) {
-      const int nH = H * B;
-      RUNS(sb, "conv_att_dgrad", gflop(M, (double)nH * S, A),
-           ((double)nH * A * S + 2.0 * nH * M * S) * 4,
-           conv_att_dgrad(sb, nH, M, S, A, ctx->T, ctx->att_i.W, ctx->dj, ctx->a, ctx->I, ctx->dZ));
-      RUNS(sb, "conv_att_wgrad", gflop(A, M, (double)nH * S),
-           ((double)nH * A * S + (double)nH * M * S) * 4,
-           conv_att_wgrad(sb, nH, M, S, A, ctx->T, ctx->I, ctx->att_i.dW, ctx->slab2));
-      RUNS(sb, "conv_embed_wgrad", gflop(M, D, (double)nH * S),
-           ((double)nH * M * S + (double)nH * D * S) * 4,
-           conv_embed_wgrad(sb, nH, D, S, M, ctx->dZ, ctx->xd, ctx->i_embed.dW, ctx->slab2));
-    } else {
-      for (int h = 0; h < H; ++h) {
-        float* Th = ctx->T + (size_t)h * B * A * S;
-        float* dZh = ctx->dZ + (size_t)h * BM_ * S;
-        RUNS(sb, "conv_att_dgrad", gflop(M, (double)B * S, A), ((double)B * A * S + 2.0 * BM_ * S) * 4,
-             conv_att_dgrad(sb, B, M, S, A, Th, ctx->att_i.W, ctx->dj + (size_t)h * BM_,
-                            ctx->a + (size_t)h * BS_, ctx->I, dZh));
-        RUNS(sb, "conv_att_wgrad", gflop(A, M, (double)B * S), ((double)B * A * S + BM_ * S) * 4,
-             conv_att_wgrad(sb, B, M, S, A, Th, ctx->I, ctx->att_i.dW, ctx->slab2));
-        RUNS(sb, "conv_embed_wgrad", gflop(M, D, (double)B * S), (BM_ * S + (double)B * D * S) * 4,
-             conv_embed_wgrad(sb, B, D, S, M, dZh, ctx->feats, ctx->i_embed.dW, ctx->slab2));
-      }
-    }
     RUNS(sb, "row_sums", 0, (double)H * BM_ * S * 4.0, row_sums(sb, H * B * M, S, ctx->dZ, ctx->rsum));
     RUNS(sb, "colsum", 0, (double)H * B * M * 4,
          colsum_acc(sb, H * B, M, ctx->rsum, M, ctx->i_embed.db, ctx->coltmp2));
