@@ -41,19 +41,21 @@ hipError_t conv_att_pre(hipStream_t st, int nB, int M, int S, int A, const float
   return launch_gemm<128, 128, BK, SRC_KC, SRC_RC_FLAT, EPI_CONV>(st, P, 1);
 }
 
-// backward of attbycontent + attselect into the i_embed pre-activation gradient:
-// dZ[b,m,s] = (sum_k Wp[k,m] dS[b,k,s] + dj[b,m] a[b,s]) * (1 - I^2)
+// backward of attbycontent + attselect into the gradient w.r.t. i_embed's OUTPUT:
+// dI[b,m,s] = sum_k Wp[k,m] dS[b,k,s] + dj[b,m] a[b,s].  The tanh derivative
+// (1 - I^2) is applied where dI is consumed (conv_embed_wgrad's operand loader,
+// row_sums_dtanh), not here: reading I in this short-K GEMM's epilogue cost more
+// than the GEMM itself.
 hipError_t conv_att_dgrad(hipStream_t st, int nB, int M, int S, int A, const float* dS,
-                          const float* Wp, const float* dj, const float* a, const float* I,
-                          float* dZ) {
+                          const float* Wp, const float* dj, const float* a, float* dI) {
   GemmParams P{};
   P.M = M; P.N = nB * S; P.K = A; P.nk = (A + BK - 1) / BK;
   P.A = Wp; P.a_rs = M;                 // Wp stored [A][M]: reduction-major, m contiguous
   P.B = dS; P.b_rs = S; P.b_bs = (long)A * S;
   P.S = S;
-  P.C = dZ; P.c_bs = (long)M * S;
-  P.v1 = dj; P.v2 = a; P.I = I;
-  return launch_gemm<128, 128, BK, SRC_RC, SRC_RC_FLAT, EPI_DI>(st, P, 1);
+  P.C = dI; P.c_bs = (long)M * S;
+  P.v1 = dj; P.v2 = a;
+  return launch_gemm<128, 128, BK, SRC_RC, SRC_RC_FLAT, EPI_OUTER>(st, P, 1);
 }
 
 static int conv_wgrad_splits(int nB, int rowsA, int rowsB) {
@@ -69,7 +71,7 @@ size_t conv_wgrad_slab_floats(int nB, int rowsA, int rowsB, int S) {
 
 // dW[ra, rb] += sum_{b,s} Aop[b,ra,s] * Bop[b,rb,s]; whole samples per split,
 // partial tiles to slabs, fixed-order reduction into dW.
-template <int BKT>
+template <int BKT, int ASRC>
 static hipError_t conv_wgrad(hipStream_t st, GemmParams P, int nB, int S, float* dW,
                              float* slab) {
   P.S = S;
@@ -84,17 +86,18 @@ static hipError_t conv_wgrad(hipStream_t st, GemmParams P, int nB, int S, float*
   P.nk_per_split = spb * P.cps;
   const int splits = (P.nk + P.nk_per_split - 1) / P.nk_per_split;
   dim3 grid(P.tiles_m * P.tiles_n, 1, splits);
-  hipLaunchKernelGGL((gemm_kernel<128, 128, BKT, SRC_SC, SRC_SC, EPI_SLAB>), grid, dim3(256), 0,
+  hipLaunchKernelGGL((gemm_kernel<128, 128, BKT, ASRC, SRC_SC, EPI_SLAB>), grid, dim3(256), 0,
                      st, P);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   return splitk_reduce_acc(st, (size_t)P.M * P.N, splits, slab, (size_t)P.M * P.N, dW);
 }
+template <int ASRC>
 static hipError_t conv_wgrad_any(hipStream_t st, const GemmParams& P, int nB, int S, float* dW,
                                  float* slab) {
   // 14x14 maps: 196 = 7 * 28, so a 28-deep K-step wastes no MFMA work on padding
-  if (S % 28 == 0) return conv_wgrad<28>(st, P, nB, S, dW, slab);
-  return conv_wgrad<32>(st, P, nB, S, dW, slab);
+  if (S % 28 == 0) return conv_wgrad<28, ASRC>(st, P, nB, S, dW, slab);
+  return conv_wgrad<32, ASRC>(st, P, nB, S, dW, slab);
 }
 
 // dWp[k,m] += sum_{b,s} dS[b,k,s] I[b,m,s]
@@ -104,17 +107,18 @@ hipError_t conv_att_wgrad(hipStream_t st, int nB, int M, int S, int A, const flo
   P.M = A; P.N = M;
   P.A = dS; P.a_bs = (long)A * S;
   P.B = I; P.b_bs = (long)M * S;
-  return conv_wgrad_any(st, P, nB, S, dWp, slab);
+  return conv_wgrad_any<SRC_SC>(st, P, nB, S, dWp, slab);
 }
 
-// dWi[m,d] += sum_{b,s} dZ[b,m,s] X'[b,d,s]      (nB may be H*B: all hops at once)
-hipError_t conv_embed_wgrad(hipStream_t st, int nB, int D, int S, int M, const float* dZ,
-                            const float* X, float* dWi, float* slab) {
+// dWi[m,d] += sum_{b,s} dZ[b,m,s] X'[b,d,s] with dZ = dI * (1 - I^2) formed while
+// staging the operand (nB may be a group of hops)
+hipError_t conv_embed_wgrad(hipStream_t st, int nB, int D, int S, int M, const float* dI,
+                            const float* I, const float* X, float* dWi, float* slab) {
   GemmParams P{};
   P.M = M; P.N = D;
-  P.A = dZ; P.a_bs = (long)M * S;
+  P.A = dI; P.A2 = I; P.a_bs = (long)M * S;
   P.B = X; P.b_bs = (long)D * S;
-  return conv_wgrad_any(st, P, nB, S, dWi, slab);
+  return conv_wgrad_any<SRC_SC_DTANH>(st, P, nB, S, dWi, slab);
 }
 
 }  // namespace rau

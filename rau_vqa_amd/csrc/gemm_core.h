@@ -27,6 +27,7 @@ struct GemmParams {
   int tiles_m, tiles_n;
   // A operand
   const float* A; long a_rs; long a_bs;
+  const float* A2;      // SC_DTANH loader: second source, A * (1 - A2^2) (same indexing as A)
   // B operand
   const float* B; long b_rs; long b_bs;
   // flattened (sample, position) column space: n -> (n / S, n % S)
@@ -43,7 +44,6 @@ struct GemmParams {
   // conv epilogue extras
   const float* v1;     // dj [sample][M]
   const float* v2;     // a  [sample][S]
-  const float* I;      // saved I
   int dbg;             // tools/kbench only: 1 = no global loads in the loop, 2 = no barriers
 };
 
@@ -137,7 +137,9 @@ struct LoadRC {
 // operand stored [sample][rows][S], reduction over (sample, position); step g
 // covers positions [BKT*(g % cps), +BKT) of sample g / cps, zero-filled past S.
 // 8 lanes per row (BKT <= 32); lanes whose chunk lies beyond BKT stay idle.
-template <int BT, int BKT>
+// DT: the operand is x * (1 - y^2) with y read from a second tensor of the same
+// layout (gradient through tanh applied while staging, at LDS-store time).
+template <int BT, int BKT, bool DT = false>
 struct LoadSC {
   static constexpr int LPR = 8;
   static constexpr int RPP = 256 / LPR;
@@ -145,12 +147,15 @@ struct LoadSC {
   long roff[NI];
   bool ok[NI];
   float4 v[NI];
+  float4 y[DT ? NI : 1];
   const float* base;
+  const float* base2;
   long bs;
   int kc, S, cps;
   __device__ __forceinline__ void init(const GemmParams& P, const float* base_, long rs,
                                        long bs_, int row0, int rows, int tid) {
     base = base_;
+    base2 = P.A2;
     bs = bs_;
     S = P.S;
     cps = P.cps;
@@ -167,20 +172,32 @@ struct LoadSC {
     const int s0 = (g - b * cps) * BKT;
     const bool kin = kc < BKT && s0 + kc < S;
 #pragma unroll
-    for (int i = 0; i < NI; ++i)
-      v[i] = (ok[i] && kin) ? *reinterpret_cast<const float4*>(base + (long)b * bs + roff[i] + s0)
+    for (int i = 0; i < NI; ++i) {
+      const long e = (long)b * bs + roff[i] + s0;
+      v[i] = (ok[i] && kin) ? *reinterpret_cast<const float4*>(base + e)
                             : make_float4(0.f, 0.f, 0.f, 0.f);
+      if (DT)
+        y[i] = (ok[i] && kin) ? *reinterpret_cast<const float4*>(base2 + e)
+                              : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
   }
   __device__ __forceinline__ void store(float* lds, int tid) const {
     if (kc >= BKT) return;
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
       const int r = tid / LPR + i * RPP;
+      float4 x = v[i];
+      if (DT) {
+        x.x *= (1.f - y[i].x * y[i].x);
+        x.y *= (1.f - y[i].y * y[i].y);
+        x.z *= (1.f - y[i].z * y[i].z);
+        x.w *= (1.f - y[i].w * y[i].w);
+      }
       float* d = lds + kc * (BT + LPAD) + r;
-      d[0] = v[i].x;
-      d[BT + LPAD] = v[i].y;
-      d[2 * (BT + LPAD)] = v[i].z;
-      d[3 * (BT + LPAD)] = v[i].w;
+      d[0] = x.x;
+      d[BT + LPAD] = x.y;
+      d[2 * (BT + LPAD)] = x.z;
+      d[3 * (BT + LPAD)] = x.w;
     }
   }
 };
@@ -190,20 +207,22 @@ enum Src : int {
   SRC_KC = 0,        // [rows][K]
   SRC_RC = 1,        // [K][cols]
   SRC_RC_FLAT = 2,   // [sample][K][S], flattened columns
-  SRC_SC = 3         // [sample][rows][S], reduction over (sample, position)
+  SRC_SC = 3,        // [sample][rows][S], reduction over (sample, position)
+  SRC_SC_DTANH = 4   // same, operand = A * (1 - A2^2)
 };
 template <int BT, int BKT, int SRC> struct LoaderOf;
 template <int BT, int BKT> struct LoaderOf<BT, BKT, SRC_KC> { using type = LoadKC<BT, BKT>; };
 template <int BT, int BKT> struct LoaderOf<BT, BKT, SRC_RC> { using type = LoadRC<BT, BKT, false>; };
 template <int BT, int BKT> struct LoaderOf<BT, BKT, SRC_RC_FLAT> { using type = LoadRC<BT, BKT, true>; };
 template <int BT, int BKT> struct LoaderOf<BT, BKT, SRC_SC> { using type = LoadSC<BT, BKT>; };
+template <int BT, int BKT> struct LoaderOf<BT, BKT, SRC_SC_DTANH> { using type = LoadSC<BT, BKT, true>; };
 
 // -------------------------------------------------------------- epilogues
 enum Epi : int {
   EPI_LIN = 0,       // generic pointwise epilogue, row-major C
   EPI_SLAB = 1,      // split-K partial: raw accumulators to slab blockIdx.z
   EPI_CONV = 2,      // C = act(acc + bias[m]) in [sample][M][S]   (act: 0 none, 1 tanh)
-  EPI_DI = 3         // dZ = (acc + dj[b,m] a[n]) * (1 - I^2)
+  EPI_OUTER = 3      // C = acc + dj[b,m] a[n]   (dI' of the attention backward)
 };
 
 template <int BM, int BN, int BKT, int ASRC, int BSRC, int EPI>
@@ -348,7 +367,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams P) {
       const int m = m0 + tid;
       rowv[tid] = (EPI == EPI_CONV && m < P.M) ? P.bias[m] : 0.f;
     }
-    if (EPI == EPI_DI && staged)
+    if (EPI == EPI_OUTER && staged)
       for (int e = tid; e < nsamp * BM; e += 256) {
         const int sb = e / BM, r = e - sb * BM;
         uv[e] = (m0 + r < P.M) ? P.v1[(long)(b0 + sb) * P.M + m0 + r] : 0.f;
@@ -363,7 +382,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams P) {
       const long cb = (long)b * P.c_bs + s;
       const float* uvb = uv + (b - b0) * BM;
       float an = 0.f;
-      if (EPI == EPI_DI) an = P.v2[nn];
+      if (EPI == EPI_OUTER) an = P.v2[nn];
 #pragma unroll
       for (int i = 0; i < IM; ++i)
 #pragma unroll
@@ -378,8 +397,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams P) {
             if (ok) P.C[ci] = P.act ? tanh_fast(t) : t;
           } else {
             const float pvm = staged ? uvb[rl] : (m < P.M ? P.v1[(long)b * P.M + m] : 0.f);
-            const float y = P.I[ci];
-            if (ok) P.C[ci] = (v + pvm * an) * (1.f - y * y);
+            if (ok) P.C[ci] = v + pvm * an;
           }
         }
     }

@@ -48,10 +48,18 @@ template <int ASRC, int BSRC>
 static hipError_t lin_gemm(hipStream_t st, int M, int N, int K, const float* A, long lda,
                            const float* W, long ldw, float* C, long ldc, const LinOpts& o) {
   GemmParams P = lin_params(M, N, K, A, lda, W, ldw, C, ldc, o);
-  if ((long)M * N >= 128L * 128 * 256)
+  if ((long)M * N >= 128L * 128 * 256 && !o.defer_splits)
     return launch_gemm<128, 128, BK, ASRC, BSRC, EPI_LIN>(st, P, 1);
   P.nk = (K + BKS - 1) / BKS;
   const int s = skinny_splits(M, N, K, o);
+  if (o.defer_splits) {  // partials stay in the slab; the consumer kernel reduces them
+    if (!o.slab || (size_t)s * M * N > o.slab_floats) return hipErrorInvalidValue;
+    P.C = o.slab;
+    P.c_rs = N;
+    P.slab_stride = (long)M * N;
+    *o.defer_splits = s;
+    return launch_gemm<64, 64, BKS, ASRC, BSRC, EPI_SLAB>(st, P, s);
+  }
   if (s <= 1) return launch_gemm<64, 64, BKS, ASRC, BSRC, EPI_LIN>(st, P, 1);
   P.C = o.slab;
   P.c_rs = N;

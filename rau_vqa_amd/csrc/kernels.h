@@ -25,6 +25,9 @@ struct LinOpts {
   // workgroups (partials to slab, then one fused reduce + epilogue kernel)
   float* slab = nullptr;
   size_t slab_floats = 0;
+  // deferred reduction: leave the K-split partials in `slab` ([splits][M*N]) and
+  // report the split count; the consumer kernel (lstm_fwd / lstm_bwd) sums them
+  int* defer_splits = nullptr;
 };
 // C[M,N] = epi(A[M,K] * W[N,K]^T)      (Linear forward)
 hipError_t gemm_nt(hipStream_t st, int M, int N, int K, const float* A, long lda,
@@ -46,16 +49,16 @@ hipError_t conv_embed_fwd(hipStream_t st, int nB, int D, int S, int M, const flo
 // P[b,k,s] = sum_m Wp[k,m] I[b,m,s] + bp[k]   (hop-invariant half of SS:244-252)
 hipError_t conv_att_pre(hipStream_t st, int nB, int M, int S, int A, const float* I,
                         const float* Wp, const float* bp, float* P);
-// dZ[b,m,s] = (sum_k Wp[k,m] dS[b,k,s] + dj[b,m] a[b,s]) * (1 - I^2)
+// dI[b,m,s] = sum_k Wp[k,m] dS[b,k,s] + dj[b,m] a[b,s]   (gradient at i_embed's output)
 hipError_t conv_att_dgrad(hipStream_t st, int nB, int M, int S, int A, const float* dS,
-                          const float* Wp, const float* dj, const float* a, const float* I,
-                          float* dZ);
-// dWp[k,m] += sum_{b,s} dS[b,k,s] I[b,m,s]   and   dWi[m,d] += sum_{b,s} dZ[b,m,s] X'[b,d,s]
+                          const float* Wp, const float* dj, const float* a, float* dI);
+// dWp[k,m] += sum_{b,s} dS[b,k,s] I[b,m,s]   and, with dZ = dI (1 - I^2),
+// dWi[m,d] += sum_{b,s} dZ[b,m,s] X'[b,d,s]
 size_t conv_wgrad_slab_floats(int nB, int rowsA, int rowsB, int S);
 hipError_t conv_att_wgrad(hipStream_t st, int nB, int M, int S, int A, const float* dS,
                           const float* I, float* dWp, float* slab);
-hipError_t conv_embed_wgrad(hipStream_t st, int nB, int D, int S, int M, const float* dZ,
-                            const float* X, float* dWi, float* slab);
+hipError_t conv_embed_wgrad(hipStream_t st, int nB, int D, int S, int M, const float* dI,
+                            const float* I, const float* X, float* dWi, float* slab);
 
 // --------------------------------------------------------- pointwise (kernels.hip)
 enum GateOrder { GATES_ATT = 0 /* i g f o, ATTLSTM.lua:12-19 */,
@@ -65,16 +68,19 @@ hipError_t fill_masks(hipStream_t st, uint64_t seed, uint32_t site, uint32_t ste
                       size_t n, uint32_t* bits);
 hipError_t embed_fwd(hipStream_t st, int rows, int E, const float* emb, const int32_t* tokens,
                      const uint32_t* mask, float mscale, float* we);
-// in place on g4: pre-activations -> activated gates; c = f c_prev + i g; h = o tanh c
+// in place on g4: pre-activations (+ sum of `nsplit` split-K partials [nB,4R] in `slab`)
+// -> activated gates; c = f c_prev + i g; h = o tanh c
 hipError_t lstm_fwd(hipStream_t st, int order, int nB, int R, float* g4, const float* c_prev,
                     long cp_rs, float* c, long c_rs, float* h, long h_rs, float* tanhc,
-                    float* drop_out, const uint32_t* mask, size_t mask_e0, float mscale);
-// dsum from (dh [+dh2], dc_next); optional row replacement by dq rows where lens[b]==t
+                    float* drop_out, const uint32_t* mask, size_t mask_e0, float mscale,
+                    const float* slab = nullptr, int nsplit = 0);
+// dsum from (dh [+dh2], dc_next), dh optionally given as `nsplit` split-K partials [nB,R]
+// in `slab`; optional row replacement by dq rows where lens[b]==t
 hipError_t lstm_bwd(hipStream_t st, int order, int nB, int R, const float* gates,
                     const float* c_prev, long cp_rs, const float* tanhc, const float* dh,
                     long dh_rs, const float* dh2, const float* dc_next, float* dsum,
                     float* dc_prev, const int32_t* lens, int t, const float* dq_c,
-                    const float* dq_h, long dq_rs);
+                    const float* dq_h, long dq_rs, const float* slab = nullptr, int nsplit = 0);
 // One workgroup per sample: T = tanh(P + u[b,:,None]) (attbycontent, SS:250),
 // e = ws . T + bs (SS:251), a = softmax(e + zm) (attbymemory, SS:288-289),
 // jv = qf + sum_s I a (attselect SS:254-263 + first CAddTable SS:270).
@@ -89,8 +95,8 @@ hipError_t att_bwd_fused(hipStream_t st, int nB, int M, int A, int S, const floa
 // xd[h][i] = X[i] * keep(h, i) * scale for h < H, i < per_hop (feature-map dropout, SS:239)
 hipError_t dropout_features(hipStream_t st, int H, size_t per_hop, const float* X,
                             const uint32_t* mask, float mscale, float* xd);
-// rs[row] = sum_s X[row, s]
-hipError_t row_sums(hipStream_t st, int rows, int S, const float* X, float* rs);
+// rs[row] = sum_s X[row, s] * (1 - Y[row, s]^2)   (Y = nullptr: plain row sums)
+hipError_t row_sums(hipStream_t st, int rows, int S, const float* X, const float* Y, float* rs);
 // dst[n] += sum_rows X[row*ld + n]   (two-stage, deterministic; tmp >= 32*N floats)
 hipError_t colsum_acc(hipStream_t st, int rows, int N, const float* X, long ld, float* dst,
                       float* tmp);

@@ -120,7 +120,8 @@ __global__ void k_lstm_fwd(int nB, int R, float* __restrict__ g4,
                            const float* __restrict__ c_prev, long cp_rs, float* __restrict__ c,
                            long c_rs, float* __restrict__ h, long h_rs,
                            float* __restrict__ tanhc, float* __restrict__ drop_out,
-                           const uint32_t* __restrict__ mask, size_t mask_e0, float mscale) {
+                           const uint32_t* __restrict__ mask, size_t mask_e0, float mscale,
+                           const float* __restrict__ slab, int nsplit) {
   RAU_CHAIN_PRIO();
   using GS = GateSlots<ORDER>;
   const size_t n = (size_t)nB * R;
@@ -128,10 +129,19 @@ __global__ void k_lstm_fwd(int nB, int R, float* __restrict__ g4,
        i += (size_t)gridDim.x * blockDim.x) {
     const int b = (int)(i / R), r = (int)(i - (size_t)b * R);
     float* g = g4 + (size_t)b * 4 * R;
-    const float gi = sigmoidf_(g[GS::I * R + r]);
-    const float gf = sigmoidf_(g[GS::F * R + r]);
-    const float go = sigmoidf_(g[GS::O * R + r]);
-    const float gg = tanh_fast(g[GS::G * R + r]);
+    float pi = g[GS::I * R + r], pf = g[GS::F * R + r], po = g[GS::O * R + r],
+          pg = g[GS::G * R + r];
+    for (int s = 0; s < nsplit; ++s) {  // split-K partials of h_prev W^T, fixed order
+      const float* sl = slab + ((size_t)s * nB + b) * 4 * R;
+      pi += sl[GS::I * R + r];
+      pf += sl[GS::F * R + r];
+      po += sl[GS::O * R + r];
+      pg += sl[GS::G * R + r];
+    }
+    const float gi = sigmoidf_(pi);
+    const float gf = sigmoidf_(pf);
+    const float go = sigmoidf_(po);
+    const float gg = tanh_fast(pg);
     g[GS::I * R + r] = gi;
     g[GS::F * R + r] = gf;
     g[GS::O * R + r] = go;
@@ -151,14 +161,15 @@ __global__ void k_lstm_fwd(int nB, int R, float* __restrict__ g4,
 }
 hipError_t lstm_fwd(hipStream_t st, int order, int nB, int R, float* g4, const float* c_prev,
                     long cp_rs, float* c, long c_rs, float* h, long h_rs, float* tanhc,
-                    float* drop_out, const uint32_t* mask, size_t mask_e0, float mscale) {
+                    float* drop_out, const uint32_t* mask, size_t mask_e0, float mscale,
+                    const float* slab, int nsplit) {
   const dim3 g(grid_for((size_t)nB * R)), b(256);
   if (order == GATES_ATT)
     hipLaunchKernelGGL(k_lstm_fwd<GATES_ATT>, g, b, 0, st, nB, R, g4, c_prev, cp_rs, c, c_rs, h,
-                       h_rs, tanhc, drop_out, mask, mask_e0, mscale);
+                       h_rs, tanhc, drop_out, mask, mask_e0, mscale, slab, nsplit);
   else
     hipLaunchKernelGGL(k_lstm_fwd<GATES_DEEP>, g, b, 0, st, nB, R, g4, c_prev, cp_rs, c, c_rs, h,
-                       h_rs, tanhc, drop_out, mask, mask_e0, mscale);
+                       h_rs, tanhc, drop_out, mask, mask_e0, mscale, slab, nsplit);
   return hipGetLastError();
 }
 
@@ -170,7 +181,7 @@ __global__ void k_lstm_bwd(int nB, int R, const float* __restrict__ gates,
                            const float* __restrict__ dc_next, float* __restrict__ dsum,
                            float* __restrict__ dc_prev, const int32_t* __restrict__ lens, int t,
                            const float* __restrict__ dq_c, const float* __restrict__ dq_h,
-                           long dq_rs) {
+                           long dq_rs, const float* __restrict__ slab, int nsplit) {
   RAU_CHAIN_PRIO();
   using GS = GateSlots<ORDER>;
   const size_t n = (size_t)nB * R;
@@ -183,6 +194,7 @@ __global__ void k_lstm_bwd(int nB, int R, const float* __restrict__ gates,
       dcv = dq_c[(size_t)b * dq_rs + r];
     } else {
       dhv = dh ? dh[(size_t)b * dh_rs + r] : 0.f;
+      for (int s = 0; s < nsplit; ++s) dhv += slab[((size_t)s * nB + b) * R + r];
       dcv = dc_next ? dc_next[i] : 0.f;
     }
     if (dh2) dhv += dh2[i];
@@ -204,14 +216,14 @@ hipError_t lstm_bwd(hipStream_t st, int order, int nB, int R, const float* gates
                     const float* c_prev, long cp_rs, const float* tanhc, const float* dh,
                     long dh_rs, const float* dh2, const float* dc_next, float* dsum,
                     float* dc_prev, const int32_t* lens, int t, const float* dq_c,
-                    const float* dq_h, long dq_rs) {
+                    const float* dq_h, long dq_rs, const float* slab, int nsplit) {
   const dim3 g(grid_for((size_t)nB * R)), b(256);
   if (order == GATES_ATT)
     hipLaunchKernelGGL(k_lstm_bwd<GATES_ATT>, g, b, 0, st, nB, R, gates, c_prev, cp_rs, tanhc,
-                       dh, dh_rs, dh2, dc_next, dsum, dc_prev, lens, t, dq_c, dq_h, dq_rs);
+                       dh, dh_rs, dh2, dc_next, dsum, dc_prev, lens, t, dq_c, dq_h, dq_rs, slab, nsplit);
   else
     hipLaunchKernelGGL(k_lstm_bwd<GATES_DEEP>, g, b, 0, st, nB, R, gates, c_prev, cp_rs, tanhc,
-                       dh, dh_rs, dh2, dc_next, dsum, dc_prev, lens, t, dq_c, dq_h, dq_rs);
+                       dh, dh_rs, dh2, dc_next, dsum, dc_prev, lens, t, dq_c, dq_h, dq_rs, slab, nsplit);
   return hipGetLastError();
 }
 
@@ -433,22 +445,32 @@ hipError_t dropout_features(hipStream_t st, int H, size_t per_hop, const float* 
   return hipGetLastError();
 }
 
-__global__ void k_row_sums(int rows, int S, const float* __restrict__ X, float* __restrict__ rs) {
+__global__ void k_row_sums(int rows, int S, const float* __restrict__ X,
+                           const float* __restrict__ Y, float* __restrict__ rs) {
   const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (row >= rows) return;
   const int l = threadIdx.x & 63;
   const int S4 = S >> 2;
   const float4* xr = reinterpret_cast<const float4*>(X + (size_t)row * S);
   float acc = 0.f;
-  for (int q = l; q < S4; q += 64) {
-    const float4 x = xr[q];
-    acc += (x.x + x.y) + (x.z + x.w);
+  if (Y) {
+    const float4* yr = reinterpret_cast<const float4*>(Y + (size_t)row * S);
+    for (int q = l; q < S4; q += 64) {
+      const float4 x = xr[q], y = yr[q];
+      acc += (x.x * (1.f - y.x * y.x) + x.y * (1.f - y.y * y.y)) +
+             (x.z * (1.f - y.z * y.z) + x.w * (1.f - y.w * y.w));
+    }
+  } else {
+    for (int q = l; q < S4; q += 64) {
+      const float4 x = xr[q];
+      acc += (x.x + x.y) + (x.z + x.w);
+    }
   }
   acc = wave_sum(acc);
   if (l == 0) rs[row] = acc;
 }
-hipError_t row_sums(hipStream_t st, int rows, int S, const float* X, float* rs) {
-  hipLaunchKernelGGL(k_row_sums, dim3((rows + 3) / 4), dim3(256), 0, st, rows, S, X, rs);
+hipError_t row_sums(hipStream_t st, int rows, int S, const float* X, const float* Y, float* rs) {
+  hipLaunchKernelGGL(k_row_sums, dim3((rows + 3) / 4), dim3(256), 0, st, rows, S, X, Y, rs);
   return hipGetLastError();
 }
 

@@ -131,6 +131,7 @@ struct rau_ctx {
       *dl, *lossrow, *dopred, *losses_d, *hopw_d;
   int32_t* argmax_d;
   // backward temporaries
+  // dZ holds dI (gradient at i_embed's OUTPUT); the tanh derivative is applied by its consumers
   float *dpre, *dhn, *dg4, *dcn[2], *dhp[2], *dj, *da_lin, *dz, *du, *dwsp, *dZ, *rsum,
       *dqt, *dQD, *dq, *slab, *slab2, *coltmp, *coltmp2, *tmpS;
   float *dG1, *dG2, *dX2, *dwe, *edc[2][2], *edh[2];
@@ -782,9 +783,10 @@ int rau_forward(rau_ctx* ctx) {
           gemm_nt(st, rows, 4 * Rq, kin, xin, kin, ctx->i2h[L].W, kin, G, 4 * Rq, o));
       for (int t = 1; t <= TL; ++t) {
         float* Gt = G + (size_t)(t - 1) * B * 4 * Rq;
+        int nsp = 0;  // split-K partials of h_{t-1} W_h2h^T, summed inside lstm_fwd
         if (t > 1) {
           LINOPTS(oa);
-          oa.accumulate = 1;
+          oa.defer_splits = &nsp;
           RUN("enc_h2h_gemm", gflop(B, 4 * Rq, Rq), 0,
               gemm_nt(st, B, 4 * Rq, Rq, hs + (size_t)(t - 1) * BRq, Rq, ctx->h2h[L].W, Rq, Gt,
                       4 * Rq, oa));
@@ -793,7 +795,7 @@ int rau_forward(rau_ctx* ctx) {
             lstm_fwd(st, GATES_DEEP, B, Rq, Gt, cs + (size_t)(t - 1) * BRq, Rq,
                      cs + (size_t)t * BRq, Rq, hs + (size_t)t * BRq, Rq,
                      tcs + (size_t)(t - 1) * BRq, L == 0 ? ctx->x2 + (size_t)(t - 1) * BRq : nullptr,
-                     m_rnn, (size_t)(t - 1) * BRq, sc(RAU_MASK_RNN)));
+                     m_rnn, (size_t)(t - 1) * BRq, sc(RAU_MASK_RNN), ctx->slab, nsp));
       }
     }
   }
@@ -863,15 +865,16 @@ int rau_forward(rau_ctx* ctx) {
       o.bias2 = ctx->lstm_h2h.b;
       RUN("small_gemm", gflop(B, 4 * R, M), 0,
           gemm_nt(st, B, 4 * R, M, jh, M, ctx->lstm_i2h.W, M, g4, 4 * R, o));
+      int nsp = 0;
       LINOPTS(oa);
-      oa.accumulate = 1;
+      oa.defer_splits = &nsp;
       RUN("small_gemm", gflop(B, 4 * R, R), 0,
           gemm_nt(st, B, 4 * R, R, hp, R, ctx->lstm_h2h.W, R, g4, 4 * R, oa));
+      RUN("lstm_fwd", 0, BR_ * 4.0 * 10,
+          lstm_fwd(st, GATES_ATT, B, R, g4, cp, R, ctx->cc + (size_t)(h + 1) * BR_, R,
+                   ctx->hh + (size_t)(h + 1) * BR_, R, ctx->tc + (size_t)h * BR_, nullptr, nullptr,
+                   0, 1.f, ctx->slab, nsp));
     }
-    RUN("lstm_fwd", 0, BR_ * 4.0 * 10,
-        lstm_fwd(st, GATES_ATT, B, R, g4, cp, R, ctx->cc + (size_t)(h + 1) * BR_, R,
-                 ctx->hh + (size_t)(h + 1) * BR_, R, ctx->tc + (size_t)h * BR_, nullptr, nullptr, 0,
-                 1.f));
     {
       LINOPTS(o);
       o.bias = ctx->lstm_out.b;
@@ -952,15 +955,15 @@ int rau_backward(rau_ctx* ctx, const float* hop_w) {
       RUN("small_gemm", gflop(B, M, K), 0,
           gemm_nn(st, B, M, K, ctx->dl + (size_t)h * B * K, K, ctx->cls.W, M, dpre, M, o));
     }
-    {  // dhn = dpre Wo + dh_next
+    {  // dhn = dpre Wo + dh_next, the K-split partials of dpre Wo summed inside lstm_bwd
+      int nsp = 0;
       LINOPTS(o);
-      o.addend = dh_next;
-      o.add_rs = R;
+      o.defer_splits = &nsp;
       RUN("small_gemm", gflop(B, R, M), 0, gemm_nn(st, B, R, M, dpre, M, ctx->lstm_out.W, R, ctx->dhn, R, o));
+      RUN("lstm_bwd", 0, BR_ * 4.0 * 12,
+          lstm_bwd(st, GATES_ATT, B, R, g4, cp, R, ctx->tc + (size_t)h * BR_, nullptr, R, dh_next,
+                   dc_next, dg4, dc_out, nullptr, 0, nullptr, nullptr, 0, ctx->slab, nsp));
     }
-    RUN("lstm_bwd", 0, BR_ * 4.0 * 12,
-        lstm_bwd(st, GATES_ATT, B, R, g4, cp, R, ctx->tc + (size_t)h * BR_, ctx->dhn, R, nullptr,
-                 dc_next, dg4, dc_out, nullptr, 0, nullptr, nullptr, 0));
     {  // dj = dpre + dg Wx ; dh_prev = dg Wr
       LINOPTS(o);
       o.addend = dpre;
@@ -1012,26 +1015,26 @@ int rau_backward(rau_ctx* ctx, const float* hop_w) {
         RUNS(sb, "conv_att_dgrad", gflop(M, (double)nH * S, A),
              ((double)nH * A * S + 2.0 * nH * M * S) * 4,
              conv_att_dgrad(sb, nH, M, S, A, ctx->T + hb * A * S, ctx->att_i.W, ctx->dj + hb * M,
-                            ctx->a + hb * S, ctx->I + hb * M * S, ctx->dZ + hb * M * S));
+                            ctx->a + hb * S, ctx->dZ + hb * M * S));
         RUNS(sb, "conv_att_wgrad", gflop(A, M, (double)nH * S),
              ((double)nH * A * S + (double)nH * M * S) * 4,
              conv_att_wgrad(sb, nH, M, S, A, ctx->T + hb * A * S, ctx->I + hb * M * S,
                             ctx->att_i.dW, ctx->slab2));
         RUNS(sb, "conv_embed_wgrad", gflop(M, D, (double)nH * S),
              ((double)nH * M * S + (double)nH * D * S) * 4,
-             conv_embed_wgrad(sb, nH, D, S, M, ctx->dZ + hb * M * S, ctx->xd + hb * D * S,
-                              ctx->i_embed.dW, ctx->slab2));
+             conv_embed_wgrad(sb, nH, D, S, M, ctx->dZ + hb * M * S, ctx->I + hb * M * S,
+                              ctx->xd + hb * D * S, ctx->i_embed.dW, ctx->slab2));
       } else {
         for (int hh2 = 0; hh2 < H; ++hh2) {  // evaluate mode: I (and X) shared by all hops
           float* Th2 = ctx->T + (size_t)hh2 * B * A * S;
           float* dZh = ctx->dZ + (size_t)hh2 * BM_ * S;
           RUNS(sb, "conv_att_dgrad", gflop(M, (double)B * S, A), ((double)B * A * S + 2.0 * BM_ * S) * 4,
                conv_att_dgrad(sb, B, M, S, A, Th2, ctx->att_i.W, ctx->dj + (size_t)hh2 * BM_,
-                              ctx->a + (size_t)hh2 * BS_, ctx->I, dZh));
+                              ctx->a + (size_t)hh2 * BS_, dZh));
           RUNS(sb, "conv_att_wgrad", gflop(A, M, (double)B * S), ((double)B * A * S + BM_ * S) * 4,
                conv_att_wgrad(sb, B, M, S, A, Th2, ctx->I, ctx->att_i.dW, ctx->slab2));
           RUNS(sb, "conv_embed_wgrad", gflop(M, D, (double)B * S), (BM_ * S + (double)B * D * S) * 4,
-               conv_embed_wgrad(sb, B, D, S, M, dZh, ctx->feats, ctx->i_embed.dW, ctx->slab2));
+               conv_embed_wgrad(sb, B, D, S, M, dZh, ctx->I, ctx->feats, ctx->i_embed.dW, ctx->slab2));
         }
       }
     }
@@ -1046,7 +1049,16 @@ int rau_backward(rau_ctx* ctx, const float* hop_w) {
   // bulk stream tail: i_embed bias gradient over all hops, then the join event
   {
     hipStream_t sb = ctx->st2;
-    RUNS(sb, "row_sums", 0, (double)H * BM_ * S * 4.0, row_sums(sb, H * B * M, S, ctx->dZ, ctx->rsum));
+    // i_embed bias gradient: sum_s dI (1 - I^2) per (hop, sample, channel) row
+    if (!ctx->I_shared) {
+      RUNS(sb, "row_sums", 0, (double)H * BM_ * S * 8.0,
+           row_sums(sb, H * B * M, S, ctx->dZ, ctx->I, ctx->rsum));
+    } else {
+      for (int h2 = 0; h2 < H; ++h2)
+        RUNS(sb, "row_sums", 0, BM_ * S * 8.0,
+             row_sums(sb, B * M, S, ctx->dZ + (size_t)h2 * BM_ * S, ctx->I,
+                      ctx->rsum + (size_t)h2 * BM_));
+    }
     RUNS(sb, "colsum", 0, (double)H * B * M * 4,
          colsum_acc(sb, H * B, M, ctx->rsum, M, ctx->i_embed.db, ctx->coltmp2));
     HIPC(hipEventRecord(ctx->evD, sb));
@@ -1087,22 +1099,24 @@ int rau_backward(rau_ctx* ctx, const float* hop_w) {
       const float* tcs = L == 0 ? ctx->tc1 : ctx->tc2;
       float* dG = L == 0 ? ctx->dG1 : ctx->dG2;
       const float* dc_n = nullptr;
-      const float* dh_rec = nullptr;
+      int nsp = 0;  // split-K partials of dG_{t+1} W_h2h (= dh_t from the recurrence)
       for (int t = TL; t >= 1; --t) {
         float* dGt = dG + (size_t)(t - 1) * B * 4 * Rq;
         float* dc_o = ctx->edc[L][t & 1];
         RUN("lstm_bwd", 0, BRq * 4.0 * 12,
             lstm_bwd(st, GATES_DEEP, B, Rq, G + (size_t)(t - 1) * B * 4 * Rq,
-                     cs + (size_t)(t - 1) * BRq, Rq, tcs + (size_t)(t - 1) * BRq, dh_rec, Rq,
+                     cs + (size_t)(t - 1) * BRq, Rq, tcs + (size_t)(t - 1) * BRq, nullptr, Rq,
                      L == 0 ? ctx->dX2 + (size_t)(t - 1) * BRq : nullptr, dc_n, dGt, dc_o,
-                     ctx->lens_d, t, ctx->dq + 2 * L * Rq, ctx->dq + (2 * L + 1) * Rq, Q));
+                     ctx->lens_d, t, ctx->dq + 2 * L * Rq, ctx->dq + (2 * L + 1) * Rq, Q, ctx->slab,
+                     nsp));
+        nsp = 0;
         if (t > 1) {
           LINOPTS(o);
+          o.defer_splits = &nsp;
           RUN("enc_h2h_dgrad", gflop(B, Rq, 4 * Rq), 0,
               gemm_nn(st, B, Rq, 4 * Rq, dGt, 4 * Rq, ctx->h2h[L].W, Rq, ctx->edh[L], Rq, o));
         }
         dc_n = dc_o;
-        dh_rec = ctx->edh[L];
       }
       if (L == 1) {  // gradient into layer 1's output through the inter-layer dropout
         LINOPTS(o);

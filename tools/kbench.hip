@@ -103,7 +103,7 @@ int main(int argc, char** argv) {
     CK(fill_masks(st, 1, 3, 0, 0.5f, (size_t)H * B * D * S, m8));
     report("dropout_features x8", timeit(st, 10, [&] { return dropout_features(st, H, (size_t)B * D * S, X, m8, 2.f, xd); }), 0);
     report("conv_embed_fwd x8 hops", timeit(st, 5, [&] { return conv_embed_fwd(st, H * B, D, S, M, xd, Wi, bi, I8); }), 2.0 * M * NS * D * H);
-    report("conv_embed_wgrad x8 hops", timeit(st, 5, [&] { return conv_embed_wgrad(st, H * B, D, S, M, I8, xd, dWi, slab); }), 2.0 * M * NS * D * H);
+    report("conv_embed_wgrad x8 hops", timeit(st, 5, [&] { return conv_embed_wgrad(st, H * B, D, S, M, I8, I8, xd, dWi, slab); }), 2.0 * M * NS * D * H);
     CK(hipFree(xd)); CK(hipFree(I8)); CK(hipFree(m8));
   }
   report("conv_att_pre", timeit(st, 20, [&] { return conv_att_pre(st, B, M, S, A, I, Wp, bp, T); }), 2.0 * A * NS * M);
@@ -111,9 +111,9 @@ int main(int argc, char** argv) {
     report("att_fwd_fused", timeit(st, 20, [&] { return att_fwd_fused(st, B, M, A, S, T, u, ws, bp, dz, I, dj, T, a, jv); }), 0);
     float* du; CK(hipMalloc(&du, (size_t)B * A * 8));
     report("att_bwd_fused", timeit(st, 20, [&] { return att_bwd_fused(st, B, M, A, S, I, dj, a, dz, ws, T, epart, du, du + B * A); }), 0); }
-  report("conv_att_dgrad", timeit(st, 20, [&] { return conv_att_dgrad(st, B, M, S, A, T, Wp, dj, a, I, dZ); }), 2.0 * A * NS * M);
+  report("conv_att_dgrad", timeit(st, 20, [&] { return conv_att_dgrad(st, B, M, S, A, T, Wp, dj, a, dZ); }), 2.0 * A * NS * M);
   report("conv_att_wgrad", timeit(st, 20, [&] { return conv_att_wgrad(st, B, M, S, A, T, I, dWp, slab); }), 2.0 * A * NS * M);
-  report("conv_embed_wgrad", timeit(st, 20, [&] { return conv_embed_wgrad(st, B, D, S, M, dZ, X, dWi, slab); }), 2.0 * M * NS * D);
+  report("conv_embed_wgrad", timeit(st, 20, [&] { return conv_embed_wgrad(st, B, D, S, M, dZ, I, X, dWi, slab); }), 2.0 * M * NS * D);
   // small GEMMs
   float* h = dev_rand((size_t)B * 2048, 0.5f), *W = dev_rand((size_t)2048 * 2048, 0.08f);
   float* C; CK(hipMalloc(&C, (size_t)8 * B * 2048 * 4));
