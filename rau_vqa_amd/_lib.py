@@ -10,7 +10,8 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librau.so")
+# RAU_LIB overrides the library path (A/B runs of two builds on one GPU box)
+LIB_PATH = os.environ.get("RAU_LIB") or os.path.join(_HERE, "librau.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 GROUP_EMBED, GROUP_RNN, GROUP_MULT = 0, 1, 2
