@@ -165,9 +165,16 @@ def main():
         avg_ms = dom["ms"] / dom["launches"]
         flops_per_launch = dom["flops"] / dom["launches"]
         achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12
+        # HBM bytes per launch of the dominant kernel from the committed PMC passes
+        # (profiles/r01_pmc_conv_embed_fwd.json: separate FETCH_SIZE / WRITE_SIZE runs,
+        # FETCH_SIZE doubled per the gfx950 correction); only valid for the default shape
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "r01_pmc_conv_embed_fwd.json")
+        if os.path.exists(pmc) and args.batch == 256 and args.D == 512:
+            traffic = json.load(open(pmc))["hbm_bytes_per_launch"]
         extra["roofline"] = {"bound": "mfma", "achieved": achieved, "peak": MFMA_F32_PEAK_TFLOPS,
                              "unit": "TFLOP/s", "frac": achieved / MFMA_F32_PEAK_TFLOPS,
-                             "traffic": None, "kernel": DOMINANT,
+                             "traffic": traffic, "kernel": DOMINANT,
                              "avg_launch_ms": avg_ms,
                              "flops_per_launch": flops_per_launch}
         tot = sum(v["ms"] for v in prof.values())

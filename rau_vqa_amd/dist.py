@@ -46,16 +46,15 @@ def allreduce_average(tensors, group=None):
     world = dist.get_world_size(group)
     if world == 1:
         return
+    avg = dist.get_backend(group) == "nccl"   # RCCL has AVG; gloo only SUM
     works = []
     for t in sorted(tensors, key=lambda x: -x.numel()):
-        if t.is_cuda:
-            works.append(dist.all_reduce(t, op=dist.ReduceOp.AVG, group=group, async_op=True))
-        else:
-            works.append(dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group, async_op=True))
+        op = dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM
+        works.append(dist.all_reduce(t, op=op, group=group, async_op=True))
     for w in works:
         w.wait()
-    for t in tensors:
-        if not t.is_cuda:
+    if not avg:
+        for t in tensors:
             t.mul_(1.0 / world)
 
 
