@@ -9,36 +9,38 @@ namespace rau {
 constexpr int BK = 32;
 
 // I[b,m,s] = tanh(sum_d Wi[m,d] X'[b,d,s] + bi[m])  -- reference SS:238-242.
-// GEMM: M rows = multfeat, N cols = nB*S, K = D.  A = Wi [M][D] (k contiguous),
-// B = X' [b][d][s] (position contiguous; dropout already applied by
-// dropout_features).  nB may be H*B: all hops in one launch.
+// GEMM: M rows = multfeat, N cols = nB*S, K = D.  A = Wi^T [D][M] (the weight
+// transposed once per step by transpose2d: a row-contiguous A operand stages with
+// 16-byte LDS writes and full-line global reads, ~10% faster than the k-contiguous
+// loader), B = X' [b][d][s] (position contiguous; dropout already applied by
+// dropout_features).  nB may be a group of hops.
 hipError_t conv_embed_fwd(hipStream_t st, int nB, int D, int S, int M, const float* X,
-                          const float* Wi, const float* bi, float* I) {
+                          const float* WiT, const float* bi, float* I) {
   GemmParams P{};
   P.M = M; P.N = nB * S; P.K = D; P.nk = (D + BK - 1) / BK;
-  P.A = Wi; P.a_rs = D;
+  P.A = WiT; P.a_rs = M;
   P.B = X; P.b_rs = S; P.b_bs = (long)D * S;
   P.S = S;
   P.C = I; P.c_bs = (long)M * S;
   P.bias = bi;
   P.act = 1;
-  return launch_gemm<128, 128, BK, SRC_KC, SRC_RC_FLAT, EPI_CONV>(st, P, 1);
+  return launch_gemm<128, 128, BK, SRC_RC, SRC_RC_FLAT, EPI_CONV>(st, P, 1);
 }
 
 // P[b,k,s] = sum_m Wp[k,m] I[b,m,s] + bp[k]: the hop-invariant part of attbycontent's
 // pre-activation (reference SS:247-249); nB may be H*B.  The per-hop part
 // (+ u[b,k], tanh, score, softmax) is att_fwd_fused in kernels.hip.
 hipError_t conv_att_pre(hipStream_t st, int nB, int M, int S, int A, const float* I,
-                        const float* Wp, const float* bp, float* Pout) {
+                        const float* WpT, const float* bp, float* Pout) {
   GemmParams P{};
   P.M = A; P.N = nB * S; P.K = M; P.nk = (M + BK - 1) / BK;
-  P.A = Wp; P.a_rs = M;
+  P.A = WpT; P.a_rs = A;                // Wp^T [M][A]: reduction-major
   P.B = I; P.b_rs = S; P.b_bs = (long)M * S;
   P.S = S;
   P.C = Pout; P.c_bs = (long)A * S;
   P.bias = bp;
   P.act = 0;
-  return launch_gemm<128, 128, BK, SRC_KC, SRC_RC_FLAT, EPI_CONV>(st, P, 1);
+  return launch_gemm<128, 128, BK, SRC_RC, SRC_RC_FLAT, EPI_CONV>(st, P, 1);
 }
 
 // backward of attbycontent + attselect into the gradient w.r.t. i_embed's OUTPUT:

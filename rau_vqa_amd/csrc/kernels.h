@@ -45,10 +45,13 @@ hipError_t gemm_tn_acc(hipStream_t st, int M, int N, int K, const float* A, long
 // I[b,m,s] = tanh(sum_d Wi[m,d] * X'[b,d,s] + bi[m])   (reference SS:238-242; X' is the
 // feature map with dropout already applied, see dropout_features; nB may be H*B)
 hipError_t conv_embed_fwd(hipStream_t st, int nB, int D, int S, int M, const float* X,
-                          const float* Wi, const float* bi, float* I);
+                          const float* WiT /* [D][M] */, const float* bi, float* I);
 // P[b,k,s] = sum_m Wp[k,m] I[b,m,s] + bp[k]   (hop-invariant half of SS:244-252)
 hipError_t conv_att_pre(hipStream_t st, int nB, int M, int S, int A, const float* I,
-                        const float* Wp, const float* bp, float* P);
+                        const float* WpT /* [M][A] */, const float* bp, float* P);
+// out[c][r] = in[r][c]  (rows x cols -> cols x rows); used once per step on the two
+// 1x1-conv weights so the forward conv GEMMs get a row-contiguous A operand
+hipError_t transpose2d(hipStream_t st, int rows, int cols, const float* in, float* out);
 // dI[b,m,s] = sum_k Wp[k,m] dS[b,k,s] + dj[b,m] a[b,s]   (gradient at i_embed's output)
 hipError_t conv_att_dgrad(hipStream_t st, int nB, int M, int S, int A, const float* dS,
                           const float* Wp, const float* dj, const float* a, float* dI);

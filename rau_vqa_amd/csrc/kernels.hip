@@ -418,6 +418,24 @@ hipError_t att_bwd_fused(hipStream_t st, int nB, int M, int A, int S, const floa
   return hipGetLastError();
 }
 
+// 32x32 LDS-tiled transpose (bulk stream; no chain priority)
+__global__ void k_transpose2d(int rows, int cols, const float* __restrict__ in,
+                              float* __restrict__ out) {
+  __shared__ float tile[32][33];
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 256 threads: 32 x 8
+  for (int j = ty; j < 32; j += 8)
+    if (r0 + j < rows && c0 + tx < cols) tile[j][tx] = in[(size_t)(r0 + j) * cols + c0 + tx];
+  __syncthreads();
+  for (int j = ty; j < 32; j += 8)
+    if (c0 + j < cols && r0 + tx < rows) out[(size_t)(c0 + j) * rows + r0 + tx] = tile[tx][j];
+}
+hipError_t transpose2d(hipStream_t st, int rows, int cols, const float* in, float* out) {
+  hipLaunchKernelGGL(k_transpose2d, dim3((cols + 31) / 32, (rows + 31) / 32), dim3(256), 0, st,
+                     rows, cols, in, out);
+  return hipGetLastError();
+}
+
 // feature-map dropout for every hop in one pass (reference SS:239, one mask per clone)
 __global__ void k_dropout_features(int H, size_t per4, const float4* __restrict__ X,
                                    const uint32_t* __restrict__ mask, float mscale,

@@ -126,6 +126,7 @@ struct rau_ctx {
   // RAU activations
   float *xd;          // [H][B][D][S] feature map after per-hop dropout (train mode)
   bool I_shared = false;  // evaluate mode: i_embed output is hop-invariant, computed once
+  float *WiT, *WpT;   // i_embed / ifeatproj weights transposed ([D][M], [M][A]), refreshed per forward
   float *P0;          // [B][A][S] hop-invariant attention pre-activation (evaluate mode)
   float *qd, *Yq, *qf, *I, *T, *u, *zm, *a, *jv, *j, *g4, *cc, *hh, *tc, *mf, *logits,
       *dl, *lossrow, *dopred, *losses_d, *hopw_d;
@@ -421,6 +422,8 @@ int rau_create(const rau_config* cfg, rau_ctx** out) {
   CK(dalloc(ctx, &ctx->T, HB * A * S));
   CK(dalloc(ctx, &ctx->u, (size_t)B * A));
   CK(dalloc(ctx, &ctx->P0, (size_t)B * A * S));
+  CK(dalloc(ctx, &ctx->WiT, (size_t)M * D));
+  CK(dalloc(ctx, &ctx->WpT, (size_t)A * M));
   CK(dalloc(ctx, &ctx->zm, (size_t)B * S));
   CK(dalloc(ctx, &ctx->a, HB * S));
   CK(dalloc(ctx, &ctx->jv, (size_t)B * M));
@@ -743,6 +746,8 @@ int rau_forward(rau_ctx* ctx) {
     hipStream_t sb = ctx->st2;
     HIPC(hipEventRecord(ctx->evA, st));
     HIPC(hipStreamWaitEvent(sb, ctx->evA, 0));
+    RUNS(sb, "transpose", 0, (double)M * D * 8, transpose2d(sb, M, D, ctx->i_embed.W, ctx->WiT));
+    RUNS(sb, "transpose", 0, (double)A * M * 8, transpose2d(sb, A, M, ctx->att_i.W, ctx->WpT));
     if (m_x)
       RUNS(sb, "dropout_features", 0, (double)(H + 1) * B * D * S * 4,
            dropout_features(sb, H, (size_t)B * D * S, ctx->feats, m_x, sc(RAU_MASK_X), ctx->xd));
@@ -754,10 +759,10 @@ int rau_forward(rau_ctx* ctx) {
       float* Pg = ctx->I_shared ? ctx->P0 : ctx->T + hb * A * S;
       RUNS(sb, "conv_embed_fwd", gflop(M, (double)nBI * S, D),
            ((double)nBI * D * S + (double)nBI * M * S) * 4,
-           conv_embed_fwd(sb, nBI, D, S, M, xin, ctx->i_embed.W, ctx->i_embed.b, Ig));
+           conv_embed_fwd(sb, nBI, D, S, M, xin, ctx->WiT, ctx->i_embed.b, Ig));
       RUNS(sb, "conv_att_pre", gflop(A, (double)nBI * S, M),
            ((double)nBI * M * S + (double)nBI * A * S) * 4,
-           conv_att_pre(sb, nBI, M, S, A, Ig, ctx->att_i.W, ctx->att_i.b, Pg));
+           conv_att_pre(sb, nBI, M, S, A, Ig, ctx->WpT, ctx->att_i.b, Pg));
       HIPC(hipEventRecord(ctx->evF[h0], sb));
     }
   }
