@@ -13,6 +13,8 @@
 // masked, or computed on the fly), "Epilogue" classes define what happens to
 // the accumulators.  Numerics: exact f32 (bitwise a k-ordered fmaf chain).
 #pragma once
+#include <type_traits>
+
 #include "common.h"
 
 namespace rau {
@@ -57,9 +59,9 @@ struct LoadKC {
   static constexpr int LPR = BKT / 4;          // lanes (float4) per row
   static constexpr int RPP = 256 / LPR;        // rows per pass
   static constexpr int NI = BT / RPP;
+  struct Regs { float4 v[NI]; };
   const float* p[NI];
   bool ok[NI];
-  float4 v[NI];
   int kc, K;
   __device__ __forceinline__ void init(const GemmParams& P, const float* base, long rs, long bs,
                                        int row0, int rows, int tid) {
@@ -72,22 +74,23 @@ struct LoadKC {
       p[i] = base + (long)(row0 + r) * rs + kc;
     }
   }
-  __device__ __forceinline__ void load(int step) {
+  template <bool FAST>
+  __device__ __forceinline__ void load(int step, Regs& R) const {
     const int k0 = step * BKT;
 #pragma unroll
     for (int i = 0; i < NI; ++i)
-      v[i] = (ok[i] && k0 + kc < K) ? *reinterpret_cast<const float4*>(p[i] + k0)
-                                    : make_float4(0.f, 0.f, 0.f, 0.f);
+      R.v[i] = (FAST || (ok[i] && k0 + kc < K)) ? *reinterpret_cast<const float4*>(p[i] + k0)
+                                                : make_float4(0.f, 0.f, 0.f, 0.f);
   }
-  __device__ __forceinline__ void store(float* lds, int tid) const {
+  __device__ __forceinline__ void store(float* lds, int tid, const Regs& R) const {
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
       const int r = tid / LPR + i * RPP;
       float* d = lds + kc * (BT + LPAD) + r;
-      d[0] = v[i].x;
-      d[BT + LPAD] = v[i].y;
-      d[2 * (BT + LPAD)] = v[i].z;
-      d[3 * (BT + LPAD)] = v[i].w;
+      d[0] = R.v[i].x;
+      d[BT + LPAD] = R.v[i].y;
+      d[2 * (BT + LPAD)] = R.v[i].z;
+      d[3 * (BT + LPAD)] = R.v[i].w;
     }
   }
 };
@@ -99,11 +102,11 @@ struct LoadRC {
   static constexpr int CPR = BT / 4;
   static constexpr int RPP = 256 / CPR;
   static constexpr int NI = BKT / RPP;
+  struct Regs { float4 v[NI]; };
   const float* p;
   long rs;
   bool ok;
   int kr, c4, K;
-  float4 v[NI];
   __device__ __forceinline__ void init(const GemmParams& P, const float* base, long rs_,
                                        long bs, int col0, int cols, int tid) {
     K = P.K;
@@ -117,19 +120,26 @@ struct LoadRC {
     if (!ok) off = 0;
     p = base + off;
   }
-  __device__ __forceinline__ void load(int step) {
+  template <bool FAST>
+  __device__ __forceinline__ void load(int step, Regs& R) const {
     const int k0 = step * BKT;
+    if (FAST) {  // interior tile: no predicates, one pointer per step
+      const float* q = p + (long)(k0 + kr) * rs;
+#pragma unroll
+      for (int i = 0; i < NI; ++i) R.v[i] = *reinterpret_cast<const float4*>(q + (long)i * RPP * rs);
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
       const int k = k0 + kr + i * RPP;
-      v[i] = (ok && k < K) ? *reinterpret_cast<const float4*>(p + (long)k * rs)
-                           : make_float4(0.f, 0.f, 0.f, 0.f);
+      R.v[i] = (ok && k < K) ? *reinterpret_cast<const float4*>(p + (long)k * rs)
+                             : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   }
-  __device__ __forceinline__ void store(float* lds, int tid) const {
+  __device__ __forceinline__ void store(float* lds, int tid, const Regs& R) const {
 #pragma unroll
     for (int i = 0; i < NI; ++i)
-      *reinterpret_cast<float4*>(lds + (kr + i * RPP) * (BT + LPAD) + c4) = v[i];
+      *reinterpret_cast<float4*>(lds + (kr + i * RPP) * (BT + LPAD) + c4) = R.v[i];
   }
 };
 
@@ -144,10 +154,9 @@ struct LoadSC {
   static constexpr int LPR = 8;
   static constexpr int RPP = 256 / LPR;
   static constexpr int NI = BT / RPP;
+  struct Regs { float4 v[NI]; float4 y[DT ? NI : 1]; };
   long roff[NI];
   bool ok[NI];
-  float4 v[NI];
-  float4 y[DT ? NI : 1];
   const float* base;
   const float* base2;
   long bs;
@@ -167,31 +176,41 @@ struct LoadSC {
       roff[i] = (long)(row0 + r) * S + kc;
     }
   }
-  __device__ __forceinline__ void load(int g) {
+  template <bool FAST>
+  __device__ __forceinline__ void load(int g, Regs& R) const {
     const int b = g / cps;
     const int s0 = (g - b * cps) * BKT;
+    if (FAST) {  // full rows, S % BKT == 0: idle lanes (kc >= BKT) re-read the last chunk
+      const long e0 = (long)b * bs + s0 - (kc >= BKT ? kc - (BKT - 4) : 0);
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        R.v[i] = *reinterpret_cast<const float4*>(base + e0 + roff[i]);
+        if (DT) R.y[i] = *reinterpret_cast<const float4*>(base2 + e0 + roff[i]);
+      }
+      return;
+    }
     const bool kin = kc < BKT && s0 + kc < S;
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
       const long e = (long)b * bs + roff[i] + s0;
-      v[i] = (ok[i] && kin) ? *reinterpret_cast<const float4*>(base + e)
-                            : make_float4(0.f, 0.f, 0.f, 0.f);
-      if (DT)
-        y[i] = (ok[i] && kin) ? *reinterpret_cast<const float4*>(base2 + e)
+      R.v[i] = (ok[i] && kin) ? *reinterpret_cast<const float4*>(base + e)
                               : make_float4(0.f, 0.f, 0.f, 0.f);
+      if (DT)
+        R.y[i] = (ok[i] && kin) ? *reinterpret_cast<const float4*>(base2 + e)
+                                : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   }
-  __device__ __forceinline__ void store(float* lds, int tid) const {
+  __device__ __forceinline__ void store(float* lds, int tid, const Regs& R) const {
     if (kc >= BKT) return;
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
       const int r = tid / LPR + i * RPP;
-      float4 x = v[i];
+      float4 x = R.v[i];
       if (DT) {
-        x.x *= (1.f - y[i].x * y[i].x);
-        x.y *= (1.f - y[i].y * y[i].y);
-        x.z *= (1.f - y[i].z * y[i].z);
-        x.w *= (1.f - y[i].w * y[i].w);
+        x.x *= (1.f - R.y[i].x * R.y[i].x);
+        x.y *= (1.f - R.y[i].y * R.y[i].y);
+        x.z *= (1.f - R.y[i].z * R.y[i].z);
+        x.w *= (1.f - R.y[i].w * R.y[i].w);
       }
       float* d = lds + kc * (BT + LPAD) + r;
       d[0] = x.x;
@@ -226,7 +245,7 @@ enum Epi : int {
 };
 
 template <int BM, int BN, int BKT, int ASRC, int BSRC, int EPI>
-__global__ __launch_bounds__(256) void gemm_kernel(const GemmParams P) {
+__global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams P) {
   constexpr int BK = BKT;
   if (BM < 128) RAU_CHAIN_PRIO();  // skinny tiles = chain-stream GEMMs
   constexpr int WM = BM / 2, WN = BN / 2;   // wave tile
@@ -266,26 +285,13 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams P) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  if (nsteps > 0) {
-    LA.load(step0);
-    LB.load(step0);
-    LA.store(As, tid);
-    LB.store(Bs, tid);
-  }
-  __syncthreads();
-
   const int fa = (l >> 5) * LDA + wm * WM + (l & 31);
   const int fb = (l >> 5) * LDB + wn * WN + (l & 31);
-  for (int it = 0; it < nsteps; ++it) {
-    const int cur = it & 1;
-    const bool more = it + 1 < nsteps;
-    if (more && !(P.dbg & 1)) {
-      LA.load(step0 + it + 1);
-      LB.load(step0 + it + 1);
-    }
+  // one K-step of MFMAs on LDS stage `cur`; fragments of k-step kk+1 are read while the
+  // MFMAs of k-step kk issue
+  auto compute = [&](int cur) {
     const float* as = As + cur * BK * LDA + fa;
     const float* bs = Bs + cur * BK * LDB + fb;
-    // fragments of k-step kk+1 are read from LDS before the MFMAs of k-step kk issue
     float a[2][IM], b[2][JN];
 #pragma unroll
     for (int i = 0; i < IM; ++i) a[0][i] = as[i * 32];
@@ -306,12 +312,45 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams P) {
         for (int j = 0; j < JN; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c][i], b[c][j], acc[i][j], 0, 0, 0);
     }
-    if (more && !(P.dbg & 1)) {
-      LA.store(As + (cur ^ 1) * BK * LDA, tid);
-      LB.store(Bs + (cur ^ 1) * BK * LDB, tid);
+  };
+
+  using LAT = typename LoaderOf<BM, BKT, ASRC>::type;
+  using LBT = typename LoaderOf<BN, BKT, BSRC>::type;
+  typename LAT::Regs ra0;
+  typename LBT::Regs rb0;
+  // Interior tiles (every row/column valid, reduction a whole number of K-steps: all
+  // the bulk shapes) take unpredicated loads: the per-load exec-mask branches and
+  // address recomputation of the general path cost ~15% of the K-loop's issue slots.
+  const bool kfull = (ASRC == SRC_SC) || (ASRC == SRC_SC_DTANH) ? (P.S % BKT == 0) : (P.K % BKT == 0);
+  const bool interior = kfull && m0 + BM <= P.M && n0 + BN <= P.N;
+  auto mainloop = [&](auto fast_tag) {
+    constexpr bool FAST = decltype(fast_tag)::value;
+    if (nsteps > 0) {
+      LA.template load<FAST>(step0, ra0);
+      LB.template load<FAST>(step0, rb0);
+      LA.store(As, tid, ra0);
+      LB.store(Bs, tid, rb0);
     }
-    if (!(P.dbg & 2)) __syncthreads();
-  }
+    __syncthreads();
+    for (int it = 0; it < nsteps; ++it) {
+      const int cur = it & 1;
+      const bool more = it + 1 < nsteps;
+      if (more && !(P.dbg & 1)) {
+        LA.template load<FAST>(step0 + it + 1, ra0);
+        LB.template load<FAST>(step0 + it + 1, rb0);
+      }
+      compute(cur);
+      if (more && !(P.dbg & 1)) {
+        LA.store(As + (cur ^ 1) * BK * LDA, tid, ra0);
+        LB.store(Bs + (cur ^ 1) * BK * LDB, tid, rb0);
+      }
+      if (!(P.dbg & 2)) __syncthreads();
+    }
+  };
+  if (interior)
+    mainloop(std::true_type{});
+  else
+    mainloop(std::false_type{});
 
   // ------------------------------------------------------------ epilogue
   // accumulator element r of block (i,j): row = (r&3) + 8*(r>>2) + 4*(l>>5), col = l&31

@@ -22,6 +22,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <numeric>
 #include <string>
@@ -319,9 +320,23 @@ int rau_create(const rau_config* cfg, rau_ctx** out) {
     // path and must not queue behind the bulk GEMMs' workgroups
     int prio_lo = 0, prio_hi = 0;
     hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
-    hipError_t es = hipStreamCreateWithPriority(&ctx->st, hipStreamNonBlocking, prio_hi);
-    if (es == hipSuccess)
-      es = hipStreamCreateWithPriority(&ctx->st2, hipStreamNonBlocking, prio_lo);
+    hipError_t es = hipSuccess;
+    // Optional spatial partition (RAU_CHAIN_CUS=n): the chain stream gets n compute
+    // units to itself, the bulk stream the rest, via per-queue CU masks.
+    const char* env_cus = std::getenv("RAU_CHAIN_CUS");
+    const int chain_cus = env_cus ? std::atoi(env_cus) : 0;
+    const int ncu = prop.multiProcessorCount;
+    if (chain_cus > 0 && chain_cus < ncu) {
+      const int words = (ncu + 31) / 32;
+      std::vector<uint32_t> mc(words, 0u), mb(words, 0u);
+      for (int i = 0; i < ncu; ++i) (i < chain_cus ? mc : mb)[i >> 5] |= 1u << (i & 31);
+      es = hipExtStreamCreateWithCUMask(&ctx->st, words, mc.data());
+      if (es == hipSuccess) es = hipExtStreamCreateWithCUMask(&ctx->st2, words, mb.data());
+    } else {
+      es = hipStreamCreateWithPriority(&ctx->st, hipStreamNonBlocking, prio_hi);
+      if (es == hipSuccess)
+        es = hipStreamCreateWithPriority(&ctx->st2, hipStreamNonBlocking, prio_lo);
+    }
     if (es != hipSuccess) {
       delete ctx;
       return fail(RAU_ERR_DEVICE, "hipStreamCreate: %s", hipGetErrorString(es));
@@ -331,6 +346,10 @@ int rau_create(const rau_config* cfg, rau_ctx** out) {
   hipEventCreate(&ctx->ev1);
   for (hipEvent_t* e : {&ctx->evA, &ctx->evD}) hipEventCreateWithFlags(e, hipEventDisableTiming);
   ctx->hop_group = (c.H % 2 == 0) ? 2 : 1;
+  if (const char* eg = std::getenv("RAU_HOP_GROUP")) {  // tuning knob: hops per bulk launch
+    const int g = std::atoi(eg);
+    if (g >= 1 && g <= c.H && c.H % g == 0) ctx->hop_group = g;
+  }
   ctx->evF.resize(c.H);
   ctx->evK.resize(c.H);
   for (int i = 0; i < c.H; ++i) {

@@ -83,6 +83,18 @@ int main(int argc, char** argv) {
     P.A = Wi; P.a_rs = D; P.B = X; P.b_rs = S; P.b_bs = (long)D * S; P.S = S;
     P.C = I; P.c_rs = P.N; P.slab_stride = 0;
     report("v: KC x RC_FLAT slab-store", timeit(st, 20, [&] { return launch_gemm<128, 128, 32, SRC_KC, SRC_RC_FLAT, EPI_SLAB>(st, P, 1); }), 2.0 * M * NS * D);
+    {
+      GemmParams P8 = P; P8.N = 8 * B * S; P8.A = Wi; P8.a_rs = M; P8.C = nullptr;
+      float* xd8; CK(hipMalloc(&xd8, (size_t)8 * B * D * S * 4)); CK(hipMemset(xd8, 0, (size_t)8 * B * D * S * 4));
+      float* I8; CK(hipMalloc(&I8, (size_t)8 * B * M * S * 4));
+      P8.B = xd8; P8.C = I8; P8.c_bs = (long)M * S; P8.bias = bi; P8.act = 1;
+      for (int dbg : {0, 0}) {
+        P8.dbg = dbg;
+        char nm[64]; snprintf(nm, 64, "v: embed_fwd x8 stagger=%d", dbg >> 4);
+        report(nm, timeit(st, 5, [&] { return launch_gemm<128, 128, 32, SRC_RC, SRC_RC_FLAT, EPI_CONV>(st, P8, 1); }), 2.0 * M * NS * D * 8);
+      }
+      CK(hipFree(xd8)); CK(hipFree(I8));
+    }
     for (int dbg : {1, 2, 3}) {
       GemmParams D1 = P; D1.dbg = dbg;
       char nm[64]; snprintf(nm, 64, "v: KC x RC_FLAT dbg=%d", dbg);
