@@ -95,7 +95,8 @@ struct rau_ctx {
   int Q;
   hipStream_t st = nullptr;    // chain stream: recurrences, small GEMMs; what callers order against
   hipStream_t st2 = nullptr;   // bulk stream: hop-batched 1x1-conv GEMMs, overlapped with the chain
-  hipEvent_t evA = nullptr, evD = nullptr;
+  hipStream_t st3 = nullptr;   // weight-gradient stream: throughput GEMMs nobody waits for until the end
+  hipEvent_t evA = nullptr, evD = nullptr, evW = nullptr, evE = nullptr, evW3 = nullptr;
   std::vector<hipEvent_t> evF, evK;  // per hop group: forward bulk done / backward chain done
   int cur_group = 1;                 // group size used by the last forward
   int hop_group = 1;                 // hops per bulk launch (pipelines bulk GEMMs with the hop loops)
@@ -135,7 +136,8 @@ struct rau_ctx {
   // backward temporaries
   // dZ holds dI (gradient at i_embed's OUTPUT); the tanh derivative is applied by its consumers
   float *dpre, *dhn, *dg4, *dcn[2], *dhp[2], *dj, *da_lin, *dz, *du, *dwsp, *dZ, *rsum,
-      *dqt, *dQD, *dq, *slab, *slab2, *coltmp, *coltmp2, *tmpS;
+      *dqt, *dQD, *dq, *slab, *slab2, *slab3, *coltmp, *coltmp2, *coltmp3, *tmpS;
+  size_t slab3_floats = 0;
   float *dG1, *dG2, *dX2, *dwe, *edc[2][2], *edh[2];
   size_t slab_floats = 0;
   // update
@@ -239,6 +241,7 @@ static int prof_collect(rau_ctx* ctx) {
   if (ctx->precs.empty()) return 0;
   HIPC(hipStreamSynchronize(ctx->st));
   HIPC(hipStreamSynchronize(ctx->st2));
+  HIPC(hipStreamSynchronize(ctx->st3));
   for (auto& r : ctx->precs) {
     float ms = 0.f;
     hipEventElapsedTime(&ms, r.a, r.b);
@@ -344,7 +347,13 @@ int rau_create(const rau_config* cfg, rau_ctx** out) {
   }
   hipEventCreate(&ctx->ev0);
   hipEventCreate(&ctx->ev1);
-  for (hipEvent_t* e : {&ctx->evA, &ctx->evD}) hipEventCreateWithFlags(e, hipEventDisableTiming);
+  for (hipEvent_t* e : {&ctx->evA, &ctx->evD, &ctx->evW, &ctx->evE, &ctx->evW3})
+    hipEventCreateWithFlags(e, hipEventDisableTiming);
+  {
+    int plo = 0, phi = 0;
+    hipDeviceGetStreamPriorityRange(&plo, &phi);
+    hipStreamCreateWithPriority(&ctx->st3, hipStreamNonBlocking, plo);
+  }
   ctx->hop_group = (c.H % 2 == 0) ? 2 : 1;
   if (const char* eg = std::getenv("RAU_HOP_GROUP")) {  // tuning knob: hops per bulk launch
     const int g = std::atoi(eg);
@@ -491,11 +500,14 @@ int rau_create(const rau_config* cfg, rau_ctx** out) {
     for (auto& s : shapes) sl = std::max(sl, gemm_tn_slab_floats(s[0], s[1], s[2]));
     ctx->slab_floats = sl;
     CK(dalloc(ctx, &ctx->slab, sl));
+    ctx->slab3_floats = sl;
+    CK(dalloc(ctx, &ctx->slab3, sl));
   }
   {
     const int widest = std::max({4 * R, 4 * Rq, K, M, S, A, Q});
     CK(dalloc(ctx, &ctx->coltmp, (size_t)32 * widest));
     CK(dalloc(ctx, &ctx->coltmp2, (size_t)32 * widest));
+    CK(dalloc(ctx, &ctx->coltmp3, (size_t)32 * widest));
     CK(dalloc(ctx, &ctx->tmpS, (size_t)S));
   }
   CK(dalloc(ctx, &ctx->dG1, TB * 4 * Rq));
@@ -525,6 +537,7 @@ void rau_destroy(rau_ctx* ctx) {
   if (!ctx) return;
   if (ctx->st) hipStreamSynchronize(ctx->st);
   if (ctx->st2) hipStreamSynchronize(ctx->st2);
+  if (ctx->st3) hipStreamSynchronize(ctx->st3);
   for (void* p : ctx->allocs) hipFree(p);
   for (auto& r : ctx->precs) {
     hipEventDestroy(r.a);
@@ -533,8 +546,9 @@ void rau_destroy(rau_ctx* ctx) {
   for (auto e : ctx->evpool) hipEventDestroy(e);
   if (ctx->ev0) hipEventDestroy(ctx->ev0);
   if (ctx->ev1) hipEventDestroy(ctx->ev1);
-  for (hipEvent_t e : {ctx->evA, ctx->evD})
+  for (hipEvent_t e : {ctx->evA, ctx->evD, ctx->evW, ctx->evE, ctx->evW3})
     if (e) hipEventDestroy(e);
+  if (ctx->st3) hipStreamDestroy(ctx->st3);
   for (hipEvent_t e : ctx->evF) hipEventDestroy(e);
   for (hipEvent_t e : ctx->evK) hipEventDestroy(e);
   if (ctx->st2) hipStreamDestroy(ctx->st2);
@@ -1087,8 +1101,13 @@ int rau_backward(rau_ctx* ctx, const float* hop_w) {
          colsum_acc(sb, H * B, M, ctx->rsum, M, ctx->i_embed.db, ctx->coltmp2));
     HIPC(hipEventRecord(ctx->evD, sb));
   }
-  // ---------------- mult-group weight gradients, one GEMM per weight over all hops
+  // ---------------- mult-group weight gradients, one GEMM per weight over all hops.
+  // Throughput work nothing else waits for: third stream, so the encoder BPTT (the
+  // long latency-bound chain) starts right after dq instead of behind ~40 launches.
   {
+    hipStream_t sw = ctx->st3;
+    HIPC(hipEventRecord(ctx->evW, st));
+    HIPC(hipStreamWaitEvent(sw, ctx->evW, 0));
     const int rows = H * B;
     const float* hprev = ctx->hh;            // h_{0..H-1}
     const float* hnew = ctx->hh + BR_;       // h_{1..H}
@@ -1100,18 +1119,18 @@ int rau_backward(rau_ctx* ctx, const float* hop_w) {
         {&ctx->att_q, ctx->du, ctx->qf},         {&ctx->q_proj, ctx->dqt, ctx->qd},
         {&ctx->h_proj, ctx->dqt, hprev}};
     for (const WG& w : wgs) {
-      RUN("wgrad_gemm", gflop(w.l->out, w.l->in, rows), 0,
-          gemm_tn_acc(st, w.l->out, w.l->in, rows, w.dY, w.l->out, w.X, w.l->in, w.l->dW, w.l->in,
-                      ctx->slab));
-      RUN("colsum", 0, (double)rows * w.l->out * 4,
-          colsum_acc(st, rows, w.l->out, w.dY, w.l->out, w.l->db, ctx->coltmp));
+      RUNS(sw, "wgrad_gemm", gflop(w.l->out, w.l->in, rows), 0,
+          gemm_tn_acc(sw, w.l->out, w.l->in, rows, w.dY, w.l->out, w.X, w.l->in, w.l->dW, w.l->in,
+                      ctx->slab3));
+      RUNS(sw, "colsum", 0, (double)rows * w.l->out * 4,
+          colsum_acc(sw, rows, w.l->out, w.dY, w.l->out, w.l->db, ctx->coltmp3));
     }
     // att_score: dws = sum dz T ; dbs = sum dz.  att_i bias: sum dS.  i_embed bias: sum dZ.
-    RUN("colsum", 0, (double)rows * A * 4, colsum_acc(st, rows, A, ctx->dwsp, A, ctx->att_score.dW, ctx->coltmp));
-    HIPC(hipMemsetAsync(ctx->tmpS, 0, S * sizeof(float), st));
-    RUN("colsum", 0, (double)rows * S * 4, colsum_acc(st, rows, S, ctx->dz, S, ctx->tmpS, ctx->coltmp));
-    RUN("colsum", 0, S * 4.0, colsum_acc(st, S, 1, ctx->tmpS, 1, ctx->att_score.db, ctx->coltmp));
-    RUN("colsum", 0, (double)rows * A * 4, colsum_acc(st, rows, A, ctx->du, A, ctx->att_i.db, ctx->coltmp));
+    RUNS(sw, "colsum", 0, (double)rows * A * 4, colsum_acc(sw, rows, A, ctx->dwsp, A, ctx->att_score.dW, ctx->coltmp3));
+    HIPC(hipMemsetAsync(ctx->tmpS, 0, S * sizeof(float), sw));
+    RUNS(sw, "colsum", 0, (double)rows * S * 4, colsum_acc(sw, rows, S, ctx->dz, S, ctx->tmpS, ctx->coltmp3));
+    RUNS(sw, "colsum", 0, S * 4.0, colsum_acc(sw, S, 1, ctx->tmpS, 1, ctx->att_score.db, ctx->coltmp3));
+    RUNS(sw, "colsum", 0, (double)rows * A * 4, colsum_acc(sw, rows, A, ctx->du, A, ctx->att_i.db, ctx->coltmp3));
   }
 
   // ---------------- encoder BPTT, SS:581-596
@@ -1158,17 +1177,23 @@ int rau_backward(rau_ctx* ctx, const float* hop_w) {
     RUN("embed_bwd", 0, (double)rows * E * 12,
         embed_bwd(st, ctx->nuniq, E, ctx->utok, ctx->ustart, ctx->upos, ctx->dwe, ctx->we, m_we,
                   sc(RAU_MASK_WE), ctx->grp[RAU_GROUP_EMBED].g));
+    // encoder weight gradients: also on the weight-gradient stream
+    hipStream_t sw = ctx->st3;
+    HIPC(hipEventRecord(ctx->evE, st));
+    HIPC(hipStreamWaitEvent(sw, ctx->evE, 0));
     struct WG { Lin* l; const float* dY; const float* X; };
     const WG wgs[] = {{&ctx->i2h[0], ctx->dG1, ctx->we}, {&ctx->h2h[0], ctx->dG1, ctx->h1},
                       {&ctx->i2h[1], ctx->dG2, ctx->x2}, {&ctx->h2h[1], ctx->dG2, ctx->h2}};
     for (const WG& w : wgs) {
-      RUN("wgrad_gemm", gflop(w.l->out, w.l->in, rows), 0,
-          gemm_tn_acc(st, w.l->out, w.l->in, rows, w.dY, w.l->out, w.X, w.l->in, w.l->dW, w.l->in,
-                      ctx->slab));
-      RUN("colsum", 0, (double)rows * w.l->out * 4,
-          colsum_acc(st, rows, w.l->out, w.dY, w.l->out, w.l->db, ctx->coltmp));
+      RUNS(sw, "wgrad_gemm", gflop(w.l->out, w.l->in, rows), 0,
+          gemm_tn_acc(sw, w.l->out, w.l->in, rows, w.dY, w.l->out, w.X, w.l->in, w.l->dW, w.l->in,
+                      ctx->slab3));
+      RUNS(sw, "colsum", 0, (double)rows * w.l->out * 4,
+          colsum_acc(sw, rows, w.l->out, w.dY, w.l->out, w.l->db, ctx->coltmp3));
     }
   }
+  HIPC(hipEventRecord(ctx->evW3, ctx->st3));
+  HIPC(hipStreamWaitEvent(st, ctx->evW3, 0));
   HIPC(hipStreamWaitEvent(st, ctx->evD, 0));  // join: every gradient is ordered on st
   return RAU_OK;
 }
