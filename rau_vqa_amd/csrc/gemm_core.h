@@ -27,6 +27,8 @@ struct GemmParams {
   int nk;               // number of BK-steps in the whole reduction
   int nk_per_split;     // BK-steps handled by one blockIdx.z
   int tiles_m, tiles_n;
+  // batched launch (blockIdx.y): same shapes, different operand / slab bases
+  int nbatch; const float* Ab[3]; const float* Bb[3]; long slab_batch_stride;
   // A operand
   const float* A; long a_rs; long a_bs;
   const float* A2;      // SC_DTANH loader: second source, A * (1 - A2^2) (same indexing as A)
@@ -274,8 +276,10 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams P) {
 
   typename LoaderOf<BM, BKT, ASRC>::type LA;
   typename LoaderOf<BN, BKT, BSRC>::type LB;
-  LA.init(P, P.A, P.a_rs, P.a_bs, m0, P.M, tid);
-  LB.init(P, P.B, P.b_rs, P.b_bs, n0, P.N, tid);
+  const float* Abase = P.nbatch ? P.Ab[blockIdx.y] : P.A;
+  const float* Bbase = P.nbatch ? P.Bb[blockIdx.y] : P.B;
+  LA.init(P, Abase, P.a_rs, P.a_bs, m0, P.M, tid);
+  LB.init(P, Bbase, P.b_rs, P.b_bs, n0, P.N, tid);
 
   f32x16 acc[IM][JN];
 #pragma unroll
@@ -358,7 +362,9 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams P) {
   const int cloc = wn * WN + (l & 31);       // column of j=0 inside the tile
 
   if (EPI == EPI_LIN || EPI == EPI_SLAB) {
-    float* C = P.C + (EPI == EPI_SLAB ? (long)blockIdx.z * P.slab_stride : 0);
+    float* C = P.C + (EPI == EPI_SLAB ? (long)blockIdx.z * P.slab_stride +
+                                        (P.nbatch ? (long)blockIdx.y * P.slab_batch_stride : 0)
+                                      : 0);
 #pragma unroll
     for (int j = 0; j < JN; ++j) {
       const int n = n0 + cloc + j * 32;
@@ -452,7 +458,7 @@ inline hipError_t launch_gemm(hipStream_t st, GemmParams P, int splits) {
   if (splits > P.nk) splits = P.nk > 0 ? P.nk : 1;
   P.nk_per_split = (P.nk + splits - 1) / splits;
   splits = P.nk_per_split > 0 ? (P.nk + P.nk_per_split - 1) / P.nk_per_split : 1;
-  dim3 grid(P.tiles_m * P.tiles_n, 1, splits);
+  dim3 grid(P.tiles_m * P.tiles_n, P.nbatch ? P.nbatch : 1, splits);
   hipLaunchKernelGGL((gemm_kernel<BM, BN, BKT, ASRC, BSRC, EPI>), grid, dim3(256), 0, st, P);
   return hipGetLastError();
 }

@@ -79,6 +79,42 @@ hipError_t gemm_nn(hipStream_t st, int M, int N, int K, const float* A, long lda
   return lin_gemm<SRC_KC, SRC_RC>(st, M, N, K, A, lda, W, ldw, C, ldc, o);
 }
 
+// nb same-shape skinny problems in ONE launch, partials left in the slab laid out
+// [problem][split][M*N]; the consumer kernel reduces them (deferred, fixed order).
+template <int ASRC, int BSRC>
+static hipError_t batched_deferred(hipStream_t st, int nb, int M, int N, int K,
+                                   const float* const* A, long lda, const float* const* W,
+                                   long ldw, float* slab, size_t slab_floats, int* splits) {
+  if (nb < 1 || nb > 3) return hipErrorInvalidValue;
+  LinOpts o;
+  o.slab = slab;
+  o.slab_floats = slab_floats / nb;
+  GemmParams P = lin_params(M, N, K, A[0], lda, W[0], ldw, slab, N, o);
+  P.nk = (K + BKS - 1) / BKS;
+  // same K-split as a single problem: these launches are latency-bound, more (shorter)
+  // workgroups beat fewer long ones
+  const int s = skinny_splits(M, N, K, o);
+  if ((size_t)nb * s * M * N > slab_floats) return hipErrorInvalidValue;
+  P.nbatch = nb;
+  for (int i = 0; i < nb; ++i) { P.Ab[i] = A[i]; P.Bb[i] = W[i]; }
+  P.C = slab;
+  P.c_rs = N;
+  P.slab_stride = (long)M * N;
+  P.slab_batch_stride = (long)s * M * N;
+  *splits = s;
+  return launch_gemm<64, 64, BKS, ASRC, BSRC, EPI_SLAB>(st, P, s);
+}
+hipError_t gemm_nt_batched_deferred(hipStream_t st, int nb, int M, int N, int K,
+                                    const float* const* A, long lda, const float* const* W,
+                                    long ldw, float* slab, size_t slab_floats, int* splits) {
+  return batched_deferred<SRC_KC, SRC_KC>(st, nb, M, N, K, A, lda, W, ldw, slab, slab_floats, splits);
+}
+hipError_t gemm_nn_batched_deferred(hipStream_t st, int nb, int M, int N, int K,
+                                    const float* const* A, long lda, const float* const* W,
+                                    long ldw, float* slab, size_t slab_floats, int* splits) {
+  return batched_deferred<SRC_KC, SRC_RC>(st, nb, M, N, K, A, lda, W, ldw, slab, slab_floats, splits);
+}
+
 static int tn_splits(int M, int N, int K) {
   const int tiles = ((M + 127) / 128) * ((N + 127) / 128);
   const int nk = (K + BK - 1) / BK;

@@ -35,6 +35,15 @@ hipError_t gemm_nt(hipStream_t st, int M, int N, int K, const float* A, long lda
 // C[M,N] = epi(A[M,K] * W[K,N])        (Linear input gradient)
 hipError_t gemm_nn(hipStream_t st, int M, int N, int K, const float* A, long lda,
                    const float* W, long ldw, float* C, long ldc, const LinOpts& o);
+// nb (<= 3) same-shape problems C_i = A_i W_i^T (nt) / A_i W_i (nn) in one launch; the
+// K-split partials stay in `slab` as [problem][split][M*N] (*splits per problem) for a
+// consumer kernel to sum -- used by the encoder's layer wavefront.
+hipError_t gemm_nt_batched_deferred(hipStream_t st, int nb, int M, int N, int K,
+                                    const float* const* A, long lda, const float* const* W,
+                                    long ldw, float* slab, size_t slab_floats, int* splits);
+hipError_t gemm_nn_batched_deferred(hipStream_t st, int nb, int M, int N, int K,
+                                    const float* const* A, long lda, const float* const* W,
+                                    long ldw, float* slab, size_t slab_floats, int* splits);
 // C[M,N] += A[K,M]^T * B[K,N]          (Linear weight gradient; deterministic split-K
 // through `slab`, which must hold gemm_tn_slab_floats(M,N,K) floats)
 size_t gemm_tn_slab_floats(int M, int N, int K);
@@ -84,6 +93,29 @@ hipError_t lstm_bwd(hipStream_t st, int order, int nB, int R, const float* gates
                     long dh_rs, const float* dh2, const float* dc_next, float* dsum,
                     float* dc_prev, const int32_t* lens, int t, const float* dq_c,
                     const float* dq_h, long dq_rs, const float* slab = nullptr, int nsplit = 0);
+// Up to two independent LSTM cells in one launch (blockIdx.y): the encoder's layer
+// wavefront evaluates layer-1 cell t+1 and layer-2 cell t together.
+struct LstmFwdCell {
+  float* g4;                      // [nB,4R] out: activated gates; in: input part if has_input
+  int has_input;                  // 1: pre-activation starts from g4, 0: from b1 + b2
+  const float* b1; const float* b2;
+  const float* slab; int nsplit;  // nsplit partials [nB,4R], contiguous, summed in order
+  const float* c_prev; long cp_rs;
+  float* c; long c_rs; float* h; long h_rs; float* tanhc;
+  float* drop_out; const uint32_t* mask; size_t mask_e0; float mscale;
+};
+struct LstmFwdCells { int n; LstmFwdCell c[2]; };
+hipError_t lstm_fwd_multi(hipStream_t st, int order, int nB, int R, const LstmFwdCells& cells);
+struct LstmBwdCell {
+  const float* gates; const float* c_prev; long cp_rs; const float* tanhc;
+  const float* slabA; int nA;     // recurrent dh partials [nB,R]
+  const float* slabB; int nBp;    // extra dh partials, passed through a dropout mask
+  const uint32_t* maskB; size_t maskB_e0; float mscaleB;
+  const float* dc_next; float* dsum; float* dc_prev;
+  int t; const float* dq_c; const float* dq_h;   // rows with lens[b]==t take dq (SS:584-591)
+};
+struct LstmBwdCells { int n; const int32_t* lens; long dq_rs; LstmBwdCell c[2]; };
+hipError_t lstm_bwd_multi(hipStream_t st, int order, int nB, int R, const LstmBwdCells& cells);
 // One workgroup per sample: T = tanh(P + u[b,:,None]) (attbycontent, SS:250),
 // e = ws . T + bs (SS:251), a = softmax(e + zm) (attbymemory, SS:288-289),
 // jv = qf + sum_s I a (attselect SS:254-263 + first CAddTable SS:270).

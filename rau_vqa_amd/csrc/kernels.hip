@@ -227,6 +227,104 @@ hipError_t lstm_bwd(hipStream_t st, int order, int nB, int R, const float* gates
   return hipGetLastError();
 }
 
+// Multi-cell variants (blockIdx.y = cell): same arithmetic as k_lstm_fwd / k_lstm_bwd.
+template <int ORDER>
+__global__ void k_lstm_fwd_multi(int nB, int R, LstmFwdCells cs) {
+  RAU_CHAIN_PRIO();
+  using GS = GateSlots<ORDER>;
+  const LstmFwdCell& C = cs.c[blockIdx.y];
+  const size_t n = (size_t)nB * R;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const int b = (int)(i / R), r = (int)(i - (size_t)b * R);
+    float* g = C.g4 + (size_t)b * 4 * R;
+    float pi, pf, po, pg;
+    if (C.has_input) {
+      pi = g[GS::I * R + r]; pf = g[GS::F * R + r]; po = g[GS::O * R + r]; pg = g[GS::G * R + r];
+    } else {
+      pi = C.b1[GS::I * R + r] + C.b2[GS::I * R + r];
+      pf = C.b1[GS::F * R + r] + C.b2[GS::F * R + r];
+      po = C.b1[GS::O * R + r] + C.b2[GS::O * R + r];
+      pg = C.b1[GS::G * R + r] + C.b2[GS::G * R + r];
+    }
+    for (int s = 0; s < C.nsplit; ++s) {
+      const float* sl = C.slab + ((size_t)s * nB + b) * 4 * R;
+      pi += sl[GS::I * R + r]; pf += sl[GS::F * R + r];
+      po += sl[GS::O * R + r]; pg += sl[GS::G * R + r];
+    }
+    const float gi = sigmoidf_(pi), gf = sigmoidf_(pf), go = sigmoidf_(po), gg = tanh_fast(pg);
+    g[GS::I * R + r] = gi; g[GS::F * R + r] = gf; g[GS::O * R + r] = go; g[GS::G * R + r] = gg;
+    const float cn = gf * C.c_prev[(size_t)b * C.cp_rs + r] + gi * gg;
+    const float tc = tanh_fast(cn);
+    const float hn = go * tc;
+    C.c[(size_t)b * C.c_rs + r] = cn;
+    C.h[(size_t)b * C.h_rs + r] = hn;
+    C.tanhc[i] = tc;
+    if (C.drop_out) {
+      float v = hn;
+      if (C.mask) v = mask_bit(C.mask, C.mask_e0 + i) ? hn * C.mscale : 0.f;
+      C.drop_out[i] = v;
+    }
+  }
+}
+hipError_t lstm_fwd_multi(hipStream_t st, int order, int nB, int R, const LstmFwdCells& cells) {
+  if (cells.n < 1) return hipSuccess;
+  const dim3 g(grid_for((size_t)nB * R, 256, 512), cells.n), b(256);
+  if (order == GATES_ATT)
+    hipLaunchKernelGGL(k_lstm_fwd_multi<GATES_ATT>, g, b, 0, st, nB, R, cells);
+  else
+    hipLaunchKernelGGL(k_lstm_fwd_multi<GATES_DEEP>, g, b, 0, st, nB, R, cells);
+  return hipGetLastError();
+}
+
+template <int ORDER>
+__global__ void k_lstm_bwd_multi(int nB, int R, LstmBwdCells cs) {
+  RAU_CHAIN_PRIO();
+  using GS = GateSlots<ORDER>;
+  const LstmBwdCell& C = cs.c[blockIdx.y];
+  const size_t n = (size_t)nB * R;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const int b = (int)(i / R), r = (int)(i - (size_t)b * R);
+    float dhv, dcv;
+    if (cs.lens[b] == C.t) {  // rows REPLACED by dq, reference SS:584-591
+      dhv = C.dq_h[(size_t)b * cs.dq_rs + r];
+      dcv = C.dq_c[(size_t)b * cs.dq_rs + r];
+    } else {
+      dhv = 0.f;
+      for (int s = 0; s < C.nA; ++s) dhv += C.slabA[((size_t)s * nB + b) * R + r];
+      dcv = C.dc_next ? C.dc_next[i] : 0.f;
+    }
+    if (C.nBp > 0) {  // gradient arriving through the inter-layer dropout (DeepLSTM.lua:39)
+      float e = 0.f;
+      for (int s = 0; s < C.nBp; ++s) e += C.slabB[((size_t)s * nB + b) * R + r];
+      if (C.maskB) e = mask_bit(C.maskB, C.maskB_e0 + i) ? e * C.mscaleB : 0.f;
+      dhv += e;
+    }
+    const float* g = C.gates + (size_t)b * 4 * R;
+    const float gi = g[GS::I * R + r], gf = g[GS::F * R + r], go = g[GS::O * R + r],
+                gg = g[GS::G * R + r];
+    const float tc = C.tanhc[i];
+    const float d_o = dhv * tc;
+    const float dc = dcv + dhv * go * (1.f - tc * tc);
+    float* ds = C.dsum + (size_t)b * 4 * R;
+    ds[GS::I * R + r] = dc * gg * gi * (1.f - gi);
+    ds[GS::F * R + r] = dc * C.c_prev[(size_t)b * C.cp_rs + r] * gf * (1.f - gf);
+    ds[GS::O * R + r] = d_o * go * (1.f - go);
+    ds[GS::G * R + r] = dc * gi * (1.f - gg * gg);
+    C.dc_prev[i] = dc * gf;
+  }
+}
+hipError_t lstm_bwd_multi(hipStream_t st, int order, int nB, int R, const LstmBwdCells& cells) {
+  if (cells.n < 1) return hipSuccess;
+  const dim3 g(grid_for((size_t)nB * R, 256, 512), cells.n), b(256);
+  if (order == GATES_ATT)
+    hipLaunchKernelGGL(k_lstm_bwd_multi<GATES_ATT>, g, b, 0, st, nB, R, cells);
+  else
+    hipLaunchKernelGGL(k_lstm_bwd_multi<GATES_DEEP>, g, b, 0, st, nB, R, cells);
+  return hipGetLastError();
+}
+
 // ------------------------------------------- fused per-sample attention kernels
 // One workgroup of kAttWaves waves per sample; everything a hop needs from the big
 // per-sample tiles P/T [A,S] and I [M,S] in one pass over them.  16 waves per

@@ -138,7 +138,7 @@ struct rau_ctx {
   float *dpre, *dhn, *dg4, *dcn[2], *dhp[2], *dj, *da_lin, *dz, *du, *dwsp, *dZ, *rsum,
       *dqt, *dQD, *dq, *slab, *slab2, *slab3, *coltmp, *coltmp2, *coltmp3, *tmpS;
   size_t slab3_floats = 0;
-  float *dG1, *dG2, *dX2, *dwe, *edc[2][2], *edh[2];
+  float *dG1, *dG2, *dwe, *edc[2][2];
   size_t slab_floats = 0;
   // update
   float *npart = nullptr, *norms_d = nullptr;
@@ -512,12 +512,10 @@ int rau_create(const rau_config* cfg, rau_ctx** out) {
   }
   CK(dalloc(ctx, &ctx->dG1, TB * 4 * Rq));
   CK(dalloc(ctx, &ctx->dG2, TB * 4 * Rq));
-  CK(dalloc(ctx, &ctx->dX2, TB * Rq));
   CK(dalloc(ctx, &ctx->dwe, TB * E));
   for (int L = 0; L < 2; ++L) {
     CK(dalloc(ctx, &ctx->edc[L][0], (size_t)B * Rq));
     CK(dalloc(ctx, &ctx->edc[L][1], (size_t)B * Rq));
-    CK(dalloc(ctx, &ctx->edh[L], (size_t)B * Rq));
   }
   CK(dalloc(ctx, &ctx->npart, (size_t)1024));
   CK(dalloc(ctx, &ctx->norms_d, (size_t)4));
@@ -801,40 +799,64 @@ int rau_forward(rau_ctx* ctx) {
   }
 
   // ---------------- encoder, SS:443-462
+  // Layer-1 cell t+1 and layer-2 cell t do not depend on each other, so the two layers
+  // advance as a wavefront: per step ONE batched split-K GEMM (h1 W_h2h1^T for layer 1;
+  // x2 W_i2h2^T and h2 W_h2h2^T for layer 2; same shapes) and ONE two-cell LSTM kernel
+  // that sums the partials -- TL+1 steps of 2 launches instead of 2*TL steps of 2.
   if (TL > 0) {
     const int rows = TL * B;
+    const size_t G4 = (size_t)B * 4 * Rq;
     RUN("embed_fwd", 0, rows * E * 8.0,
         embed_fwd(st, rows, E, ctx->grp[RAU_GROUP_EMBED].w, ctx->tokens, m_we, sc(RAU_MASK_WE),
                   ctx->we));
-    for (int L = 0; L < 2; ++L) {
-      float* G = L == 0 ? ctx->G1 : ctx->G2;
-      float* cs = L == 0 ? ctx->c1 : ctx->c2;
-      float* hs = L == 0 ? ctx->h1 : ctx->h2;
-      float* tcs = L == 0 ? ctx->tc1 : ctx->tc2;
-      const float* xin = L == 0 ? ctx->we : ctx->x2;
-      const int kin = L == 0 ? E : Rq;
+    {  // layer-1 input projection of every token at once (no recurrence in it)
       LINOPTS(o);
-      o.bias = ctx->i2h[L].b;
-      o.bias2 = ctx->h2h[L].b;
-      // input projection of every token at once (no recurrence in it)
-      RUN("enc_i2h_gemm", gflop(rows, 4 * Rq, kin), 0,
-          gemm_nt(st, rows, 4 * Rq, kin, xin, kin, ctx->i2h[L].W, kin, G, 4 * Rq, o));
-      for (int t = 1; t <= TL; ++t) {
-        float* Gt = G + (size_t)(t - 1) * B * 4 * Rq;
-        int nsp = 0;  // split-K partials of h_{t-1} W_h2h^T, summed inside lstm_fwd
-        if (t > 1) {
-          LINOPTS(oa);
-          oa.defer_splits = &nsp;
-          RUN("enc_h2h_gemm", gflop(B, 4 * Rq, Rq), 0,
-              gemm_nt(st, B, 4 * Rq, Rq, hs + (size_t)(t - 1) * BRq, Rq, ctx->h2h[L].W, Rq, Gt,
-                      4 * Rq, oa));
-        }
-        RUN("lstm_fwd", 0, BRq * 4.0 * 10,
-            lstm_fwd(st, GATES_DEEP, B, Rq, Gt, cs + (size_t)(t - 1) * BRq, Rq,
-                     cs + (size_t)t * BRq, Rq, hs + (size_t)t * BRq, Rq,
-                     tcs + (size_t)(t - 1) * BRq, L == 0 ? ctx->x2 + (size_t)(t - 1) * BRq : nullptr,
-                     m_rnn, (size_t)(t - 1) * BRq, sc(RAU_MASK_RNN), ctx->slab, nsp));
+      o.bias = ctx->i2h[0].b;
+      o.bias2 = ctx->h2h[0].b;
+      RUN("enc_i2h_gemm", gflop(rows, 4 * Rq, E), 0,
+          gemm_nt(st, rows, 4 * Rq, E, ctx->we, E, ctx->i2h[0].W, E, ctx->G1, 4 * Rq, o));
+    }
+    for (int s = 1; s <= TL + 1; ++s) {
+      const float* Ap[3];
+      const float* Wp[3];
+      int nb = 0, i0 = -1, i1 = -1, i2 = -1;
+      if (s <= TL && s >= 2) { Ap[nb] = ctx->h1 + (size_t)(s - 1) * BRq; Wp[nb] = ctx->h2h[0].W; i0 = nb++; }
+      if (s >= 2) { Ap[nb] = ctx->x2 + (size_t)(s - 2) * BRq; Wp[nb] = ctx->i2h[1].W; i1 = nb++; }
+      if (s >= 3) { Ap[nb] = ctx->h2 + (size_t)(s - 2) * BRq; Wp[nb] = ctx->h2h[1].W; i2 = nb++; }
+      int nsp = 0;
+      if (nb > 0)
+        RUN("enc_h2h_gemm", gflop(B, 4 * Rq, Rq) * nb, 0,
+            gemm_nt_batched_deferred(st, nb, B, 4 * Rq, Rq, Ap, Rq, Wp, Rq, ctx->slab,
+                                     ctx->slab_floats, &nsp));
+      LstmFwdCells cells{};
+      if (s <= TL) {  // layer-1 cell t = s
+        LstmFwdCell& C1 = cells.c[cells.n++];
+        C1.g4 = ctx->G1 + (size_t)(s - 1) * G4;
+        C1.has_input = 1;
+        C1.slab = i0 >= 0 ? ctx->slab + (size_t)i0 * nsp * G4 : nullptr;
+        C1.nsplit = i0 >= 0 ? nsp : 0;
+        C1.c_prev = ctx->c1 + (size_t)(s - 1) * BRq; C1.cp_rs = Rq;
+        C1.c = ctx->c1 + (size_t)s * BRq; C1.c_rs = Rq;
+        C1.h = ctx->h1 + (size_t)s * BRq; C1.h_rs = Rq;
+        C1.tanhc = ctx->tc1 + (size_t)(s - 1) * BRq;
+        C1.drop_out = ctx->x2 + (size_t)(s - 1) * BRq;   // layer-2 input, DeepLSTM.lua:39
+        C1.mask = m_rnn; C1.mask_e0 = (size_t)(s - 1) * BRq; C1.mscale = sc(RAU_MASK_RNN);
       }
+      if (s >= 2) {  // layer-2 cell t = s - 1
+        const int t = s - 1;
+        LstmFwdCell& C2 = cells.c[cells.n++];
+        C2.g4 = ctx->G2 + (size_t)(t - 1) * G4;
+        C2.has_input = 0;
+        C2.b1 = ctx->i2h[1].b; C2.b2 = ctx->h2h[1].b;
+        C2.slab = ctx->slab + (size_t)i1 * nsp * G4;      // x2 W_i2h2^T then h2 W_h2h2^T partials
+        C2.nsplit = i2 >= 0 ? 2 * nsp : nsp;
+        C2.c_prev = ctx->c2 + (size_t)(t - 1) * BRq; C2.cp_rs = Rq;
+        C2.c = ctx->c2 + (size_t)t * BRq; C2.c_rs = Rq;
+        C2.h = ctx->h2 + (size_t)t * BRq; C2.h_rs = Rq;
+        C2.tanhc = ctx->tc2 + (size_t)(t - 1) * BRq;
+        C2.drop_out = nullptr; C2.mask = nullptr; C2.mask_e0 = 0; C2.mscale = 1.f;
+      }
+      RUN("lstm_fwd", 0, BRq * 4.0 * 10 * cells.n, lstm_fwd_multi(st, GATES_DEEP, B, Rq, cells));
     }
   }
   RUN("gather_q", 0, (double)B * Q * 8,
@@ -1133,46 +1155,63 @@ int rau_backward(rau_ctx* ctx, const float* hop_w) {
     RUNS(sw, "colsum", 0, (double)rows * A * 4, colsum_acc(sw, rows, A, ctx->du, A, ctx->att_i.db, ctx->coltmp3));
   }
 
-  // ---------------- encoder BPTT, SS:581-596
+  // ---------------- encoder BPTT, SS:581-596 -- the same two-layer wavefront, reversed:
+  // step u handles layer-2 cell u and layer-1 cell u+1; their incoming dh are the
+  // K-split partials of the previous step's dG (dG2 W_h2h2, dG2 W_i2h2 through the
+  // inter-layer dropout, dG1 W_h2h1), one batched GEMM, summed inside the cell kernel.
   if (TL > 0) {
     const int rows = TL * B;
-    for (int L = 1; L >= 0; --L) {
-      const float* G = L == 0 ? ctx->G1 : ctx->G2;
-      const float* cs = L == 0 ? ctx->c1 : ctx->c2;
-      const float* tcs = L == 0 ? ctx->tc1 : ctx->tc2;
-      float* dG = L == 0 ? ctx->dG1 : ctx->dG2;
-      const float* dc_n = nullptr;
-      int nsp = 0;  // split-K partials of dG_{t+1} W_h2h (= dh_t from the recurrence)
-      for (int t = TL; t >= 1; --t) {
-        float* dGt = dG + (size_t)(t - 1) * B * 4 * Rq;
-        float* dc_o = ctx->edc[L][t & 1];
-        RUN("lstm_bwd", 0, BRq * 4.0 * 12,
-            lstm_bwd(st, GATES_DEEP, B, Rq, G + (size_t)(t - 1) * B * 4 * Rq,
-                     cs + (size_t)(t - 1) * BRq, Rq, tcs + (size_t)(t - 1) * BRq, nullptr, Rq,
-                     L == 0 ? ctx->dX2 + (size_t)(t - 1) * BRq : nullptr, dc_n, dGt, dc_o,
-                     ctx->lens_d, t, ctx->dq + 2 * L * Rq, ctx->dq + (2 * L + 1) * Rq, Q, ctx->slab,
-                     nsp));
-        nsp = 0;
-        if (t > 1) {
-          LINOPTS(o);
-          o.defer_splits = &nsp;
-          RUN("enc_h2h_dgrad", gflop(B, Rq, 4 * Rq), 0,
-              gemm_nn(st, B, Rq, 4 * Rq, dGt, 4 * Rq, ctx->h2h[L].W, Rq, ctx->edh[L], Rq, o));
-        }
-        dc_n = dc_o;
+    const size_t G4 = (size_t)B * 4 * Rq;
+    for (int u = TL; u >= 0; --u) {
+      const float* Ap[3];
+      const float* Wp[3];
+      int nb = 0, iq2 = -1, iqx = -1, iq1 = -1;
+      if (u >= 1 && u + 1 <= TL) { Ap[nb] = ctx->dG2 + (size_t)u * G4; Wp[nb] = ctx->h2h[1].W; iq2 = nb++; }
+      if (u + 1 <= TL) { Ap[nb] = ctx->dG2 + (size_t)u * G4; Wp[nb] = ctx->i2h[1].W; iqx = nb++; }
+      if (u + 2 <= TL) { Ap[nb] = ctx->dG1 + (size_t)(u + 1) * G4; Wp[nb] = ctx->h2h[0].W; iq1 = nb++; }
+      int nsp = 0;
+      if (nb > 0)
+        RUN("enc_h2h_dgrad", gflop(B, Rq, 4 * Rq) * nb, 0,
+            gemm_nn_batched_deferred(st, nb, B, Rq, 4 * Rq, Ap, 4 * Rq, Wp, Rq, ctx->slab,
+                                     ctx->slab_floats, &nsp));
+      LstmBwdCells cells{};
+      cells.lens = ctx->lens_d;
+      cells.dq_rs = Q;
+      if (u >= 1) {  // layer-2 cell t = u
+        LstmBwdCell& C2 = cells.c[cells.n++];
+        C2.gates = ctx->G2 + (size_t)(u - 1) * G4;
+        C2.c_prev = ctx->c2 + (size_t)(u - 1) * BRq; C2.cp_rs = Rq;
+        C2.tanhc = ctx->tc2 + (size_t)(u - 1) * BRq;
+        C2.slabA = iq2 >= 0 ? ctx->slab + (size_t)iq2 * nsp * BRq : nullptr;
+        C2.nA = iq2 >= 0 ? nsp : 0;
+        C2.slabB = nullptr; C2.nBp = 0; C2.maskB = nullptr; C2.maskB_e0 = 0; C2.mscaleB = 1.f;
+        C2.dc_next = u < TL ? ctx->edc[1][(u + 1) & 1] : nullptr;
+        C2.dsum = ctx->dG2 + (size_t)(u - 1) * G4;
+        C2.dc_prev = ctx->edc[1][u & 1];
+        C2.t = u; C2.dq_c = ctx->dq + 2 * Rq; C2.dq_h = ctx->dq + 3 * Rq;
       }
-      if (L == 1) {  // gradient into layer 1's output through the inter-layer dropout
-        LINOPTS(o);
-        o.emask = m_rnn;
-        o.emask_e0 = 0;
-        o.emscale = sc(RAU_MASK_RNN);
-        RUN("enc_i2h_dgrad", gflop(rows, Rq, 4 * Rq), 0,
-            gemm_nn(st, rows, Rq, 4 * Rq, ctx->dG2, 4 * Rq, ctx->i2h[1].W, Rq, ctx->dX2, Rq, o));
-      } else {
-        LINOPTS(o);
-        RUN("enc_i2h_dgrad", gflop(rows, E, 4 * Rq), 0,
-            gemm_nn(st, rows, E, 4 * Rq, ctx->dG1, 4 * Rq, ctx->i2h[0].W, E, ctx->dwe, E, o));
+      if (u + 1 <= TL) {  // layer-1 cell t = u + 1
+        const int t = u + 1;
+        LstmBwdCell& C1 = cells.c[cells.n++];
+        C1.gates = ctx->G1 + (size_t)u * G4;
+        C1.c_prev = ctx->c1 + (size_t)u * BRq; C1.cp_rs = Rq;
+        C1.tanhc = ctx->tc1 + (size_t)u * BRq;
+        C1.slabA = iq1 >= 0 ? ctx->slab + (size_t)iq1 * nsp * BRq : nullptr;
+        C1.nA = iq1 >= 0 ? nsp : 0;
+        C1.slabB = ctx->slab + (size_t)iqx * nsp * BRq;   // dG2[t] W_i2h2, then the dropout mask
+        C1.nBp = nsp;
+        C1.maskB = m_rnn; C1.maskB_e0 = (size_t)u * BRq; C1.mscaleB = sc(RAU_MASK_RNN);
+        C1.dc_next = t < TL ? ctx->edc[0][(t + 1) & 1] : nullptr;
+        C1.dsum = ctx->dG1 + (size_t)u * G4;
+        C1.dc_prev = ctx->edc[0][t & 1];
+        C1.t = t; C1.dq_c = ctx->dq; C1.dq_h = ctx->dq + Rq;
       }
+      RUN("lstm_bwd", 0, BRq * 4.0 * 12 * cells.n, lstm_bwd_multi(st, GATES_DEEP, B, Rq, cells));
+    }
+    {  // gradient w.r.t. the word embeddings' tanh output, all tokens at once
+      LINOPTS(o);
+      RUN("enc_i2h_dgrad", gflop(rows, E, 4 * Rq), 0,
+          gemm_nn(st, rows, E, 4 * Rq, ctx->dG1, 4 * Rq, ctx->i2h[0].W, E, ctx->dwe, E, o));
     }
     RUN("embed_bwd", 0, (double)rows * E * 12,
         embed_bwd(st, ctx->nuniq, E, ctx->utok, ctx->ustart, ctx->upos, ctx->dwe, ctx->we, m_we,
