@@ -85,3 +85,15 @@ def test_zero_length_rows_and_hop_gating():
     sh = util.shapes(util.SMALL)
     lens = np.array([0, 6, 1, 3, 6, 2, 0, 4], np.int32)
     check(sh, lens=lens, hop_w=np.array([1.0, 0.0, 1.0], np.float32), scale=0.5)
+
+
+def test_resnet_like_channels_d2048():
+    """cnnout_dim = 2048 (Ours_ResNet, reference ResNet:38,217): long K loop in i_embed."""
+    dims = dict(B=6, T=4, V=40, E=200, Rq=32, D=2048, S=196, M=64, A=32, R=32, K=1000, H=2)
+    check(util.shapes(dims), scale=0.05)
+
+
+def test_batch_100_default_sizes_of_heads():
+    """opt.batch_size default 100 (SS:48): tile edges in every flattened-column GEMM."""
+    dims = dict(B=100, T=5, V=60, E=200, Rq=32, D=64, S=196, M=128, A=64, R=32, K=1000, H=2)
+    check(util.shapes(dims), scale=0.1)
