@@ -253,13 +253,18 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams P) {
   constexpr int WM = BM / 2, WN = BN / 2;   // wave tile
   constexpr int IM = WM / 32, JN = WN / 32; // 32x32 blocks per wave
   constexpr int LDA = BM + LPAD, LDB = BN + LPAD;
-  constexpr int kStage = 2 * BK * LDA + 2 * BK * LDB;  // floats of operand staging
+  // 128-wide (bulk) tiles double-buffer their LDS stages; the 64-wide chain tiles keep ONE
+  // stage (8.7 KB): next to two resident bulk workgroups (2 x 67.6 of 160 KB) only a
+  // footprint under 12 KB lets two chain workgroups share a CU, and these launches are
+  // latency-bound, so the second barrier per K-step costs nothing measurable.
+  constexpr int NST = BM >= 128 ? 2 : 1;
+  constexpr int kStage = NST * BK * LDA + NST * BK * LDB;  // floats of operand staging
   // epilogue scratch lives in the (then idle) staging area: per-row vectors,
   // per-(sample,row) vectors of the samples this tile's columns touch, column sums
   constexpr int kUCap = kStage - BM;
   __shared__ __attribute__((aligned(16))) float smem[kStage];
   float* As = smem;
-  float* Bs = smem + 2 * BK * LDA;
+  float* Bs = smem + NST * BK * LDA;
 
   const int tid = threadIdx.x;
   const int l = tid & 63, w = tid >> 6;
@@ -337,16 +342,17 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams P) {
     }
     __syncthreads();
     for (int it = 0; it < nsteps; ++it) {
-      const int cur = it & 1;
+      const int cur = NST == 2 ? (it & 1) : 0;
       const bool more = it + 1 < nsteps;
       if (more && !(P.dbg & 1)) {
         LA.template load<FAST>(step0 + it + 1, ra0);
         LB.template load<FAST>(step0 + it + 1, rb0);
       }
       compute(cur);
+      if (NST == 1) __syncthreads();   // everyone is done reading the single stage
       if (more && !(P.dbg & 1)) {
-        LA.store(As + (cur ^ 1) * BK * LDA, tid, ra0);
-        LB.store(Bs + (cur ^ 1) * BK * LDB, tid, rb0);
+        LA.store(As + (NST == 2 ? (cur ^ 1) * BK * LDA : 0), tid, ra0);
+        LB.store(Bs + (NST == 2 ? (cur ^ 1) * BK * LDB : 0), tid, rb0);
       }
       if (!(P.dbg & 2)) __syncthreads();
     }

@@ -88,9 +88,9 @@ int main(int argc, char** argv) {
       float* xd8; CK(hipMalloc(&xd8, (size_t)8 * B * D * S * 4)); CK(hipMemset(xd8, 0, (size_t)8 * B * D * S * 4));
       float* I8; CK(hipMalloc(&I8, (size_t)8 * B * M * S * 4));
       P8.B = xd8; P8.C = I8; P8.c_bs = (long)M * S; P8.bias = bi; P8.act = 1;
-      for (int dbg : {0, 0}) {
+      for (int dbg : {0, 1, 2, 3, 0}) {
         P8.dbg = dbg;
-        char nm[64]; snprintf(nm, 64, "v: embed_fwd x8 stagger=%d", dbg >> 4);
+        char nm[64]; snprintf(nm, 64, "v: embed_fwd x8 dbg=%d", dbg);
         report(nm, timeit(st, 5, [&] { return launch_gemm<128, 128, 32, SRC_RC, SRC_RC_FLAT, EPI_CONV>(st, P8, 1); }), 2.0 * M * NS * D * 8);
       }
       CK(hipFree(xd8)); CK(hipFree(I8));
