@@ -1,6 +1,8 @@
 // gemm_conv.hip -- the two per-position 1x1 convolutions of the RAU and their
 // gradients as flattened-(sample,position) GEMMs on the f32-MFMA engine.
 // These carry ~94% of the path's FLOPs.
+#include <cstdlib>
+
 #include "gemm_core.h"
 #include "kernels.h"
 
@@ -62,7 +64,12 @@ hipError_t conv_att_dgrad(hipStream_t st, int nB, int M, int S, int A, const flo
 
 static int conv_wgrad_splits(int nB, int rowsA, int rowsB) {
   const int tiles = ((rowsA + 127) / 128) * ((rowsB + 127) / 128);
-  int s = 1024 / tiles;
+  static const int target = [] {  // tuning knob: workgroups a conv weight-gradient launch aims for
+    const char* e = std::getenv("RAU_WGRAD_WGS");
+    const int v = e ? std::atoi(e) : 0;
+    return v > 0 ? v : 512;   // = one resident wave of workgroups (2 per CU x 256 CUs)
+  }();
+  int s = target / tiles;
   if (s > nB) s = nB;
   if (s < 1) s = 1;
   return s;

@@ -1,6 +1,8 @@
 // gemm_lin.hip -- Linear-layer GEMMs on the f32-MFMA engine (gemm_core.h):
 // forward y = x W^T (gemm_nt), input gradient dx = dy W (gemm_nn) and the
 // deterministic split-K weight gradient dW += dy^T x (gemm_tn_acc).
+#include <cstdlib>
+
 #include "gemm_core.h"
 #include "kernels.h"
 
@@ -30,13 +32,20 @@ static GemmParams lin_params(int M, int N, int K, const float* A, long lda, cons
 }
 
 // Skinny problems (few output tiles, long K) are latency-bound per workgroup, so
-// they are split over K across workgroups until the grid covers the chip; the
+// they are split over K across workgroups -- but only up to ~160 workgroups: they
+// run next to the bulk GEMMs, and more (shorter) workgroups disturb those more than
+// they shorten the chain (sweep: 128-192 best, 384 +2%, no split +16%).  The
 // partials are combined by lin_reduce_epilogue in fixed order.
 static int skinny_splits(int M, int N, int K, const LinOpts& o) {
   if (!o.slab) return 1;
   const int tiles = ((M + 63) / 64) * ((N + 63) / 64);
   const int nk = (K + BKS - 1) / BKS;
-  int s = (384 + tiles - 1) / tiles;
+  static const int target = [] {  // tuning knob: workgroups a skinny launch aims for
+    const char* e = std::getenv("RAU_SKINNY_WGS");
+    const int v = e ? std::atoi(e) : 0;
+    return v > 0 ? v : 160;
+  }();
+  int s = (target + tiles - 1) / tiles;
   if (s > nk / 2) s = nk / 2;
   if (s < 1) s = 1;
   while (s > 1 && (size_t)s * M * N > o.slab_floats) --s;
@@ -118,7 +127,12 @@ hipError_t gemm_nn_batched_deferred(hipStream_t st, int nb, int M, int N, int K,
 static int tn_splits(int M, int N, int K) {
   const int tiles = ((M + 127) / 128) * ((N + 127) / 128);
   const int nk = (K + BK - 1) / BK;
-  int s = 512 / tiles;
+  static const int target = [] {  // tuning knob: workgroups a Linear weight-gradient launch aims for
+    const char* e = std::getenv("RAU_TN_WGS");
+    const int v = e ? std::atoi(e) : 0;
+    return v > 0 ? v : 512;
+  }();
+  int s = target / tiles;
   if (s > nk / 8) s = nk / 8;
   if (s < 1) s = 1;
   const int per = (nk + s - 1) / s;
