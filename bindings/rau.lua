@@ -45,6 +45,24 @@ int rau_set_batch(rau_ctx* ctx, const float* feats, const int32_t* tokens,
 int rau_batch_feats(rau_ctx* ctx, float** feats_dev);
 int rau_forward(rau_ctx* ctx);
 int rau_backward(rau_ctx* ctx, const float* hop_w);
+int rau_embed_forward(rau_ctx* ctx, int t, const int32_t* tokens_dev, float** we);
+int rau_embed_backward(rau_ctx* ctx, int t, const int32_t* tokens_dev, const float* d_we);
+int rau_deeplstm_forward(rau_ctx* ctx, int t, const float* x, const float* state,
+                         float** state_out);
+int rau_deeplstm_backward(rau_ctx* ctx, int t, const float* x, const float* state,
+                          const float* d_state_out, float** d_x, float** d_state);
+int rau_multimodal_forward(rau_ctx* ctx, int h, const float* q, const float* X,
+                           const float* c_prev, const float* h_prev, float** logits,
+                           float** do_pred, float** attprob, float** c_out, float** h_out);
+int rau_multimodal_backward(rau_ctx* ctx, int h, const float* q, const float* X,
+                            const float* c_prev, const float* h_prev, const float* d_logits,
+                            const float* d_do_pred, const float* d_attprob,
+                            const float* d_c, const float* d_h, float** d_q, float** d_X,
+                            float** d_c_prev, float** d_h_prev);
+int rau_criterion_forward(rau_ctx* ctx, int h, const float* logits, const int32_t* labels_dev,
+                          float* loss);
+int rau_criterion_backward(rau_ctx* ctx, int h, const float* logits,
+                           const int32_t* labels_dev, float scale, float** d_logits);
 int rau_sync(rau_ctx* ctx);
 int rau_get_losses(rau_ctx* ctx, float* losses);
 int rau_get_argmax(rau_ctx* ctx, int32_t* ans);
@@ -136,5 +154,69 @@ function RAU:answers(out) check(C.rau_get_argmax(self.h, out:data())); return ou
 function RAU:logits(out) check(C.rau_get_logits(self.h, out:data())); return out end
 function RAU:attention(out) check(C.rau_get_attention(self.h, out:data())); return out end
 function RAU:sync() check(C.rau_sync(self.h)) end
+
+-- Module-level clones ---------------------------------------------------------
+-- For scripts that keep feval's own loops (SS:443-596).  Arguments and results are
+-- device float* / int32_t* (cdata); a result points into a ctx-owned slot that stays
+-- valid until the same clone runs again (the lifetime of nn.Module's self.output).
+-- Indices are 1-based like embed_clones[t] / lstm_clones[t] / multimodal_clones[h].
+local function clone(self, kind, i)
+  local m = { rau = self, i = i - 1 }
+  if kind == 'embed' then
+    function m:forward(x_t)
+      local o = ffi.new('float*[1]')
+      check(C.rau_embed_forward(self.rau.h, self.i, x_t, o)); self.output = o[0]
+      return self.output
+    end
+    function m:backward(x_t, d_we) check(C.rau_embed_backward(self.rau.h, self.i, x_t, d_we)) end
+  elseif kind == 'rnn' then
+    function m:forward(inp)   -- {x, state}
+      local o = ffi.new('float*[1]')
+      check(C.rau_deeplstm_forward(self.rau.h, self.i, inp[1], inp[2], o)); self.output = o[0]
+      return self.output
+    end
+    function m:backward(inp, d_state_out)
+      local dx, ds = ffi.new('float*[1]'), ffi.new('float*[1]')
+      check(C.rau_deeplstm_backward(self.rau.h, self.i, inp[1], inp[2], d_state_out, dx, ds))
+      self.gradInput = { dx[0], ds[0] }
+      return self.gradInput
+    end
+  elseif kind == 'multimodal' then
+    function m:forward(inp)   -- {q, X, c, h}
+      local o = {}
+      for k = 1, 5 do o[k] = ffi.new('float*[1]') end
+      check(C.rau_multimodal_forward(self.rau.h, self.i, inp[1], inp[2], inp[3], inp[4],
+                                     o[1], o[2], o[3], o[4], o[5]))
+      self.output = { o[1][0], o[2][0], o[3][0], o[4][0], o[5][0] }  -- {logits, dp, a, c, h}
+      return self.output
+    end
+    function m:backward(inp, g)   -- g = {d_logits, d_do_pred|nil, d_attprob|nil, d_c, d_h}
+      local o = {}
+      for k = 1, 4 do o[k] = ffi.new('float*[1]') end
+      check(C.rau_multimodal_backward(self.rau.h, self.i, inp[1], inp[2], inp[3], inp[4],
+                                      g[1], g[2], g[3], g[4], g[5], o[1], nil, o[3], o[4]))
+      self.gradInput = { o[1][0], nil, o[3][0], o[4][0] }   -- {d_q, (d_X dead, SS:579), d_c, d_h}
+      return self.gradInput
+    end
+  elseif kind == 'criterion' then
+    function m:forward(logits, y)
+      local l = ffi.new('float[1]')
+      check(C.rau_criterion_forward(self.rau.h, self.i, logits, y, l))
+      return l[0]
+    end
+    function m:backward(logits, y, scale)
+      local o = ffi.new('float*[1]')
+      check(C.rau_criterion_backward(self.rau.h, self.i, logits, y, scale or 1, o))
+      return o[0]
+    end
+  end
+  function m:training() self.rau:training() end
+  function m:evaluate() self.rau:evaluate() end
+  return m
+end
+function RAU:embedClone(t) return clone(self, 'embed', t) end
+function RAU:rnnClone(t) return clone(self, 'rnn', t) end
+function RAU:multimodalClone(h) return clone(self, 'multimodal', h) end
+function RAU:criterion(h) return clone(self, 'criterion', h) end
 
 return RAU

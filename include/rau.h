@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define RAU_ABI_VERSION 1
+#define RAU_ABI_VERSION 2
 
 typedef enum rau_status {
   RAU_OK = 0,
@@ -155,6 +155,59 @@ int rau_batch_feats(rau_ctx* ctx, float** feats_dev);
  *               buffers like accGradParameters; call rau_zero_grads first. */
 int rau_forward(rau_ctx* ctx);
 int rau_backward(rau_ctx* ctx, const float* hop_w /* [H] host */);
+
+/* ---- module-level entry points: one call per nn.Module :forward / :backward -----
+ * For hosts that keep feval's own loops (SS:443-596) and call the clones one by one.
+ * t in [0,T) / h in [0,H) select the clone (the reference's embed_clones[t+1],
+ * lstm_clones[t+1], multimodal_clones[h+1], criteria[h+1]; SS:340-347): it fixes the
+ * clone's dropout-mask slice and the ctx-owned slot its activations are saved in.
+ * All tensor arguments are DEVICE pointers (16-byte aligned, dense row-major), in the
+ * reference's table orders; NULL for an optional input means "zeros" (or, for tokens /
+ * X / labels, "the resident batch of rau_set_batch").  Outputs are returned as
+ * pointers to ctx-owned slots indexed by (t|h): valid until the next :forward /
+ * :backward of the same clone -- the lifetime rule of nn.Module's self.output /
+ * self.gradInput.  :backward ACCUMULATES the clone's parameter gradients into the flat
+ * gradient buffers (accGradParameters).  Work is enqueued on the ctx stream; nothing
+ * synchronises except rau_criterion_forward when `loss` is non-NULL.
+ * The step-level rau_forward/rau_backward above compute the same values faster
+ * (they batch across clones); do not interleave the two within one step. */
+
+/* word_embed = LookupTable -> Dropout(0.5) -> Tanh, SS:203-206; :forward SS:451,
+ * :backward SS:593 (LookupTable has no gradInput).  tokens_dev [B] int32 1-based. */
+int rau_embed_forward(rau_ctx* ctx, int t, const int32_t* tokens_dev, float** we /* [B,E] */);
+int rau_embed_backward(rau_ctx* ctx, int t, const int32_t* tokens_dev, const float* d_we);
+
+/* DeepLSTM.create(E, Rq, 2, 0.5), model/DeepLSTM.lua:14-71: {x [B,E], state [B,4Rq] =
+ * [c1 h1 c2 h2]} -> state' [B,4Rq]; :forward SS:452, :backward SS:592 returning
+ * {d_x [B,E], d_state [B,4Rq]}.  The length-select / dq row replacement of SS:455-461,
+ * 584-591 stays in the host loop, as in the reference. */
+int rau_deeplstm_forward(rau_ctx* ctx, int t, const float* x, const float* state,
+                         float** state_out);
+int rau_deeplstm_backward(rau_ctx* ctx, int t, const float* x, const float* state,
+                          const float* d_state_out, float** d_x, float** d_state);
+
+/* protos.multimodal, SS:292-307: {q [B,4Rq], X [B,D,S], c [B,R], h [B,R]} ->
+ * {logits [B,K], do_pred [B], attprob [B,S], c' [B,R], h' [B,R]}; :forward SS:480,
+ * :backward SS:571 with gradOutput {d_logits, d_do_pred, d_attprob, d_c, d_h}
+ * (d_do_pred / d_attprob may be NULL = zeros, which is what feval passes, SS:566,573)
+ * returning {d_q, d_X, d_c, d_h}.  d_X is the gradient feval discards (SS:579): pass
+ * d_X = NULL to skip computing it. */
+int rau_multimodal_forward(rau_ctx* ctx, int h, const float* q, const float* X,
+                           const float* c_prev, const float* h_prev, float** logits,
+                           float** do_pred, float** attprob, float** c_out, float** h_out);
+int rau_multimodal_backward(rau_ctx* ctx, int h, const float* q, const float* X,
+                            const float* c_prev, const float* h_prev, const float* d_logits,
+                            const float* d_do_pred, const float* d_attprob,
+                            const float* d_c, const float* d_h, float** d_q, float** d_X,
+                            float** d_c_prev, float** d_h_prev);
+
+/* nn.CrossEntropyCriterion (sizeAverage), SS:310: :forward SS:518 -> *loss (host,
+ * may be NULL); :backward SS:565-569 -> d_logits [B,K] = scale*(softmax-onehot)/B,
+ * scale = the dpred:mul(w) of SS:569.  labels_dev [B] int32 1-based. */
+int rau_criterion_forward(rau_ctx* ctx, int h, const float* logits, const int32_t* labels_dev,
+                          float* loss);
+int rau_criterion_backward(rau_ctx* ctx, int h, const float* logits,
+                           const int32_t* labels_dev, float scale, float** d_logits);
 
 /* ---- results (valid after rau_sync; these calls synchronise themselves) ------ */
 int rau_sync(rau_ctx* ctx);

@@ -70,6 +70,21 @@ _SIGS = {
     "rau_batch_feats": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
     "rau_forward": (C.c_int, [C.c_void_p]),
     "rau_backward": (C.c_int, [C.c_void_p, C.c_void_p]),
+    # module-level entry points: device pointers in, pointers to ctx-owned slots out
+    "rau_embed_forward": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "rau_embed_backward": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "rau_deeplstm_forward": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                       C.POINTER(C.c_void_p)]),
+    "rau_deeplstm_backward": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
+    "rau_multimodal_forward": (C.c_int, [C.c_void_p, C.c_int] + [C.c_void_p] * 4 +
+                               [C.POINTER(C.c_void_p)] * 5),
+    "rau_multimodal_backward": (C.c_int, [C.c_void_p, C.c_int] + [C.c_void_p] * 9 +
+                                [C.POINTER(C.c_void_p)] * 4),
+    "rau_criterion_forward": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                        C.POINTER(C.c_float)]),
+    "rau_criterion_backward": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_float,
+                                         C.POINTER(C.c_void_p)]),
     "rau_sync": (C.c_int, [C.c_void_p]),
     "rau_get_losses": (C.c_int, [C.c_void_p, C.c_void_p]),
     "rau_get_argmax": (C.c_int, [C.c_void_p, C.c_void_p]),

@@ -62,6 +62,22 @@ hipError_t conv_att_dgrad(hipStream_t st, int nB, int M, int S, int A, const flo
   return launch_gemm<128, 128, BK, SRC_RC, SRC_RC_FLAT, EPI_OUTER>(st, P, 1);
 }
 
+// dX'[b,d,s] = sum_m Wi[m,d] dZ[b,m,s]: gradient w.r.t. i_embed's (dropped-out) input.  The
+// reference computes it and discards it (SS:579); only the module-level
+// rau_multimodal_backward forms it, and only on request.
+hipError_t conv_embed_dgrad(hipStream_t st, int nB, int D, int S, int M, const float* dZ,
+                            const float* Wi, float* dX) {
+  GemmParams P{};
+  P.M = D; P.N = nB * S; P.K = M; P.nk = (M + BK - 1) / BK;
+  P.A = Wi; P.a_rs = D;                 // Wi stored [M][D]: reduction-major, d contiguous
+  P.B = dZ; P.b_rs = S; P.b_bs = (long)M * S;
+  P.S = S;
+  P.C = dX; P.c_bs = (long)D * S;
+  P.bias = nullptr;
+  P.act = 0;
+  return launch_gemm<128, 128, BK, SRC_RC, SRC_RC_FLAT, EPI_CONV>(st, P, 1);
+}
+
 static int conv_wgrad_splits(int nB, int rowsA, int rowsB) {
   const int tiles = ((rowsA + 127) / 128) * ((rowsB + 127) / 128);
   static const int target = [] {  // tuning knob: workgroups a conv weight-gradient launch aims for

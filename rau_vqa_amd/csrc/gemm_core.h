@@ -416,7 +416,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams P) {
     const bool staged = nsamp * BM <= kUCap;
     if (tid < BM) {
       const int m = m0 + tid;
-      rowv[tid] = (EPI == EPI_CONV && m < P.M) ? P.bias[m] : 0.f;
+      rowv[tid] = (EPI == EPI_CONV && m < P.M && P.bias) ? P.bias[m] : 0.f;
     }
     if (EPI == EPI_OUTER && staged)
       for (int e = tid; e < nsamp * BM; e += 256) {

@@ -64,6 +64,9 @@ hipError_t transpose2d(hipStream_t st, int rows, int cols, const float* in, floa
 // dI[b,m,s] = sum_k Wp[k,m] dS[b,k,s] + dj[b,m] a[b,s]   (gradient at i_embed's output)
 hipError_t conv_att_dgrad(hipStream_t st, int nB, int M, int S, int A, const float* dS,
                           const float* Wp, const float* dj, const float* a, float* dI);
+// dX'[b,d,s] = sum_m Wi[m,d] dZ[b,m,s]   (dead in feval, SS:579; module-level API only)
+hipError_t conv_embed_dgrad(hipStream_t st, int nB, int D, int S, int M, const float* dZ,
+                            const float* Wi, float* dX);
 // dWp[k,m] += sum_{b,s} dS[b,k,s] I[b,m,s]   and, with dZ = dI (1 - I^2),
 // dWi[m,d] += sum_{b,s} dZ[b,m,s] X'[b,d,s]
 size_t conv_wgrad_slab_floats(int nB, int rowsA, int rowsB, int S);
@@ -79,7 +82,10 @@ enum GateOrder { GATES_ATT = 0 /* i g f o, ATTLSTM.lua:12-19 */,
 hipError_t fill_masks(hipStream_t st, uint64_t seed, uint32_t site, uint32_t step, float p,
                       size_t n, uint32_t* bits);
 hipError_t embed_fwd(hipStream_t st, int rows, int E, const float* emb, const int32_t* tokens,
-                     const uint32_t* mask, float mscale, float* we);
+                     const uint32_t* mask, float mscale, float* we, size_t mask_e0 = 0);
+hipError_t embed_bwd_rows(hipStream_t st, int rows, int E, const int32_t* tokens, const float* dwe,
+                          const float* we, const uint32_t* mask, size_t mask_e0, float mscale,
+                          float* gE);
 // in place on g4: pre-activations (+ sum of `nsplit` split-K partials [nB,4R] in `slab`)
 // -> activated gates; c = f c_prev + i g; h = o tanh c
 hipError_t lstm_fwd(hipStream_t st, int order, int nB, int R, float* g4, const float* c_prev,
@@ -129,13 +135,14 @@ hipError_t att_bwd_fused(hipStream_t st, int nB, int M, int A, int S, const floa
                          const float* ws, float* T_to_dS, float* dz, float* du, float* dwsp);
 // xd[h][i] = X[i] * keep(h, i) * scale for h < H, i < per_hop (feature-map dropout, SS:239)
 hipError_t dropout_features(hipStream_t st, int H, size_t per_hop, const float* X,
-                            const uint32_t* mask, float mscale, float* xd);
+                            const uint32_t* mask, float mscale, float* xd, size_t mask_e0 = 0);
 // rs[row] = sum_s X[row, s] * (1 - Y[row, s]^2)   (Y = nullptr: plain row sums)
 hipError_t row_sums(hipStream_t st, int rows, int S, const float* X, const float* Y, float* rs);
 // dst[n] += sum_rows X[row*ld + n]   (two-stage, deterministic; tmp >= 32*N floats)
 hipError_t colsum_acc(hipStream_t st, int rows, int N, const float* X, long ld, float* dst,
                       float* tmp);
 // per-row CE: argmax (1-based, first max), loss row, dl = (softmax - onehot)/nB, do_pred
+// (labels == nullptr: no loss/dl; mf == nullptr: no do_pred)
 hipError_t ce_fwd(hipStream_t st, int nB, int K, int M, const float* logits,
                   const int32_t* labels, const float* mf, const float* wd, const float* bd,
                   float* dl, float* lossrow, int32_t* argmax, float* dopred);
@@ -144,7 +151,13 @@ hipError_t scale_hops(hipStream_t st, int H, size_t per_hop, const float* w_dev,
 hipError_t gather_q(hipStream_t st, int nB, int Rq, int T, const int32_t* lens, const float* c1,
                     const float* h1, const float* c2, const float* h2, float* q);
 hipError_t apply_mask(hipStream_t st, size_t n, size_t period, const float* x,
-                      const uint32_t* mask, float mscale, float* y);
+                      const uint32_t* mask, float mscale, float* y, size_t mask_e0 = 0);
+// module-level helpers: out[r,n] = s[r] (X ? X[r,n] : 1) (v ? v[n] : 1); sigmoid / tanh backward
+hipError_t row_scale(hipStream_t st, int rows, int N, const float* s, const float* X,
+                     const float* v, float* out);
+hipError_t sigmoid_bwd(hipStream_t st, int n, const float* dy, const float* y, float* dx);
+hipError_t mul_dtanh(hipStream_t st, size_t n, const float* d, const float* y, float* out);
+hipError_t scale_inplace(hipStream_t st, size_t n, float s, float* x);
 // dq[i] = sum_h dQD[h][i] * mask_h[i] * scale
 hipError_t dq_reduce(hipStream_t st, int H, size_t n, const float* dQD, const uint32_t* mask,
                      float mscale, float* dq);

@@ -58,7 +58,7 @@ hipError_t uniform_fill(hipStream_t st, uint64_t seed, uint32_t stream, size_t n
 // we[row, e] = tanh(drop(E[token[row]-1, e]))      reference SS:203-206
 __global__ void k_embed_fwd(int rows, int E, const float* __restrict__ emb,
                             const int32_t* __restrict__ tokens,
-                            const uint32_t* __restrict__ mask, float mscale,
+                            const uint32_t* __restrict__ mask, size_t mask_e0, float mscale,
                             float* __restrict__ we) {
   RAU_CHAIN_PRIO();
   const size_t n = (size_t)rows * E;
@@ -66,14 +66,38 @@ __global__ void k_embed_fwd(int rows, int E, const float* __restrict__ emb,
        i += (size_t)gridDim.x * blockDim.x) {
     const int row = (int)(i / E), e = (int)(i - (size_t)row * E);
     float v = emb[(size_t)(tokens[row] - 1) * E + e];
-    if (mask) v = mask_bit(mask, i) ? v * mscale : 0.f;
+    if (mask) v = mask_bit(mask, mask_e0 + i) ? v * mscale : 0.f;
     we[i] = tanh_fast(v);
   }
 }
 hipError_t embed_fwd(hipStream_t st, int rows, int E, const float* emb, const int32_t* tokens,
-                     const uint32_t* mask, float mscale, float* we) {
+                     const uint32_t* mask, float mscale, float* we, size_t mask_e0) {
   hipLaunchKernelGGL(k_embed_fwd, dim3(grid_for((size_t)rows * E)), dim3(256), 0, st, rows, E,
-                     emb, tokens, mask, mscale, we);
+                     emb, tokens, mask, mask_e0, mscale, we);
+  return hipGetLastError();
+}
+
+// LookupTable gradient of ONE token row set (module-level word_embed:backward, SS:593):
+// thread e walks the rows in order, so repeated tokens accumulate deterministically.
+__global__ void k_embed_bwd_rows(int rows, int E, const int32_t* __restrict__ tokens,
+                                 const float* __restrict__ dwe, const float* __restrict__ we,
+                                 const uint32_t* __restrict__ mask, size_t mask_e0, float mscale,
+                                 float* __restrict__ gE) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= E) return;
+  for (int r = 0; r < rows; ++r) {
+    const size_t i = (size_t)r * E + e;
+    const float y = we[i];
+    float d = dwe[i] * (1.f - y * y);
+    if (mask) d = mask_bit(mask, mask_e0 + i) ? d * mscale : 0.f;
+    gE[(size_t)(tokens[r] - 1) * E + e] += d;
+  }
+}
+hipError_t embed_bwd_rows(hipStream_t st, int rows, int E, const int32_t* tokens, const float* dwe,
+                          const float* we, const uint32_t* mask, size_t mask_e0, float mscale,
+                          float* gE) {
+  hipLaunchKernelGGL(k_embed_bwd_rows, dim3((E + 63) / 64), dim3(64), 0, st, rows, E, tokens, dwe,
+                     we, mask, mask_e0, mscale, gE);
   return hipGetLastError();
 }
 
@@ -536,13 +560,13 @@ hipError_t transpose2d(hipStream_t st, int rows, int cols, const float* in, floa
 
 // feature-map dropout for every hop in one pass (reference SS:239, one mask per clone)
 __global__ void k_dropout_features(int H, size_t per4, const float4* __restrict__ X,
-                                   const uint32_t* __restrict__ mask, float mscale,
+                                   const uint32_t* __restrict__ mask, size_t e0, float mscale,
                                    float4* __restrict__ xd) {
   for (size_t q = blockIdx.x * (size_t)blockDim.x + threadIdx.x; q < per4;
        q += (size_t)gridDim.x * blockDim.x) {
     const float4 x = X[q];
     for (int h = 0; h < H; ++h) {
-      const size_t e = ((size_t)h * per4 + q) * 4;
+      const size_t e = e0 + ((size_t)h * per4 + q) * 4;
       const uint32_t nib = mask_nib(mask, e);
       float4 o;
       o.x = (nib & 1u) ? x.x * mscale : 0.f;
@@ -554,9 +578,9 @@ __global__ void k_dropout_features(int H, size_t per4, const float4* __restrict_
   }
 }
 hipError_t dropout_features(hipStream_t st, int H, size_t per_hop, const float* X,
-                            const uint32_t* mask, float mscale, float* xd) {
+                            const uint32_t* mask, float mscale, float* xd, size_t mask_e0) {
   hipLaunchKernelGGL(k_dropout_features, dim3(grid_for(per_hop / 4)), dim3(256), 0, st, H,
-                     per_hop / 4, reinterpret_cast<const float4*>(X), mask, mscale,
+                     per_hop / 4, reinterpret_cast<const float4*>(X), mask, mask_e0, mscale,
                      reinterpret_cast<float4*>(xd));
   return hipGetLastError();
 }
@@ -674,6 +698,7 @@ __global__ void k_ce_fwd(int nB, int K, int M, const float* __restrict__ logits,
     if (tid == 0) lossrow[b] = lse - lg[y];
   }
   // do_pred
+  if (!mf) return;   // criterion-only use (uniform per launch)
   float acc = 0.f;
   for (int m = tid; m < M; m += 256) acc += mf[(size_t)b * M + m] * wd[m];
   acc = wave_sum(acc);
@@ -743,19 +768,80 @@ hipError_t gather_q(hipStream_t st, int nB, int Rq, int T, const int32_t* lens, 
 
 // y[i] = x[i % period] * mask(i) * scale      (i over n; mask may be null)
 __global__ void k_apply_mask(size_t n, size_t period, const float* __restrict__ x,
-                             const uint32_t* __restrict__ mask, float mscale,
+                             const uint32_t* __restrict__ mask, size_t e0, float mscale,
                              float* __restrict__ y) {
   RAU_CHAIN_PRIO();
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n;
        i += (size_t)gridDim.x * blockDim.x) {
     const float v = x[i % period];
-    y[i] = mask ? (mask_bit(mask, i) ? v * mscale : 0.f) : v;
+    y[i] = mask ? (mask_bit(mask, e0 + i) ? v * mscale : 0.f) : v;
   }
 }
 hipError_t apply_mask(hipStream_t st, size_t n, size_t period, const float* x,
-                      const uint32_t* mask, float mscale, float* y) {
+                      const uint32_t* mask, float mscale, float* y, size_t mask_e0) {
   hipLaunchKernelGGL(k_apply_mask, dim3(grid_for(n)), dim3(256), 0, st, n, period, x, mask,
-                     mscale, y);
+                     mask_e0, mscale, y);
+  return hipGetLastError();
+}
+
+// ---- small helpers of the module-level entry points (rau_modules.hip)
+// out[r, n] = s[r] * (X ? X[r, n] : 1) * (v ? v[n] : 1)
+__global__ void k_row_scale(int rows, int N, const float* __restrict__ s,
+                            const float* __restrict__ X, const float* __restrict__ v,
+                            float* __restrict__ out) {
+  const size_t n = (size_t)rows * N;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const int r = (int)(i / N), col = (int)(i - (size_t)r * N);
+    float o = s[r];
+    if (X) o *= X[i];
+    if (v) o *= v[col];
+    out[i] = o;
+  }
+}
+hipError_t row_scale(hipStream_t st, int rows, int N, const float* s, const float* X,
+                     const float* v, float* out) {
+  hipLaunchKernelGGL(k_row_scale, dim3(grid_for((size_t)rows * N)), dim3(256), 0, st, rows, N, s,
+                     X, v, out);
+  return hipGetLastError();
+}
+// s[b] = ddp[b] * dp[b] (1 - dp[b])      (Sigmoid backward of out_do_pred, SS:281-282)
+__global__ void k_sigmoid_bwd(int n, const float* __restrict__ dy, const float* __restrict__ y,
+                              float* __restrict__ dx) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dx[i] = dy[i] * y[i] * (1.f - y[i]);
+}
+hipError_t sigmoid_bwd(hipStream_t st, int n, const float* dy, const float* y, float* dx) {
+  hipLaunchKernelGGL(k_sigmoid_bwd, dim3((n + 255) / 256), dim3(256), 0, st, n, dy, y, dx);
+  return hipGetLastError();
+}
+// out[i] = dI[i] * (1 - I[i]^2)   (Tanh backward of i_embed, materialised for the feature-map gradient)
+__global__ void k_mul_dtanh(size_t n4, const float4* __restrict__ d, const float4* __restrict__ y,
+                            float4* __restrict__ out) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const float4 a = d[i], b = y[i];
+    float4 o;
+    o.x = a.x * (1.f - b.x * b.x);
+    o.y = a.y * (1.f - b.y * b.y);
+    o.z = a.z * (1.f - b.z * b.z);
+    o.w = a.w * (1.f - b.w * b.w);
+    out[i] = o;
+  }
+}
+hipError_t mul_dtanh(hipStream_t st, size_t n, const float* d, const float* y, float* out) {
+  hipLaunchKernelGGL(k_mul_dtanh, dim3(grid_for(n / 4)), dim3(256), 0, st, n / 4,
+                     reinterpret_cast<const float4*>(d), reinterpret_cast<const float4*>(y),
+                     reinterpret_cast<float4*>(out));
+  return hipGetLastError();
+}
+__global__ void k_scale_inplace(size_t n, float s, float* __restrict__ x) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n;
+       i += (size_t)gridDim.x * blockDim.x)
+    x[i] *= s;
+}
+hipError_t scale_inplace(hipStream_t st, size_t n, float s, float* x) {
+  hipLaunchKernelGGL(k_scale_inplace, dim3(grid_for(n)), dim3(256), 0, st, n, s, x);
   return hipGetLastError();
 }
 

@@ -1,0 +1,237 @@
+// rau_ctx.h -- the rau_ctx object shared by the translation units that implement
+// include/rau.h (internal to librau.so; not installed).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "../../include/rau.h"
+#include "kernels.h"
+
+using namespace rau;
+
+// LinOpts pre-wired with the ctx's split-K workspace
+#define LINOPTS(name) LinOpts name; name.slab = ctx->slab; name.slab_floats = ctx->slab_floats
+
+// ------------------------------------------------------------------ errors
+// sets the calling thread's rau_last_error() message and returns `code`
+__attribute__((visibility("hidden"))) int fail(int code, const char* fmt, ...);
+#define HIPC(expr)                                                                        \
+  do {                                                                                    \
+    hipError_t e_ = (expr);                                                               \
+    if (e_ != hipSuccess)                                                                 \
+      return fail(RAU_ERR_DEVICE, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_),  \
+                  __FILE__, __LINE__);                                                    \
+  } while (0)
+#define NEED(cond, ...)                               \
+  do {                                                \
+    if (!(cond)) return fail(RAU_ERR_INVALID, __VA_ARGS__); \
+  } while (0)
+
+// ------------------------------------------------------------------ ctx
+struct Lin {  // one Linear (or 1x1 conv) inside a flat group
+  float *W, *b, *dW, *db;
+  int out, in;
+};
+struct Entry {
+  std::string name;
+  size_t off;
+  int rows, cols;
+};
+struct Group {
+  float* w = nullptr;
+  float* g = nullptr;
+  float* m = nullptr;  // Adam moments (allocated on first update)
+  float* v = nullptr;
+  size_t n = 0;
+  int64_t adam_t = 0;
+  std::vector<Entry> layout;
+};
+struct ProfRec {
+  int cls;
+  hipEvent_t a, b;
+};
+struct ProfCls {
+  std::string name;
+  int64_t launches = 0;
+  double ms = 0, flops = 0, bytes = 0;
+};
+
+struct rau_ctx {
+  rau_config cfg;
+  int Q;
+  hipStream_t st = nullptr;    // chain stream: recurrences, small GEMMs; what callers order against
+  hipStream_t st2 = nullptr;   // bulk stream: hop-batched 1x1-conv GEMMs, overlapped with the chain
+  hipStream_t st3 = nullptr;   // weight-gradient stream: throughput GEMMs nobody waits for until the end
+  hipEvent_t evA = nullptr, evD = nullptr, evW = nullptr, evE = nullptr, evW3 = nullptr;
+  std::vector<hipEvent_t> evF, evK;  // per hop group: forward bulk done / backward chain done
+  int cur_group = 1;                 // group size used by the last forward
+  int hop_group = 1;                 // hops per bulk launch (pipelines bulk GEMMs with the hop loops)
+  std::vector<void*> allocs;
+  Group grp[3];
+  // mult
+  Lin q_proj, h_proj, i_embed, att_q, att_i, att_score, att_mem, feat_attprob, lstm_i2h,
+      lstm_h2h, lstm_out, cls, do_pred;
+  // rnn
+  Lin i2h[2], h2h[2];
+  // batch
+  float* feats = nullptr;
+  int32_t *tokens = nullptr, *lens_d = nullptr, *labels_d = nullptr;
+  std::vector<int32_t> lens_h;
+  int max_len = 0;
+  bool have_batch = false, have_labels = false;
+  int nuniq = 0;
+  int32_t *utok = nullptr, *ustart = nullptr, *upos = nullptr;
+  // dropout
+  int mode = RAU_MODE_TRAIN;
+  uint32_t* mbits[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  size_t mcount[5] = {0, 0, 0, 0, 0};
+  bool mexplicit[5] = {false, false, false, false, false};
+  float mp[5];
+  uint64_t seed = 0;
+  uint32_t step = 0;
+  // encoder activations
+  float *we, *G1, *G2, *c1, *h1, *c2, *h2, *tc1, *tc2, *x2, *q;
+  // RAU activations
+  float *xd;          // [H][B][D][S] feature map after per-hop dropout (train mode)
+  bool I_shared = false;  // evaluate mode: i_embed output is hop-invariant, computed once
+  float *WiT, *WpT;   // i_embed / ifeatproj weights transposed ([D][M], [M][A]), refreshed per forward
+  float *P0;          // [B][A][S] hop-invariant attention pre-activation (evaluate mode)
+  float *qd, *Yq, *qf, *I, *T, *u, *zm, *a, *jv, *j, *g4, *cc, *hh, *tc, *mf, *logits,
+      *dl, *lossrow, *dopred, *losses_d, *hopw_d;
+  int32_t* argmax_d;
+  // backward temporaries
+  // dZ holds dI (gradient at i_embed's OUTPUT); the tanh derivative is applied by its consumers
+  float *dpre, *dhn, *dg4, *dcn[2], *dhp[2], *dj, *da_lin, *dz, *du, *dwsp, *dZ, *rsum,
+      *dqt, *dQD, *dq, *slab, *slab2, *slab3, *coltmp, *coltmp2, *coltmp3, *tmpS;
+  size_t slab3_floats = 0;
+  float *dG1, *dG2, *dwe, *edc[2][2];
+  size_t slab_floats = 0;
+  // module-level entry points (rau_modules.hip); allocated on first use
+  bool mod_ready = false;
+  float *m_state = nullptr, *m_dstate = nullptr;   // [T][B][Q] packed DeepLSTM state slots
+  float *m_tmp[4] = {nullptr, nullptr, nullptr, nullptr};  // [B][max(Rq,R,M)] scratch
+  float *m_dq = nullptr, *m_dc = nullptr, *m_dh = nullptr;  // [H][B][Q], [H][B][R], [H][B][R]
+  float *m_dX = nullptr, *m_dZ = nullptr;          // [B][D][S], [B][M][S]: feature-map gradient, on request
+  float *m_add = nullptr, *m_s = nullptr, *m_zero = nullptr;  // [B][M], [B], zeros [B][max(Q,R)]
+  float *m_loss = nullptr;                         // [H] criterion outputs
+  uint64_t mod_masks_seed = 0;                     // (seed, step) the device masks were drawn for
+  uint32_t mod_masks_step = 0;
+  bool mod_masks_valid = false;
+  // update
+  float *npart = nullptr, *norms_d = nullptr;
+  bool fwd_done = false;
+  // timing
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  bool prof_on = false;
+  std::vector<ProfCls> pcls;
+  std::vector<ProfRec> precs;
+  std::vector<hipEvent_t> evpool;
+};
+
+template <typename Tp>
+static int dalloc(rau_ctx* c, Tp** p, size_t count) {
+  void* d = nullptr;
+  const size_t bytes = std::max<size_t>(count, 1) * sizeof(Tp);
+  hipError_t e = hipMalloc(&d, bytes);
+  if (e != hipSuccess)
+    return fail(RAU_ERR_NOMEM, "hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
+  e = hipMemsetAsync(d, 0, bytes, c->st);
+  if (e != hipSuccess) return fail(RAU_ERR_DEVICE, "hipMemsetAsync: %s", hipGetErrorString(e));
+  c->allocs.push_back(d);
+  *p = reinterpret_cast<Tp*>(d);
+  return 0;
+}
+
+struct LayoutBuilder {
+  Group* g;
+  size_t off = 0;
+  Lin take(const char* name, int out, int in) {
+    Lin l;
+    l.out = out;
+    l.in = in;
+    g->layout.push_back({std::string(name) + ".weight", off, out, in});
+    l.W = reinterpret_cast<float*>(off);
+    off += (size_t)out * in;
+    g->layout.push_back({std::string(name) + ".bias", off, out, 1});
+    l.b = reinterpret_cast<float*>(off);
+    off += out;
+    return l;
+  }
+};
+static inline void bind(Lin& l, const Group& g) {
+  const size_t ow = reinterpret_cast<size_t>(l.W), ob = reinterpret_cast<size_t>(l.b);
+  l.W = g.w + ow;
+  l.b = g.w + ob;
+  l.dW = g.g + ow;
+  l.db = g.g + ob;
+}
+
+static inline int prof_class(rau_ctx* c, const char* name) {
+  for (size_t i = 0; i < c->pcls.size(); ++i)
+    if (c->pcls[i].name == name) return (int)i;
+  c->pcls.push_back(ProfCls{name});
+  return (int)c->pcls.size() - 1;
+}
+static inline hipEvent_t prof_event(rau_ctx* c) {
+  if (!c->evpool.empty()) {
+    hipEvent_t e = c->evpool.back();
+    c->evpool.pop_back();
+    return e;
+  }
+  hipEvent_t e;
+  hipEventCreate(&e);
+  return e;
+}
+
+// Launch wrapper: counts launches/FLOPs/bytes per kernel class and, when
+// profiling is on, brackets the launch with HIP events on the ctx stream.
+#define RUN(cname, fl, by, expr) RUNS(ctx->st, cname, fl, by, expr)
+#define RUNS(rstream, cname, fl, by, expr)                                                \
+  do {                                                                                    \
+    ProfRec pr_;                                                                          \
+    int pc_ = -1;                                                                         \
+    if (ctx->prof_on) {                                                                   \
+      pc_ = prof_class(ctx, cname);                                                       \
+      ctx->pcls[pc_].launches++;                                                          \
+      ctx->pcls[pc_].flops += (double)(fl);                                               \
+      ctx->pcls[pc_].bytes += (double)(by);                                               \
+      pr_.cls = pc_;                                                                      \
+      pr_.a = prof_event(ctx);                                                            \
+      pr_.b = prof_event(ctx);                                                            \
+      hipEventRecord(pr_.a, rstream);                                                     \
+    }                                                                                     \
+    hipError_t e_ = (expr);                                                               \
+    if (pc_ >= 0) {                                                                       \
+      hipEventRecord(pr_.b, rstream);                                                     \
+      ctx->precs.push_back(pr_);                                                          \
+    }                                                                                     \
+    if (e_ != hipSuccess)                                                                 \
+      return fail(RAU_ERR_DEVICE, "kernel %s: %s (%s:%d)", cname, hipGetErrorString(e_),  \
+                  __FILE__, __LINE__);                                                    \
+  } while (0)
+
+// ---- shared between the step-level path (rau_ctx.hip) and the module-level entry
+// points (rau_modules.hip)
+struct HopGrad {
+  const float* dl;        // [B,K] gradient at the logits (already scaled by the hop weight)
+  const float* dc_next;   // [B,R] or null (zeros)
+  const float* dh_next;
+  const float* dmf_add;   // [B,M] or null: extra gradient at merge_feat before its dropout
+  const float* da_out;    // [B,S] or null: gradient at the attprob output
+  float* dc_out;          // [B,R] out: gradient at prev_c
+  float* dh_out;          // [B,R] out: gradient at prev_h
+};
+__attribute__((visibility("hidden"))) int hop_forward(rau_ctx* ctx, int h, const float* cp,
+    const float* hp, float* c_out, float* h_out, const float* Ih, const float* Pin,
+    const int32_t* labels);
+__attribute__((visibility("hidden"))) int hop_backward(rau_ctx* ctx, int h, const float* cp,
+    const float* Ih, const HopGrad& g);

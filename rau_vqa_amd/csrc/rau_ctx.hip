@@ -16,226 +16,16 @@
 //     (one [H*B]- or [T*B]-row GEMM per weight instead of one per clone);
 //   * dropout masks are bit-packed and applied while staging GEMM operands;
 //   * the dead gradient w.r.t. the feature map (SS:579 discards it) is skipped.
-#include <hip/hip_runtime.h>
+#include "rau_ctx.h"
 
-#include <algorithm>
-#include <cmath>
-#include <cstdarg>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <numeric>
-#include <string>
-#include <vector>
-
-#include "../../include/rau.h"
-#include "kernels.h"
-
-using namespace rau;
-
-// LinOpts pre-wired with the ctx's split-K workspace
-#define LINOPTS(name) LinOpts name; name.slab = ctx->slab; name.slab_floats = ctx->slab_floats
-
-// ------------------------------------------------------------------ errors
 static thread_local char g_err[512] = "";
-static int fail(int code, const char* fmt, ...) {
+int fail(int code, const char* fmt, ...) {
   va_list ap;
   va_start(ap, fmt);
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
   return code;
 }
-#define HIPC(expr)                                                                        \
-  do {                                                                                    \
-    hipError_t e_ = (expr);                                                               \
-    if (e_ != hipSuccess)                                                                 \
-      return fail(RAU_ERR_DEVICE, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_),  \
-                  __FILE__, __LINE__);                                                    \
-  } while (0)
-#define NEED(cond, ...)                               \
-  do {                                                \
-    if (!(cond)) return fail(RAU_ERR_INVALID, __VA_ARGS__); \
-  } while (0)
-
-// ------------------------------------------------------------------ ctx
-namespace {
-
-struct Lin {  // one Linear (or 1x1 conv) inside a flat group
-  float *W, *b, *dW, *db;
-  int out, in;
-};
-struct Entry {
-  std::string name;
-  size_t off;
-  int rows, cols;
-};
-struct Group {
-  float* w = nullptr;
-  float* g = nullptr;
-  float* m = nullptr;  // Adam moments (allocated on first update)
-  float* v = nullptr;
-  size_t n = 0;
-  int64_t adam_t = 0;
-  std::vector<Entry> layout;
-};
-struct ProfRec {
-  int cls;
-  hipEvent_t a, b;
-};
-struct ProfCls {
-  std::string name;
-  int64_t launches = 0;
-  double ms = 0, flops = 0, bytes = 0;
-};
-
-}  // namespace
-
-struct rau_ctx {
-  rau_config cfg;
-  int Q;
-  hipStream_t st = nullptr;    // chain stream: recurrences, small GEMMs; what callers order against
-  hipStream_t st2 = nullptr;   // bulk stream: hop-batched 1x1-conv GEMMs, overlapped with the chain
-  hipStream_t st3 = nullptr;   // weight-gradient stream: throughput GEMMs nobody waits for until the end
-  hipEvent_t evA = nullptr, evD = nullptr, evW = nullptr, evE = nullptr, evW3 = nullptr;
-  std::vector<hipEvent_t> evF, evK;  // per hop group: forward bulk done / backward chain done
-  int cur_group = 1;                 // group size used by the last forward
-  int hop_group = 1;                 // hops per bulk launch (pipelines bulk GEMMs with the hop loops)
-  std::vector<void*> allocs;
-  Group grp[3];
-  // mult
-  Lin q_proj, h_proj, i_embed, att_q, att_i, att_score, att_mem, feat_attprob, lstm_i2h,
-      lstm_h2h, lstm_out, cls, do_pred;
-  // rnn
-  Lin i2h[2], h2h[2];
-  // batch
-  float* feats = nullptr;
-  int32_t *tokens = nullptr, *lens_d = nullptr, *labels_d = nullptr;
-  std::vector<int32_t> lens_h;
-  int max_len = 0;
-  bool have_batch = false, have_labels = false;
-  int nuniq = 0;
-  int32_t *utok = nullptr, *ustart = nullptr, *upos = nullptr;
-  // dropout
-  int mode = RAU_MODE_TRAIN;
-  uint32_t* mbits[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-  size_t mcount[5] = {0, 0, 0, 0, 0};
-  bool mexplicit[5] = {false, false, false, false, false};
-  float mp[5];
-  uint64_t seed = 0;
-  uint32_t step = 0;
-  // encoder activations
-  float *we, *G1, *G2, *c1, *h1, *c2, *h2, *tc1, *tc2, *x2, *q;
-  // RAU activations
-  float *xd;          // [H][B][D][S] feature map after per-hop dropout (train mode)
-  bool I_shared = false;  // evaluate mode: i_embed output is hop-invariant, computed once
-  float *WiT, *WpT;   // i_embed / ifeatproj weights transposed ([D][M], [M][A]), refreshed per forward
-  float *P0;          // [B][A][S] hop-invariant attention pre-activation (evaluate mode)
-  float *qd, *Yq, *qf, *I, *T, *u, *zm, *a, *jv, *j, *g4, *cc, *hh, *tc, *mf, *logits,
-      *dl, *lossrow, *dopred, *losses_d, *hopw_d;
-  int32_t* argmax_d;
-  // backward temporaries
-  // dZ holds dI (gradient at i_embed's OUTPUT); the tanh derivative is applied by its consumers
-  float *dpre, *dhn, *dg4, *dcn[2], *dhp[2], *dj, *da_lin, *dz, *du, *dwsp, *dZ, *rsum,
-      *dqt, *dQD, *dq, *slab, *slab2, *slab3, *coltmp, *coltmp2, *coltmp3, *tmpS;
-  size_t slab3_floats = 0;
-  float *dG1, *dG2, *dwe, *edc[2][2];
-  size_t slab_floats = 0;
-  // update
-  float *npart = nullptr, *norms_d = nullptr;
-  bool fwd_done = false;
-  // timing
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  bool prof_on = false;
-  std::vector<ProfCls> pcls;
-  std::vector<ProfRec> precs;
-  std::vector<hipEvent_t> evpool;
-};
-
-namespace {
-
-template <typename Tp>
-int dalloc(rau_ctx* c, Tp** p, size_t count) {
-  void* d = nullptr;
-  const size_t bytes = std::max<size_t>(count, 1) * sizeof(Tp);
-  hipError_t e = hipMalloc(&d, bytes);
-  if (e != hipSuccess)
-    return fail(RAU_ERR_NOMEM, "hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
-  e = hipMemsetAsync(d, 0, bytes, c->st);
-  if (e != hipSuccess) return fail(RAU_ERR_DEVICE, "hipMemsetAsync: %s", hipGetErrorString(e));
-  c->allocs.push_back(d);
-  *p = reinterpret_cast<Tp*>(d);
-  return 0;
-}
-
-struct LayoutBuilder {
-  Group* g;
-  size_t off = 0;
-  Lin take(const char* name, int out, int in) {
-    Lin l;
-    l.out = out;
-    l.in = in;
-    g->layout.push_back({std::string(name) + ".weight", off, out, in});
-    l.W = reinterpret_cast<float*>(off);
-    off += (size_t)out * in;
-    g->layout.push_back({std::string(name) + ".bias", off, out, 1});
-    l.b = reinterpret_cast<float*>(off);
-    off += out;
-    return l;
-  }
-};
-void bind(Lin& l, const Group& g) {
-  const size_t ow = reinterpret_cast<size_t>(l.W), ob = reinterpret_cast<size_t>(l.b);
-  l.W = g.w + ow;
-  l.b = g.w + ob;
-  l.dW = g.g + ow;
-  l.db = g.g + ob;
-}
-
-int prof_class(rau_ctx* c, const char* name) {
-  for (size_t i = 0; i < c->pcls.size(); ++i)
-    if (c->pcls[i].name == name) return (int)i;
-  c->pcls.push_back(ProfCls{name});
-  return (int)c->pcls.size() - 1;
-}
-hipEvent_t prof_event(rau_ctx* c) {
-  if (!c->evpool.empty()) {
-    hipEvent_t e = c->evpool.back();
-    c->evpool.pop_back();
-    return e;
-  }
-  hipEvent_t e;
-  hipEventCreate(&e);
-  return e;
-}
-
-}  // namespace
-
-// Launch wrapper: counts launches/FLOPs/bytes per kernel class and, when
-// profiling is on, brackets the launch with HIP events on the ctx stream.
-#define RUN(cname, fl, by, expr) RUNS(ctx->st, cname, fl, by, expr)
-#define RUNS(rstream, cname, fl, by, expr)                                                \
-  do {                                                                                    \
-    ProfRec pr_;                                                                          \
-    int pc_ = -1;                                                                         \
-    if (ctx->prof_on) {                                                                   \
-      pc_ = prof_class(ctx, cname);                                                       \
-      ctx->pcls[pc_].launches++;                                                          \
-      ctx->pcls[pc_].flops += (double)(fl);                                               \
-      ctx->pcls[pc_].bytes += (double)(by);                                               \
-      pr_.cls = pc_;                                                                      \
-      pr_.a = prof_event(ctx);                                                            \
-      pr_.b = prof_event(ctx);                                                            \
-      hipEventRecord(pr_.a, rstream);                                                     \
-    }                                                                                     \
-    hipError_t e_ = (expr);                                                               \
-    if (pc_ >= 0) {                                                                       \
-      hipEventRecord(pr_.b, rstream);                                                     \
-      ctx->precs.push_back(pr_);                                                          \
-    }                                                                                     \
-    if (e_ != hipSuccess)                                                                 \
-      return fail(RAU_ERR_DEVICE, "kernel %s: %s (%s:%d)", cname, hipGetErrorString(e_),  \
-                  __FILE__, __LINE__);                                                    \
-  } while (0)
 
 static int prof_collect(rau_ctx* ctx) {
   if (ctx->precs.empty()) return 0;
@@ -252,7 +42,6 @@ static int prof_collect(rau_ctx* ctx) {
   ctx->precs.clear();
   return 0;
 }
-
 // ================================================================== C ABI
 extern "C" {
 
@@ -637,6 +426,7 @@ int rau_set_dropout_seed(rau_ctx* ctx, uint64_t seed, uint32_t step) {
   ctx->seed = seed;
   ctx->step = step;
   for (int i = 0; i < 5; ++i) ctx->mexplicit[i] = false;
+  ctx->mod_masks_valid = false;
   return RAU_OK;
 }
 int rau_set_mask(rau_ctx* ctx, int site, const uint8_t* keep, size_t n) {
@@ -651,6 +441,7 @@ int rau_set_mask(rau_ctx* ctx, int site, const uint8_t* keep, size_t n) {
                       ctx->st));
   HIPC(hipStreamSynchronize(ctx->st));
   ctx->mexplicit[site] = true;
+  ctx->mod_masks_valid = false;
   return RAU_OK;
 }
 static int gen_masks(rau_ctx* ctx) {
@@ -741,13 +532,188 @@ int rau_batch_feats(rau_ctx* ctx, float** feats_dev) {
   return RAU_OK;
 }
 
+}  // extern "C"
+
+// ================================================================ one hop
+// The recurrence-dependent half of one answering hop (SS:292-307 given this hop's I and
+// P = Wp I + bp): q_embed's recurrent half, attention, attention LSTM, classifier and the
+// criterion head.  Activations land in the ctx's hop-h slots; the new state in c_out/h_out.
+int hop_forward(rau_ctx* ctx, int h, const float* cp, const float* hp, float* c_out, float* h_out,
+                const float* Ih, const float* Pin, const int32_t* labels) {
+  const rau_config& c = ctx->cfg;
+  const int B = c.B, S = c.S, M = c.M, A = c.A, R = c.R, K = c.K;
+  hipStream_t st = ctx->st;
+  const bool tr = ctx->mode == RAU_MODE_TRAIN;
+  const uint32_t* m_mf = (tr && ctx->mp[RAU_MASK_MF] > 0.f) ? ctx->mbits[RAU_MASK_MF] : nullptr;
+  auto sc = [&](int site) { return 1.f / (1.f - ctx->mp[site]); };
+  auto gflop = [](double m, double n, double k) { return 2.0 * m * n * k; };
+  const size_t BM_ = (size_t)B * M, BS_ = (size_t)B * S, BR_ = (size_t)B * R;
+  float* qf = ctx->qf + (size_t)h * BM_;
+  float* Th = ctx->T + (size_t)h * B * A * S;
+  float* ah = ctx->a + (size_t)h * BS_;
+  float* jh = ctx->j + (size_t)h * BM_;
+  float* g4 = ctx->g4 + (size_t)h * B * 4 * R;
+  float* mfh = ctx->mf + (size_t)h * BM_;
+  float* lg = ctx->logits + (size_t)h * B * K;
+  {  // q_embed SS:231-236
+    LINOPTS(o);
+    o.addend = ctx->Yq + (size_t)h * BM_;
+    o.add_rs = M;
+    o.act = 1;
+    RUN("small_gemm", gflop(B, M, R), 0, gemm_nt(st, B, M, R, hp, R, ctx->h_proj.W, R, qf, M, o));
+  }
+  {  // attbycontent SS:244-252
+    LINOPTS(o);
+    o.bias = ctx->att_q.b;
+    RUN("small_gemm", gflop(B, A, M), 0, gemm_nt(st, B, A, M, qf, M, ctx->att_q.W, M, ctx->u, A, o));
+  }
+  {  // attbymemory SS:285-290 (linear part)
+    LINOPTS(o);
+    o.bias = ctx->att_mem.b;
+    RUN("small_gemm", gflop(B, S, R), 0, gemm_nt(st, B, S, R, hp, R, ctx->att_mem.W, R, ctx->zm, S, o));
+  }
+  // tanh(P+u), score, softmax, attention-weighted sum: one pass per sample
+  RUN("att_fwd_fused", 2.0 * B * S * (A + M), ((double)B * A * S * 2 + BM_ * S) * 4,
+      att_fwd_fused(st, B, M, A, S, Pin, ctx->u, ctx->att_score.W,
+                    ctx->att_score.b, ctx->zm, Ih, qf, Th, ah, ctx->jv));
+  {  // classifier SS:265-283
+    LINOPTS(o);
+    o.bias = ctx->feat_attprob.b;
+    o.addend = ctx->jv;
+    o.add_rs = M;
+    RUN("small_gemm", gflop(B, M, S), 0, gemm_nt(st, B, M, S, ah, S, ctx->feat_attprob.W, S, jh, M, o));
+  }
+  {
+    LINOPTS(o);
+    o.bias = ctx->lstm_i2h.b;
+    o.bias2 = ctx->lstm_h2h.b;
+    RUN("small_gemm", gflop(B, 4 * R, M), 0,
+        gemm_nt(st, B, 4 * R, M, jh, M, ctx->lstm_i2h.W, M, g4, 4 * R, o));
+    int nsp = 0;
+    LINOPTS(oa);
+    oa.defer_splits = &nsp;
+    RUN("small_gemm", gflop(B, 4 * R, R), 0,
+        gemm_nt(st, B, 4 * R, R, hp, R, ctx->lstm_h2h.W, R, g4, 4 * R, oa));
+    RUN("lstm_fwd", 0, BR_ * 4.0 * 10,
+        lstm_fwd(st, GATES_ATT, B, R, g4, cp, R, c_out, R,
+                 h_out, R, ctx->tc + (size_t)h * BR_, nullptr, nullptr,
+                 0, 1.f, ctx->slab, nsp));
+  }
+  {
+    LINOPTS(o);
+    o.bias = ctx->lstm_out.b;
+    o.addend = jh;
+    o.add_rs = M;
+    o.emask = m_mf;
+    o.emask_e0 = (size_t)h * BM_;
+    o.emscale = sc(RAU_MASK_MF);
+    RUN("small_gemm", gflop(B, M, R), 0,
+        gemm_nt(st, B, M, R, h_out, R, ctx->lstm_out.W, R, mfh, M, o));
+  }
+  {
+    LINOPTS(o);
+    o.bias = ctx->cls.b;
+    RUN("small_gemm", gflop(B, K, M), 0, gemm_nt(st, B, K, M, mfh, M, ctx->cls.W, M, lg, K, o));
+  }
+  RUN("ce_fwd", 0, (double)B * K * 12,
+      ce_fwd(st, B, K, M, lg, labels, mfh, ctx->do_pred.W,
+             ctx->do_pred.b, ctx->dl + (size_t)h * B * K, ctx->lossrow + (size_t)h * B,
+             ctx->argmax_d + (size_t)h * B, ctx->dopred + (size_t)h * B));
+  return RAU_OK;
+}
+
+// Backward of hop_forward (hand-derived, SURVEY 8a "exact backward of one hop"): from the
+// gradients at {logits, next_c, next_h} to dpre, dg4, dj, dz, dS (in T), du, dq~ in the
+// hop-h slots and {dc_prev, dh_prev} in g.dc_out / g.dh_out.  Weight gradients and the
+// 1x1-conv gradients are formed by the callers from those slots.
+int hop_backward(rau_ctx* ctx, int h, const float* cp, const float* Ih, const HopGrad& g) {
+  const rau_config& c = ctx->cfg;
+  const int B = c.B, S = c.S, M = c.M, A = c.A, R = c.R, K = c.K;
+  hipStream_t st = ctx->st;
+  const bool tr = ctx->mode == RAU_MODE_TRAIN;
+  const uint32_t* m_mf = (tr && ctx->mp[RAU_MASK_MF] > 0.f) ? ctx->mbits[RAU_MASK_MF] : nullptr;
+  auto sc = [&](int site) { return 1.f / (1.f - ctx->mp[site]); };
+  auto gflop = [](double m, double n, double k) { return 2.0 * m * n * k; };
+  const size_t BM_ = (size_t)B * M, BS_ = (size_t)B * S, BR_ = (size_t)B * R;
+  const float* qf = ctx->qf + (size_t)h * BM_;
+  float* Th = ctx->T + (size_t)h * B * A * S;   // becomes dS in place
+  const float* ah = ctx->a + (size_t)h * BS_;
+  const float* g4 = ctx->g4 + (size_t)h * B * 4 * R;
+  float* dpre = ctx->dpre + (size_t)h * BM_;
+  float* dg4 = ctx->dg4 + (size_t)h * B * 4 * R;
+  float* djh = ctx->dj + (size_t)h * BM_;
+  float* dzh = ctx->dz + (size_t)h * BS_;
+  float* duh = ctx->du + (size_t)h * B * A;
+  float* dqt = ctx->dqt + (size_t)h * BM_;
+  float* dc_out = g.dc_out;
+  float* dh_out = g.dh_out;
+  {  // dmf = dlogits Wc ; dpre = dmf (.) mask   (do_pred grad is zero, SS:566)
+    LINOPTS(o);
+    o.addend = g.dmf_add;   // module-level callers: gradient through do_pred (zero in feval)
+    o.add_rs = M;
+    o.emask = m_mf;
+    o.emask_e0 = (size_t)h * BM_;
+    o.emscale = sc(RAU_MASK_MF);
+    RUN("small_gemm", gflop(B, M, K), 0,
+        gemm_nn(st, B, M, K, g.dl, K, ctx->cls.W, M, dpre, M, o));
+  }
+  {  // dhn = dpre Wo + dh_next, the K-split partials of dpre Wo summed inside lstm_bwd
+    int nsp = 0;
+    LINOPTS(o);
+    o.defer_splits = &nsp;
+    RUN("small_gemm", gflop(B, R, M), 0, gemm_nn(st, B, R, M, dpre, M, ctx->lstm_out.W, R, ctx->dhn, R, o));
+    RUN("lstm_bwd", 0, BR_ * 4.0 * 12,
+        lstm_bwd(st, GATES_ATT, B, R, g4, cp, R, ctx->tc + (size_t)h * BR_, nullptr, R, g.dh_next,
+                 g.dc_next, dg4, dc_out, nullptr, 0, nullptr, nullptr, 0, ctx->slab, nsp));
+  }
+  {  // dj = dpre + dg Wx ; dh_prev = dg Wr
+    LINOPTS(o);
+    o.addend = dpre;
+    o.add_rs = M;
+    RUN("small_gemm", gflop(B, M, 4 * R), 0,
+        gemm_nn(st, B, M, 4 * R, dg4, 4 * R, ctx->lstm_i2h.W, M, djh, M, o));
+    LINOPTS(o2);
+    RUN("small_gemm", gflop(B, R, 4 * R), 0,
+        gemm_nn(st, B, R, 4 * R, dg4, 4 * R, ctx->lstm_h2h.W, R, dh_out, R, o2));
+  }
+  {  // da = dj Wf  (+ attselect term below) (+ gradient at the attprob OUTPUT, zero in feval)
+    LINOPTS(o);
+    o.addend = g.da_out;
+    o.add_rs = S;
+    RUN("small_gemm", gflop(B, S, M), 0,
+        gemm_nn(st, B, S, M, djh, M, ctx->feat_attprob.W, S, ctx->da_lin, S, o));
+  }
+  RUN("att_bwd_fused", 2.0 * B * S * (A + M), ((double)B * A * S * 2 + BM_ * S) * 4,
+      att_bwd_fused(st, B, M, A, S, Ih, djh, ah, ctx->da_lin, ctx->att_score.W, Th, dzh, duh,
+                    ctx->dwsp + (size_t)h * B * A));
+  {  // dh_prev += dz Wm
+    LINOPTS(o);
+    o.accumulate = 1;
+    RUN("small_gemm", gflop(B, R, S), 0, gemm_nn(st, B, R, S, dzh, S, ctx->att_mem.W, R, dh_out, R, o));
+  }
+  {  // dq~ = (dj + du Wa) (1 - qf^2)
+    LINOPTS(o);
+    o.addend = djh;
+    o.add_rs = M;
+    o.ymul = qf;
+    o.y_rs = M;
+    RUN("small_gemm", gflop(B, M, A), 0, gemm_nn(st, B, M, A, duh, A, ctx->att_q.W, M, dqt, M, o));
+    LINOPTS(o2);
+    o2.accumulate = 1;
+    RUN("small_gemm", gflop(B, R, M), 0, gemm_nn(st, B, R, M, dqt, M, ctx->h_proj.W, R, dh_out, R, o2));
+  }
+  return RAU_OK;
+}
+
+extern "C" {
+
 // ================================================================ forward
 int rau_forward(rau_ctx* ctx) {
   NEED(ctx, "null ctx");
   if (!ctx->have_batch) return fail(RAU_ERR_STATE, "rau_forward: no batch (call rau_set_batch)");
   const rau_config& c = ctx->cfg;
-  const int B = c.B, E = c.E, Rq = c.Rq, D = c.D, S = c.S, M = c.M, A = c.A, R = c.R, K = c.K,
-            H = c.H, Q = ctx->Q;
+  const int B = c.B, E = c.E, Rq = c.Rq, D = c.D, S = c.S, M = c.M, A = c.A, R = c.R, H = c.H,
+            Q = ctx->Q;
   const int TL = ctx->max_len;
   hipStream_t st = ctx->st;
   if (int rc = gen_masks(ctx)) return rc;
@@ -757,7 +723,7 @@ int rau_forward(rau_ctx* ctx) {
   };
   auto sc = [&](int site) { return 1.f / (1.f - ctx->mp[site]); };
   const uint32_t *m_we = mk(RAU_MASK_WE), *m_rnn = mk(RAU_MASK_RNN), *m_q = mk(RAU_MASK_Q),
-                 *m_x = mk(RAU_MASK_X), *m_mf = mk(RAU_MASK_MF);
+                 *m_x = mk(RAU_MASK_X);
   const size_t BRq = (size_t)B * Rq;
   auto gflop = [](double m, double n, double k) { return 2.0 * m * n * k; };
 
@@ -863,7 +829,7 @@ int rau_forward(rau_ctx* ctx) {
       gather_q(st, B, Rq, TL, ctx->lens_d, ctx->c1, ctx->h1, ctx->c2, ctx->h2, ctx->q));
 
   // ---------------- RAU hops, SS:467-520
-  const size_t BM_ = (size_t)B * M, BS_ = (size_t)B * S, BR_ = (size_t)B * R;
+  const size_t BM_ = (size_t)B * M, BR_ = (size_t)B * R;
   RUN("apply_mask", 0, (double)H * B * Q * 8,
       apply_mask(st, (size_t)H * B * Q, (size_t)B * Q, ctx->q, m_q, sc(RAU_MASK_Q), ctx->qd));
   {
@@ -881,80 +847,12 @@ int rau_forward(rau_ctx* ctx) {
   HIPC(hipMemsetAsync(ctx->hh, 0, BR_ * sizeof(float), st));
   for (int h = 0; h < H; ++h) {
     if (h % GH == 0) HIPC(hipStreamWaitEvent(st, ctx->evF[h], 0));  // this group's I and P are ready
-    const float* hp = ctx->hh + (size_t)h * BR_;
-    const float* cp = ctx->cc + (size_t)h * BR_;
-    float* qf = ctx->qf + (size_t)h * BM_;
-    float* Ih = ctx->I + (ctx->I_shared ? 0 : (size_t)h * BM_ * S);
-    float* Th = ctx->T + (size_t)h * B * A * S;
-    float* ah = ctx->a + (size_t)h * BS_;
-    float* jh = ctx->j + (size_t)h * BM_;
-    float* g4 = ctx->g4 + (size_t)h * B * 4 * R;
-    float* mfh = ctx->mf + (size_t)h * BM_;
-    float* lg = ctx->logits + (size_t)h * B * K;
-    {  // q_embed SS:231-236
-      LINOPTS(o);
-      o.addend = ctx->Yq + (size_t)h * BM_;
-      o.add_rs = M;
-      o.act = 1;
-      RUN("small_gemm", gflop(B, M, R), 0, gemm_nt(st, B, M, R, hp, R, ctx->h_proj.W, R, qf, M, o));
-    }
-    {  // attbycontent SS:244-252
-      LINOPTS(o);
-      o.bias = ctx->att_q.b;
-      RUN("small_gemm", gflop(B, A, M), 0, gemm_nt(st, B, A, M, qf, M, ctx->att_q.W, M, ctx->u, A, o));
-    }
-    {  // attbymemory SS:285-290 (linear part)
-      LINOPTS(o);
-      o.bias = ctx->att_mem.b;
-      RUN("small_gemm", gflop(B, S, R), 0, gemm_nt(st, B, S, R, hp, R, ctx->att_mem.W, R, ctx->zm, S, o));
-    }
-    // tanh(P+u), score, softmax, attention-weighted sum: one pass per sample
-    RUN("att_fwd_fused", 2.0 * B * S * (A + M), ((double)B * A * S * 2 + BM_ * S) * 4,
-        att_fwd_fused(st, B, M, A, S, ctx->I_shared ? ctx->P0 : Th, ctx->u, ctx->att_score.W,
-                      ctx->att_score.b, ctx->zm, Ih, qf, Th, ah, ctx->jv));
-    {  // classifier SS:265-283
-      LINOPTS(o);
-      o.bias = ctx->feat_attprob.b;
-      o.addend = ctx->jv;
-      o.add_rs = M;
-      RUN("small_gemm", gflop(B, M, S), 0, gemm_nt(st, B, M, S, ah, S, ctx->feat_attprob.W, S, jh, M, o));
-    }
-    {
-      LINOPTS(o);
-      o.bias = ctx->lstm_i2h.b;
-      o.bias2 = ctx->lstm_h2h.b;
-      RUN("small_gemm", gflop(B, 4 * R, M), 0,
-          gemm_nt(st, B, 4 * R, M, jh, M, ctx->lstm_i2h.W, M, g4, 4 * R, o));
-      int nsp = 0;
-      LINOPTS(oa);
-      oa.defer_splits = &nsp;
-      RUN("small_gemm", gflop(B, 4 * R, R), 0,
-          gemm_nt(st, B, 4 * R, R, hp, R, ctx->lstm_h2h.W, R, g4, 4 * R, oa));
-      RUN("lstm_fwd", 0, BR_ * 4.0 * 10,
-          lstm_fwd(st, GATES_ATT, B, R, g4, cp, R, ctx->cc + (size_t)(h + 1) * BR_, R,
-                   ctx->hh + (size_t)(h + 1) * BR_, R, ctx->tc + (size_t)h * BR_, nullptr, nullptr,
-                   0, 1.f, ctx->slab, nsp));
-    }
-    {
-      LINOPTS(o);
-      o.bias = ctx->lstm_out.b;
-      o.addend = jh;
-      o.add_rs = M;
-      o.emask = m_mf;
-      o.emask_e0 = (size_t)h * BM_;
-      o.emscale = sc(RAU_MASK_MF);
-      RUN("small_gemm", gflop(B, M, R), 0,
-          gemm_nt(st, B, M, R, ctx->hh + (size_t)(h + 1) * BR_, R, ctx->lstm_out.W, R, mfh, M, o));
-    }
-    {
-      LINOPTS(o);
-      o.bias = ctx->cls.b;
-      RUN("small_gemm", gflop(B, K, M), 0, gemm_nt(st, B, K, M, mfh, M, ctx->cls.W, M, lg, K, o));
-    }
-    RUN("ce_fwd", 0, (double)B * K * 12,
-        ce_fwd(st, B, K, M, lg, ctx->have_labels ? ctx->labels_d : nullptr, mfh, ctx->do_pred.W,
-               ctx->do_pred.b, ctx->dl + (size_t)h * B * K, ctx->lossrow + (size_t)h * B,
-               ctx->argmax_d + (size_t)h * B, ctx->dopred + (size_t)h * B));
+    if (int rc = hop_forward(ctx, h, ctx->cc + (size_t)h * BR_, ctx->hh + (size_t)h * BR_,
+                             ctx->cc + (size_t)(h + 1) * BR_, ctx->hh + (size_t)(h + 1) * BR_,
+                             ctx->I + (ctx->I_shared ? 0 : (size_t)h * BM_ * S),
+                             ctx->I_shared ? ctx->P0 : ctx->T + (size_t)h * B * A * S,
+                             ctx->have_labels ? ctx->labels_d : nullptr))
+      return rc;
   }
   if (ctx->have_labels)
     RUN("loss_reduce", 0, 0, loss_reduce(st, H, B, ctx->lossrow, ctx->losses_d));
@@ -978,8 +876,7 @@ int rau_backward(rau_ctx* ctx, const float* hop_w) {
     return (tr && ctx->mp[site] > 0.f) ? ctx->mbits[site] : nullptr;
   };
   auto sc = [&](int site) { return 1.f / (1.f - ctx->mp[site]); };
-  const uint32_t *m_we = mk(RAU_MASK_WE), *m_rnn = mk(RAU_MASK_RNN), *m_q = mk(RAU_MASK_Q),
-                 *m_mf = mk(RAU_MASK_MF);
+  const uint32_t *m_we = mk(RAU_MASK_WE), *m_rnn = mk(RAU_MASK_RNN), *m_q = mk(RAU_MASK_Q);
   auto gflop = [](double m, double n, double k) { return 2.0 * m * n * k; };
   const size_t BM_ = (size_t)B * M, BS_ = (size_t)B * S, BR_ = (size_t)B * R;
   const size_t BRq = (size_t)B * Rq;
@@ -993,70 +890,18 @@ int rau_backward(rau_ctx* ctx, const float* hop_w) {
   const float* dc_next = nullptr;  // grad_att_c / grad_att_h zeros, SS:561-562
   const float* dh_next = nullptr;
   for (int h = H - 1; h >= 0; --h) {
-    const float* cp = ctx->cc + (size_t)h * BR_;
-    const float* qf = ctx->qf + (size_t)h * BM_;
-    const float* Ih = ctx->I + (ctx->I_shared ? 0 : (size_t)h * BM_ * S);
-    float* Th = ctx->T + (size_t)h * B * A * S;   // becomes dS in place
-    const float* ah = ctx->a + (size_t)h * BS_;
-    const float* g4 = ctx->g4 + (size_t)h * B * 4 * R;
-    float* dpre = ctx->dpre + (size_t)h * BM_;
-    float* dg4 = ctx->dg4 + (size_t)h * B * 4 * R;
-    float* djh = ctx->dj + (size_t)h * BM_;
-    float* dzh = ctx->dz + (size_t)h * BS_;
-    float* duh = ctx->du + (size_t)h * B * A;
-    float* dqt = ctx->dqt + (size_t)h * BM_;
     float* dc_out = ctx->dcn[h & 1];
     float* dh_out = ctx->dhp[h & 1];
-    {  // dmf = dlogits Wc ; dpre = dmf (.) mask   (do_pred grad is zero, SS:566)
-      LINOPTS(o);
-      o.emask = m_mf;
-      o.emask_e0 = (size_t)h * BM_;
-      o.emscale = sc(RAU_MASK_MF);
-      RUN("small_gemm", gflop(B, M, K), 0,
-          gemm_nn(st, B, M, K, ctx->dl + (size_t)h * B * K, K, ctx->cls.W, M, dpre, M, o));
-    }
-    {  // dhn = dpre Wo + dh_next, the K-split partials of dpre Wo summed inside lstm_bwd
-      int nsp = 0;
-      LINOPTS(o);
-      o.defer_splits = &nsp;
-      RUN("small_gemm", gflop(B, R, M), 0, gemm_nn(st, B, R, M, dpre, M, ctx->lstm_out.W, R, ctx->dhn, R, o));
-      RUN("lstm_bwd", 0, BR_ * 4.0 * 12,
-          lstm_bwd(st, GATES_ATT, B, R, g4, cp, R, ctx->tc + (size_t)h * BR_, nullptr, R, dh_next,
-                   dc_next, dg4, dc_out, nullptr, 0, nullptr, nullptr, 0, ctx->slab, nsp));
-    }
-    {  // dj = dpre + dg Wx ; dh_prev = dg Wr
-      LINOPTS(o);
-      o.addend = dpre;
-      o.add_rs = M;
-      RUN("small_gemm", gflop(B, M, 4 * R), 0,
-          gemm_nn(st, B, M, 4 * R, dg4, 4 * R, ctx->lstm_i2h.W, M, djh, M, o));
-      LINOPTS(o2);
-      RUN("small_gemm", gflop(B, R, 4 * R), 0,
-          gemm_nn(st, B, R, 4 * R, dg4, 4 * R, ctx->lstm_h2h.W, R, dh_out, R, o2));
-    }
-    {  // da = dj Wf  (+ attselect term below)
-      LINOPTS(o);
-      RUN("small_gemm", gflop(B, S, M), 0,
-          gemm_nn(st, B, S, M, djh, M, ctx->feat_attprob.W, S, ctx->da_lin, S, o));
-    }
-    RUN("att_bwd_fused", 2.0 * B * S * (A + M), ((double)B * A * S * 2 + BM_ * S) * 4,
-        att_bwd_fused(st, B, M, A, S, Ih, djh, ah, ctx->da_lin, ctx->att_score.W, Th, dzh, duh,
-                      ctx->dwsp + (size_t)h * B * A));
-    {  // dh_prev += dz Wm
-      LINOPTS(o);
-      o.accumulate = 1;
-      RUN("small_gemm", gflop(B, R, S), 0, gemm_nn(st, B, R, S, dzh, S, ctx->att_mem.W, R, dh_out, R, o));
-    }
-    {  // dq~ = (dj + du Wa) (1 - qf^2)
-      LINOPTS(o);
-      o.addend = djh;
-      o.add_rs = M;
-      o.ymul = qf;
-      o.y_rs = M;
-      RUN("small_gemm", gflop(B, M, A), 0, gemm_nn(st, B, M, A, duh, A, ctx->att_q.W, M, dqt, M, o));
-      LINOPTS(o2);
-      o2.accumulate = 1;
-      RUN("small_gemm", gflop(B, R, M), 0, gemm_nn(st, B, R, M, dqt, M, ctx->h_proj.W, R, dh_out, R, o2));
+    {
+      HopGrad g{};
+      g.dl = ctx->dl + (size_t)h * B * K;
+      g.dc_next = dc_next;
+      g.dh_next = dh_next;
+      g.dc_out = dc_out;
+      g.dh_out = dh_out;
+      if (int rc = hop_backward(ctx, h, ctx->cc + (size_t)h * BR_,
+                                ctx->I + (ctx->I_shared ? 0 : (size_t)h * BM_ * S), g))
+        return rc;
     }
     dc_next = dc_out;
     dh_next = dh_out;
