@@ -75,6 +75,7 @@ int rau_noise_clip_adam(rau_ctx* ctx, int64_t step_t, float lr, float mult_lr,
                         float beta1, float beta2, float eps, float eta, float gamma,
                         float clip, uint64_t noise_seed, float* out_norms);
 int rau_stream(rau_ctx* ctx, void** hip_stream);
+int rau_wait_grads(rau_ctx* ctx, int group, void* hip_stream);
 int rau_timer_begin(rau_ctx* ctx);
 int rau_timer_end(rau_ctx* ctx, float* ms);
 ]]

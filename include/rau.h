@@ -234,6 +234,12 @@ int rau_noise_clip_adam(rau_ctx* ctx, int64_t step_t, float lr, float mult_lr,
  * RCCL all-reduce of the flat grad buffers issued through torch.distributed)
  * after the ctx's kernels without a device-wide sync. */
 int rau_stream(rau_ctx* ctx, void** hip_stream);
+/* Makes `hip_stream` (a hipStream_t of the same device) wait until the gradients of
+ * `group` from the last rau_backward are final, without blocking the host or the ctx
+ * stream.  RAU_GROUP_MULT is final BEFORE the encoder BPTT has run, so a host can put
+ * that bucket's all-reduce on a side stream underneath the rest of the backward pass
+ * (rau_vqa_amd/dist.py); the other two groups are final at the end of rau_backward. */
+int rau_wait_grads(rau_ctx* ctx, int group, void* hip_stream);
 /* HIP-event bracket on the ctx stream: kernel time of everything enqueued
  * between begin and end, in milliseconds (end synchronises). */
 int rau_timer_begin(rau_ctx* ctx);

@@ -96,6 +96,7 @@ _SIGS = {
     "rau_noise_clip_adam": (C.c_int, [C.c_void_p, C.c_int64] + [C.c_float] * 8 +
                             [C.c_uint64, C.c_void_p]),
     "rau_stream": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
+    "rau_wait_grads": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "rau_timer_begin": (C.c_int, [C.c_void_p]),
     "rau_timer_end": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
     "rau_prof_enable": (C.c_int, [C.c_void_p, C.c_int]),

@@ -71,7 +71,8 @@ struct rau_ctx {
   hipStream_t st = nullptr;    // chain stream: recurrences, small GEMMs; what callers order against
   hipStream_t st2 = nullptr;   // bulk stream: hop-batched 1x1-conv GEMMs, overlapped with the chain
   hipStream_t st3 = nullptr;   // weight-gradient stream: throughput GEMMs nobody waits for until the end
-  hipEvent_t evA = nullptr, evD = nullptr, evW = nullptr, evE = nullptr, evW3 = nullptr;
+  hipEvent_t evA = nullptr, evD = nullptr, evW = nullptr, evE = nullptr, evW3 = nullptr,
+             evM3 = nullptr, evEnd = nullptr;
   std::vector<hipEvent_t> evF, evK;  // per hop group: forward bulk done / backward chain done
   int cur_group = 1;                 // group size used by the last forward
   int hop_group = 1;                 // hops per bulk launch (pipelines bulk GEMMs with the hop loops)
@@ -128,7 +129,7 @@ struct rau_ctx {
   bool mod_masks_valid = false;
   // update
   float *npart = nullptr, *norms_d = nullptr;
-  bool fwd_done = false;
+  bool fwd_done = false, bwd_done = false;
   // timing
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   bool prof_on = false;

@@ -136,7 +136,7 @@ int rau_create(const rau_config* cfg, rau_ctx** out) {
   }
   hipEventCreate(&ctx->ev0);
   hipEventCreate(&ctx->ev1);
-  for (hipEvent_t* e : {&ctx->evA, &ctx->evD, &ctx->evW, &ctx->evE, &ctx->evW3})
+  for (hipEvent_t* e : {&ctx->evA, &ctx->evD, &ctx->evW, &ctx->evE, &ctx->evW3, &ctx->evM3, &ctx->evEnd})
     hipEventCreateWithFlags(e, hipEventDisableTiming);
   {
     int plo = 0, phi = 0;
@@ -333,7 +333,7 @@ void rau_destroy(rau_ctx* ctx) {
   for (auto e : ctx->evpool) hipEventDestroy(e);
   if (ctx->ev0) hipEventDestroy(ctx->ev0);
   if (ctx->ev1) hipEventDestroy(ctx->ev1);
-  for (hipEvent_t e : {ctx->evA, ctx->evD, ctx->evW, ctx->evE, ctx->evW3})
+  for (hipEvent_t e : {ctx->evA, ctx->evD, ctx->evW, ctx->evE, ctx->evW3, ctx->evM3, ctx->evEnd})
     if (e) hipEventDestroy(e);
   if (ctx->st3) hipStreamDestroy(ctx->st3);
   for (hipEvent_t e : ctx->evF) hipEventDestroy(e);
@@ -998,6 +998,7 @@ int rau_backward(rau_ctx* ctx, const float* hop_w) {
     RUNS(sw, "colsum", 0, (double)rows * S * 4, colsum_acc(sw, rows, S, ctx->dz, S, ctx->tmpS, ctx->coltmp3));
     RUNS(sw, "colsum", 0, S * 4.0, colsum_acc(sw, S, 1, ctx->tmpS, 1, ctx->att_score.db, ctx->coltmp3));
     RUNS(sw, "colsum", 0, (double)rows * A * 4, colsum_acc(sw, rows, A, ctx->du, A, ctx->att_i.db, ctx->coltmp3));
+    HIPC(hipEventRecord(ctx->evM3, sw));   // with evD: the mult group's gradients are final
   }
 
   // ---------------- encoder BPTT, SS:581-596 -- the same two-layer wavefront, reversed:
@@ -1079,6 +1080,23 @@ int rau_backward(rau_ctx* ctx, const float* hop_w) {
   HIPC(hipEventRecord(ctx->evW3, ctx->st3));
   HIPC(hipStreamWaitEvent(st, ctx->evW3, 0));
   HIPC(hipStreamWaitEvent(st, ctx->evD, 0));  // join: every gradient is ordered on st
+  HIPC(hipEventRecord(ctx->evEnd, st));
+  ctx->bwd_done = true;
+  return RAU_OK;
+}
+
+int rau_wait_grads(rau_ctx* ctx, int group, void* hip_stream) {
+  if (int rc = check_group(ctx, group)) return rc;
+  if (!ctx->bwd_done) return fail(RAU_ERR_STATE, "rau_wait_grads: no rau_backward to wait for");
+  hipStream_t s = (hipStream_t)hip_stream;
+  if (group == RAU_GROUP_MULT) {
+    // final once the bulk stream's conv gradients (evD) and the weight-gradient stream's
+    // mult block (evM3) are done -- i.e. before the encoder BPTT, which they overlap
+    HIPC(hipStreamWaitEvent(s, ctx->evD, 0));
+    HIPC(hipStreamWaitEvent(s, ctx->evM3, 0));
+  } else {
+    HIPC(hipStreamWaitEvent(s, ctx->evEnd, 0));
+  }
   return RAU_OK;
 }
 

@@ -61,21 +61,42 @@ def allreduce_average(tensors, group=None):
 class GradAllReduce:
     """Averages a RAU ctx's three flat gradient buffers across ranks.
 
-    Collectives are enqueued relative to the ctx's own HIP stream (wrapped as a
-    torch ExternalStream), so no host synchronisation is needed between
-    rau_backward, the all-reduce and rau_noise_clip_adam.
+    The `mult` bucket (the largest) is final before the encoder BPTT has run
+    (rau_wait_grads), so its all-reduce is issued on a side stream underneath the rest
+    of the backward pass; `rnn` and `embed` follow when rau_backward's last kernel is
+    done.  Everything is ordered with stream events -- no host synchronisation between
+    rau_backward, the collectives and rau_noise_clip_adam; the ctx stream waits for the
+    reduced gradients before whatever is enqueued next (the update).
     """
 
     def __init__(self, rau, group=None):
         self.rau = rau
         self.group = group
-        dev = rau.cfg.device_id
-        self.stream = torch.cuda.ExternalStream(rau.stream(), device=torch.device("cuda", dev))
-        self.grads = []
-        for g in ("mult", "rnn", "embed"):   # mult finishes first in backward
+        dev = torch.device("cuda", rau.cfg.device_id)
+        self.stream = torch.cuda.ExternalStream(rau.stream(), device=dev)
+        self.comm = torch.cuda.Stream(device=dev)
+        self.grads = {}
+        for g in ("mult", "rnn", "embed"):
             _, gp, n = rau.device_pointers(g)
-            self.grads.append(device_view(gp, n, dev))
+            self.grads[g] = device_view(gp, n, rau.cfg.device_id)
 
     def __call__(self):
-        with torch.cuda.stream(self.stream):
-            allreduce_average(self.grads, self.group)
+        world = dist.get_world_size(self.group)
+        if world == 1:
+            return
+        avg = dist.get_backend(self.group) == "nccl"   # RCCL has AVG; gloo only SUM
+        op = dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM
+        works = []
+        for names in (("mult",), ("rnn", "embed")):
+            self.rau.wait_grads(names[0], self.comm.cuda_stream)
+            with torch.cuda.stream(self.comm):
+                for g in names:
+                    works.append(dist.all_reduce(self.grads[g], op=op, group=self.group,
+                                                 async_op=True))
+        with torch.cuda.stream(self.comm):
+            for w in works:
+                w.wait()
+            if not avg:
+                for t in self.grads.values():
+                    t.mul_(1.0 / world)
+        self.stream.wait_stream(self.comm)

@@ -242,6 +242,10 @@ class RAU:
         L.check(self._lib.rau_stream(self._h, C.byref(s)))
         return s.value or 0
 
+    def wait_grads(self, group: str, hip_stream: int):
+        """Order `hip_stream` after the last backward's gradients of `group` (no host sync)."""
+        L.check(self._lib.rau_wait_grads(self._h, L.GROUPS[group], C.c_void_p(hip_stream)))
+
     def timer_begin(self):
         L.check(self._lib.rau_timer_begin(self._h))
 
