@@ -118,6 +118,13 @@ def lib() -> C.CDLL:
             raise RauError(f"{LIB_PATH} not found: build it with "
                            "`python -c 'import __graft_entry__ as g; g.build()'` "
                            "(there is no CPU fallback)")
+        # PyTorch wheels bundle their own libamdhip64; if librau pulled in the system copy
+        # first, a later `import torch` would bring up a SECOND HIP runtime in the process,
+        # which then finds no GPU.  Loading torch first makes both share one runtime.
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
         l = C.CDLL(LIB_PATH)
         for name, (res, args) in _SIGS.items():
             fn = getattr(l, name)  # AttributeError if the symbol is missing

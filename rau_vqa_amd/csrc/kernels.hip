@@ -615,6 +615,10 @@ hipError_t row_sums(hipStream_t st, int rows, int S, const float* X, const float
 }
 
 // ----------------------------------------------- deterministic column sums
+// dst[n] += sum_r X[r, n]: stage 1 sums kColChunks row chunks (fixed order inside a chunk),
+// stage 2 adds the chunk partials in order.  The vector path (N, ld multiples of 4) gives a
+// 256-thread workgroup 256 columns x one row chunk: each wave takes every 4th row of the chunk
+// with float4 loads, four independent accumulators, then the waves combine through LDS.
 constexpr int kColChunks = 32;
 __global__ void k_colsum_stage1(int rows, int N, const float* __restrict__ X, long ld,
                                 float* __restrict__ tmp) {
@@ -629,6 +633,52 @@ __global__ void k_colsum_stage1(int rows, int N, const float* __restrict__ X, lo
   for (int r = r0; r < r1; ++r) acc += X[(size_t)r * ld + n];
   tmp[(size_t)blockIdx.y * N + n] = acc;
 }
+__global__ __launch_bounds__(256) void k_colsum_stage1_v4(int rows, int N,
+                                                         const float* __restrict__ X, long ld,
+                                                         float* __restrict__ tmp) {
+  __shared__ float4 part[4][64];
+  const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int n = (blockIdx.x * 64 + l) * 4;
+  const int per = (rows + kColChunks - 1) / kColChunks;
+  const int r0 = blockIdx.y * per;
+  int r1 = r0 + per;
+  if (r1 > rows) r1 = rows;
+  float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0, a3 = a0;
+  if (n < N) {
+    const float* p = X + n;
+    int r = r0 + w;
+    for (; r + 12 < r1; r += 16) {
+      const float4 x0 = *reinterpret_cast<const float4*>(p + (size_t)r * ld);
+      const float4 x1 = *reinterpret_cast<const float4*>(p + (size_t)(r + 4) * ld);
+      const float4 x2 = *reinterpret_cast<const float4*>(p + (size_t)(r + 8) * ld);
+      const float4 x3 = *reinterpret_cast<const float4*>(p + (size_t)(r + 12) * ld);
+      a0.x += x0.x; a0.y += x0.y; a0.z += x0.z; a0.w += x0.w;
+      a1.x += x1.x; a1.y += x1.y; a1.z += x1.z; a1.w += x1.w;
+      a2.x += x2.x; a2.y += x2.y; a2.z += x2.z; a2.w += x2.w;
+      a3.x += x3.x; a3.y += x3.y; a3.z += x3.z; a3.w += x3.w;
+    }
+    for (; r < r1; r += 4) {
+      const float4 x0 = *reinterpret_cast<const float4*>(p + (size_t)r * ld);
+      a0.x += x0.x; a0.y += x0.y; a0.z += x0.z; a0.w += x0.w;
+    }
+  }
+  float4 a;
+  a.x = (a0.x + a1.x) + (a2.x + a3.x);
+  a.y = (a0.y + a1.y) + (a2.y + a3.y);
+  a.z = (a0.z + a1.z) + (a2.z + a3.z);
+  a.w = (a0.w + a1.w) + (a2.w + a3.w);
+  part[w][l] = a;
+  __syncthreads();
+  if (w == 0 && n < N) {
+    const float4 b = part[1][l], c = part[2][l], d = part[3][l];
+    float4 o;
+    o.x = (a.x + b.x) + (c.x + d.x);
+    o.y = (a.y + b.y) + (c.y + d.y);
+    o.z = (a.z + b.z) + (c.z + d.z);
+    o.w = (a.w + b.w) + (c.w + d.w);
+    *reinterpret_cast<float4*>(tmp + (size_t)blockIdx.y * N + n) = o;
+  }
+}
 __global__ void k_colsum_stage2(int N, const float* __restrict__ tmp, float* __restrict__ dst) {
   RAU_CHAIN_PRIO();
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
@@ -639,8 +689,14 @@ __global__ void k_colsum_stage2(int N, const float* __restrict__ tmp, float* __r
 }
 hipError_t colsum_acc(hipStream_t st, int rows, int N, const float* X, long ld, float* dst,
                       float* tmp) {
-  hipLaunchKernelGGL(k_colsum_stage1, dim3((N + 63) / 64, kColChunks), dim3(64), 0, st, rows, N,
-                     X, ld, tmp);
+  const bool vec = (N % 4 == 0) && (ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(X) & 15u) == 0) &&
+                   rows >= 4 * kColChunks;
+  if (vec)
+    hipLaunchKernelGGL(k_colsum_stage1_v4, dim3((N + 255) / 256, kColChunks), dim3(256), 0, st,
+                       rows, N, X, ld, tmp);
+  else
+    hipLaunchKernelGGL(k_colsum_stage1, dim3((N + 63) / 64, kColChunks), dim3(64), 0, st, rows, N,
+                       X, ld, tmp);
   hipLaunchKernelGGL(k_colsum_stage2, dim3((N + 63) / 64), dim3(64), 0, st, N, tmp, dst);
   return hipGetLastError();
 }

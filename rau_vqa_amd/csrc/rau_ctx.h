@@ -58,6 +58,7 @@ struct Group {
 struct ProfRec {
   int cls;
   hipEvent_t a, b;
+  int sid;   // 0 chain, 1 bulk, 2 weight-gradient stream
 };
 struct ProfCls {
   std::string name;
@@ -208,6 +209,7 @@ static inline hipEvent_t prof_event(rau_ctx* c) {
       pr_.cls = pc_;                                                                      \
       pr_.a = prof_event(ctx);                                                            \
       pr_.b = prof_event(ctx);                                                            \
+      pr_.sid = (rstream) == ctx->st ? 0 : (rstream) == ctx->st2 ? 1 : 2;                 \
       hipEventRecord(pr_.a, rstream);                                                     \
     }                                                                                     \
     hipError_t e_ = (expr);                                                               \

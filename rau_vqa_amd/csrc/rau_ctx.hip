@@ -32,14 +32,22 @@ static int prof_collect(rau_ctx* ctx) {
   HIPC(hipStreamSynchronize(ctx->st));
   HIPC(hipStreamSynchronize(ctx->st2));
   HIPC(hipStreamSynchronize(ctx->st3));
+  FILE* tl = nullptr;   // RAU_PROF_TIMELINE=path: per-launch (class, stream, start, end) in ms
+  if (const char* p = std::getenv("RAU_PROF_TIMELINE")) tl = std::fopen(p, "a");
   for (auto& r : ctx->precs) {
     float ms = 0.f;
     hipEventElapsedTime(&ms, r.a, r.b);
+    if (tl) {
+      float t0 = 0.f;
+      hipEventElapsedTime(&t0, ctx->precs[0].a, r.a);
+      std::fprintf(tl, "%s,%d,%.4f,%.4f\n", ctx->pcls[r.cls].name.c_str(), r.sid, t0, t0 + ms);
+    }
     ctx->pcls[r.cls].ms += ms;
     ctx->evpool.push_back(r.a);
     ctx->evpool.push_back(r.b);
   }
   ctx->precs.clear();
+  if (tl) { std::fprintf(tl, "#\n"); std::fclose(tl); }
   return 0;
 }
 // ================================================================== C ABI
@@ -136,8 +144,9 @@ int rau_create(const rau_config* cfg, rau_ctx** out) {
   }
   hipEventCreate(&ctx->ev0);
   hipEventCreate(&ctx->ev1);
+  const unsigned evflags = hipEventDisableTiming;
   for (hipEvent_t* e : {&ctx->evA, &ctx->evD, &ctx->evW, &ctx->evE, &ctx->evW3, &ctx->evM3, &ctx->evEnd})
-    hipEventCreateWithFlags(e, hipEventDisableTiming);
+    hipEventCreateWithFlags(e, evflags);
   {
     int plo = 0, phi = 0;
     hipDeviceGetStreamPriorityRange(&plo, &phi);
@@ -151,8 +160,8 @@ int rau_create(const rau_config* cfg, rau_ctx** out) {
   ctx->evF.resize(c.H);
   ctx->evK.resize(c.H);
   for (int i = 0; i < c.H; ++i) {
-    hipEventCreateWithFlags(&ctx->evF[i], hipEventDisableTiming);
-    hipEventCreateWithFlags(&ctx->evK[i], hipEventDisableTiming);
+    hipEventCreateWithFlags(&ctx->evF[i], evflags);
+    hipEventCreateWithFlags(&ctx->evK[i], evflags);
   }
 
   const int B = c.B, T = c.T, E = c.E, Rq = c.Rq, D = c.D, S = c.S, M = c.M, A = c.A, R = c.R,
@@ -971,9 +980,9 @@ int rau_backward(rau_ctx* ctx, const float* hop_w) {
   // ---------------- mult-group weight gradients, one GEMM per weight over all hops.
   // Throughput work nothing else waits for: third stream, so the encoder BPTT (the
   // long latency-bound chain) starts right after dq instead of behind ~40 launches.
-  {
+  HIPC(hipEventRecord(ctx->evW, st));
+  auto mult_wgrads = [&]() -> int {
     hipStream_t sw = ctx->st3;
-    HIPC(hipEventRecord(ctx->evW, st));
     HIPC(hipStreamWaitEvent(sw, ctx->evW, 0));
     const int rows = H * B;
     const float* hprev = ctx->hh;            // h_{0..H-1}
@@ -999,7 +1008,9 @@ int rau_backward(rau_ctx* ctx, const float* hop_w) {
     RUNS(sw, "colsum", 0, S * 4.0, colsum_acc(sw, S, 1, ctx->tmpS, 1, ctx->att_score.db, ctx->coltmp3));
     RUNS(sw, "colsum", 0, (double)rows * A * 4, colsum_acc(sw, rows, A, ctx->du, A, ctx->att_i.db, ctx->coltmp3));
     HIPC(hipEventRecord(ctx->evM3, sw));   // with evD: the mult group's gradients are final
-  }
+    return 0;
+  };
+  if (int rc = mult_wgrads()) return rc;
 
   // ---------------- encoder BPTT, SS:581-596 -- the same two-layer wavefront, reversed:
   // step u handles layer-2 cell u and layer-1 cell u+1; their incoming dh are the
