@@ -137,6 +137,23 @@ class RAU:
             a = np.ascontiguousarray(a, np.float32)
             L.check(self._lib.rau_set_grads(self._h, L.GROUPS[g], a.ctypes.data, a.size))
 
+    # ---- snapshots (torch.save / torch.load of SS:1188-1197, Eval.lua:113-114,344-347)
+    def save_snapshot(self, path, it, epoch, opt, cuda=True):
+        from . import t7
+        self.sync()
+        t7.save_snapshot(path, self.get_params(), it, epoch, opt, cuda=cuda)
+
+    def load_snapshot(self, path):
+        """embed_param:copy(snap.params[1]) ...; returns (it, epoch, opt)."""
+        from . import t7
+        it, epoch, opt, params = t7.load_snapshot(path)
+        for g, a in params.items():
+            if a.size != self.group_size(g):
+                raise ValueError(f"snapshot group {g} has {a.size} floats, model has "
+                                 f"{self.group_size(g)}")
+        self.set_params(params)
+        return it, epoch, opt
+
     def init_uniform(self, seed=123, lo=-0.08, hi=0.08):
         L.check(self._lib.rau_init_uniform(self._h, seed, lo, hi))
 

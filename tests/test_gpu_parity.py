@@ -97,3 +97,23 @@ def test_batch_100_default_sizes_of_heads():
     """opt.batch_size default 100 (SS:48): tile edges in every flattened-column GEMM."""
     dims = dict(B=100, T=5, V=60, E=200, Rq=32, D=64, S=196, M=128, A=64, R=32, K=1000, H=2)
     check(util.shapes(dims), scale=0.1)
+
+
+def test_snapshot_round_trip_through_t7(tmp_path):
+    """torch.save(checkpoint) / embed_param:copy(snap.params[1]) (SS:1188-1197, Eval.lua:344-347)."""
+    from rau_vqa_amd.model import RAU, Config
+    sh = util.shapes(util.SMALL)
+    cfg = Config(**{k: getattr(sh, k) for k in
+                    ("B", "T", "V", "E", "Rq", "D", "S", "M", "A", "R", "K", "H")})
+    a, b = RAU(cfg), RAU(cfg)
+    a.init_uniform(seed=5)
+    b.init_uniform(seed=6)
+    p = tmp_path / "snapshot_iter000010_epoch0.01.t7"
+    a.save_snapshot(p, it=10, epoch=0.01, opt={"nhop": sh.H, "alg_name": "Ours_SS"})
+    it, epoch, opt = b.load_snapshot(p)
+    assert (it, opt["nhop"]) == (10, sh.H)
+    pa, pb = a.get_params(), b.get_params()
+    for g in pa:
+        np.testing.assert_array_equal(pa[g], pb[g])
+    a.close()
+    b.close()
