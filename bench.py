@@ -28,6 +28,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md, f32-input MFMA
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md, HBM3E (about 6300 achievable)
 DOMINANT = "conv_embed_fwd"    # gemm_kernel<128,128,KC,RC_FLAT_MASK,CONV_TANH>
 
 
@@ -83,6 +84,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=256, help="per-GPU batch")
     ap.add_argument("--D", type=int, default=512)
+    ap.add_argument("--dtype", choices=("f32", "bf16"), default="f32",
+                    help="bf16 = BASELINE.json configs[2] mode (use with --D 2048): bf16-operand "
+                         "conv GEMMs, f32 accumulate; never the default metric")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -107,7 +111,7 @@ def main():
 
     cfgd = dict(B=args.batch, T=26, V=14000, E=200, Rq=512, D=args.D, S=196, M=512, A=256,
                 R=512, K=1000, H=8)
-    cfg = Config(device_id=local_rank, **cfgd)
+    cfg = Config(device_id=local_rank, dtype=args.dtype, **cfgd)
     m = RAU(cfg)
     m.init_uniform(seed=123)                      # uniform(-0.08, 0.08), SS:352-354
     batch = synth.make_batch(cfg.B, cfg.T, cfg.V, cfg.D, cfg.S, cfg.K, seed=123 + rank,
@@ -177,6 +181,15 @@ def main():
                              "traffic": traffic, "kernel": DOMINANT,
                              "avg_launch_ms": avg_ms,
                              "flops_per_launch": flops_per_launch}
+        if args.dtype == "bf16":
+            # bf16 operands: the same kernel is HBM-bound; algorithmic bytes =
+            # read X' once + write I once per launch, both f32 in memory
+            gbs = dom["bytes"] / dom["launches"] / (avg_ms * 1e-3) / 1e9
+            extra["roofline"] = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS,
+                                 "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None,
+                                 "kernel": DOMINANT, "avg_launch_ms": avg_ms,
+                                 "bytes_per_launch": dom["bytes"] / dom["launches"],
+                                 "mfma_tflops": achieved}
         tot = sum(v["ms"] for v in prof.values())
         extra["kernel_classes_ms_per_step"] = {
             k: round(v["ms"] / nprof, 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}
@@ -211,8 +224,11 @@ def main():
                 "value": qa, "unit": "QA-pairs/s", "n_gpus": world, "steps": args.steps,
                 "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
                 "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-                "dtype": "f32", "data": "synthetic",
-                "config": {"workload": "Ours_SS 8-step RAU fwd+bwd (configs[1])",
+                "dtype": "f32" if args.dtype == "f32" else "bf16 conv-GEMM operands, f32 accumulate",
+                "data": "synthetic",
+                "config": {"workload": "Ours_SS 8-step RAU fwd+bwd (configs[1])"
+                           if (args.dtype, args.D) == ("f32", 512) else
+                           f"8-step RAU fwd+bwd, D={args.D}, {args.dtype} (not the headline config)",
                            "batch_per_gpu": cfg.B, "global_batch": cfg.B * world, "T": cfg.T,
                            "feature_map": f"14x14x{cfg.D}", "hops": cfg.H,
                            "parallelism": f"dp{world}", "hop_weights": "SS (x nHop)",

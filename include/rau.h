@@ -67,7 +67,11 @@ typedef enum rau_mask_site {   /* the five nn.Dropout sites on the path */
 } rau_mask_site;
 
 typedef enum rau_dtype {
-  RAU_F32 = 0        /* f32 operands, f32 MFMA accumulate (exact fmaf chain) */
+  RAU_F32 = 0,       /* f32 operands, f32 MFMA accumulate (exact fmaf chain) */
+  RAU_BF16 = 1       /* the five 1x1-conv GEMMs (i_embed, ifeatproj and their gradients: 94-98 %
+                      * of the FLOPs) take bf16-rounded operands with f32 accumulation; all
+                      * tensors in memory, the recurrences, attention and loss stay f32
+                      * (BASELINE.json configs[2]: Ours_ResNet 14x14x2048, bf16 MFMA) */
 } rau_dtype;
 
 /* Network hyper-parameters: the hard-coded locals of SS:202,209-229 plus the

@@ -48,6 +48,38 @@ def rnn_specs(sh):
             ("l2_i2h", 4 * sh.Rq, sh.Rq), ("l2_h2h", 4 * sh.Rq, sh.Rq)]
 
 
+def _rb(x):
+    """Round to bfloat16 (RNE, via float32 like the device's staging path) and back."""
+    return x.detach().to(torch.float32).to(torch.bfloat16).to(x.dtype)
+
+
+class _Conv1x1BF16(torch.autograd.Function):
+    """y[b,o,s] = sum_i W[o,i] x[b,i,s] (+ bias) as librau's RAU_BF16 mode computes it: every GEMM
+    of the forward AND the backward rounds both of its operands to bf16 and accumulates exactly;
+    the bias, and everything outside the GEMMs, is untouched.  (The straight-through backward
+    of a rounded forward would not round dY; the device does, because dY is a GEMM operand.)"""
+
+    @staticmethod
+    def forward(ctx, x, W, b):
+        ctx.save_for_backward(x, W)
+        return torch.einsum("oi,bis->bos", _rb(W), _rb(x)) + b.view(1, -1, 1)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, W = ctx.saved_tensors
+        dyr = _rb(dy)
+        dx = torch.einsum("oi,bos->bis", _rb(W), dyr)
+        dW = torch.einsum("bos,bis->oi", dyr, _rb(x))
+        return dx, dW, dy.sum((0, 2))
+
+
+def _conv1x1(x3, W, b, bf16):
+    """1x1 SpatialConvolution on [B, C, S] (reference SS:240, SS:247)."""
+    if bf16:
+        return _Conv1x1BF16.apply(x3, W, b)
+    return F.conv2d(x3.unsqueeze(3), W.view(W.shape[0], W.shape[1], 1, 1), b).squeeze(3)
+
+
 def _drop(x, mask, p):
     """nn.Dropout v2 with an explicit keep mask (None = evaluate mode)."""
     if mask is None:
@@ -92,20 +124,19 @@ def att_lstm(sh, P, x, prev_c, prev_h):
     return next_c, next_h
 
 
-def multimodal(sh, P, q, feats4d, prev_c, prev_h, mq, mx, mmf):
-    """SS:292-307: returns (logits, do_pred, attprob, next_c, next_h)."""
+def multimodal(sh, P, q, feats4d, prev_c, prev_h, mq, mx, mmf, bf16=False):
+    """SS:292-307: returns (logits, do_pred, attprob, next_c, next_h).
+    bf16=True emulates librau's RAU_BF16 mode on the two 1x1 convolutions."""
     B = q.shape[0]
     # q_embed
     qf = torch.tanh(F.linear(_drop(q, mq, sh.p_q), P["q_proj.W"], P["q_proj.b"]) +
                     F.linear(prev_h, P["h_proj.W"], P["h_proj.b"]))
     # i_embed: Dropout -> 1x1 conv -> Tanh -> Reshape(M, S)
     xi = _drop(feats4d, mx, sh.p_x)
-    ifeat = torch.tanh(F.conv2d(xi, P["i_embed.W"].view(sh.M, sh.D, 1, 1), P["i_embed.b"]))
-    ifeat = ifeat.reshape(B, sh.M, sh.S)
+    ifeat = torch.tanh(_conv1x1(xi.reshape(B, sh.D, sh.S), P["i_embed.W"], P["i_embed.b"], bf16))
     # attbycontent
     qatt = F.linear(qf, P["att_q.W"], P["att_q.b"]).unsqueeze(2).expand(B, sh.A, sh.S)
-    iproj = F.conv2d(ifeat.reshape(B, sh.M, sh.S, 1), P["att_i.W"].view(sh.A, sh.M, 1, 1),
-                     P["att_i.b"]).reshape(B, sh.A, sh.S)
+    iproj = _conv1x1(ifeat, P["att_i.W"], P["att_i.b"], bf16)
     addfeat = torch.tanh(iproj + qatt).reshape(B, sh.A, sh.S, 1)
     attscore = F.conv2d(addfeat, P["att_score.W"].view(1, sh.A, 1, 1),
                         P["att_score.b"]).reshape(B, sh.S)
@@ -123,7 +154,7 @@ def multimodal(sh, P, q, feats4d, prev_c, prev_h, mq, mx, mmf):
 
 
 def step(sh, params, feats, tokens, lens, labels, masks=None, hop_w=None,
-         backward=True, dtype=torch.float64):
+         backward=True, dtype=torch.float64, bf16=False):
     """One feval forward(+backward), SS:428-596.  Same I/O convention as oracle.step."""
     t = lambda a: torch.as_tensor(a).to(dtype)
     flat = {k: t(params[k]).clone().requires_grad_(backward) for k in ("embed", "rnn", "mult")}
@@ -159,7 +190,7 @@ def step(sh, params, feats, tokens, lens, labels, masks=None, hop_w=None,
             sh, Pm, q, feats4d, c, h,
             None if m_q is None else m_q[hop],
             None if m_x is None else m_x[hop].reshape(sh.B, sh.D, sh.S, 1),
-            None if m_mf is None else m_mf[hop])
+            None if m_mf is None else m_mf[hop], bf16=bf16)
         out["logits"].append(score.detach())
         out["dopred"].append(dp.detach())
         out["att"].append(a.detach())

@@ -17,7 +17,7 @@ constexpr int BK = 32;
 // loader), B = X' [b][d][s] (position contiguous; dropout already applied by
 // dropout_features).  nB may be a group of hops.
 hipError_t conv_embed_fwd(hipStream_t st, int nB, int D, int S, int M, const float* X,
-                          const float* WiT, const float* bi, float* I) {
+                          const float* WiT, const float* bi, float* I, int bf16) {
   GemmParams P{};
   P.M = M; P.N = nB * S; P.K = D; P.nk = (D + BK - 1) / BK;
   P.A = WiT; P.a_rs = M;
@@ -26,6 +26,7 @@ hipError_t conv_embed_fwd(hipStream_t st, int nB, int D, int S, int M, const flo
   P.C = I; P.c_bs = (long)M * S;
   P.bias = bi;
   P.act = 1;
+  if (bf16) return launch_gemm<128, 128, BK, SRC_RC, SRC_RC_FLAT, EPI_CONV, 1>(st, P, 1);
   return launch_gemm<128, 128, BK, SRC_RC, SRC_RC_FLAT, EPI_CONV>(st, P, 1);
 }
 
@@ -33,7 +34,7 @@ hipError_t conv_embed_fwd(hipStream_t st, int nB, int D, int S, int M, const flo
 // pre-activation (reference SS:247-249); nB may be H*B.  The per-hop part
 // (+ u[b,k], tanh, score, softmax) is att_fwd_fused in kernels.hip.
 hipError_t conv_att_pre(hipStream_t st, int nB, int M, int S, int A, const float* I,
-                        const float* WpT, const float* bp, float* Pout) {
+                        const float* WpT, const float* bp, float* Pout, int bf16) {
   GemmParams P{};
   P.M = A; P.N = nB * S; P.K = M; P.nk = (M + BK - 1) / BK;
   P.A = WpT; P.a_rs = A;                // Wp^T [M][A]: reduction-major
@@ -42,6 +43,7 @@ hipError_t conv_att_pre(hipStream_t st, int nB, int M, int S, int A, const float
   P.C = Pout; P.c_bs = (long)A * S;
   P.bias = bp;
   P.act = 0;
+  if (bf16) return launch_gemm<128, 128, BK, SRC_RC, SRC_RC_FLAT, EPI_CONV, 1>(st, P, 1);
   return launch_gemm<128, 128, BK, SRC_RC, SRC_RC_FLAT, EPI_CONV>(st, P, 1);
 }
 
@@ -51,7 +53,7 @@ hipError_t conv_att_pre(hipStream_t st, int nB, int M, int S, int A, const float
 // row_sums_dtanh), not here: reading I in this short-K GEMM's epilogue cost more
 // than the GEMM itself.
 hipError_t conv_att_dgrad(hipStream_t st, int nB, int M, int S, int A, const float* dS,
-                          const float* Wp, const float* dj, const float* a, float* dI) {
+                          const float* Wp, const float* dj, const float* a, float* dI, int bf16) {
   GemmParams P{};
   P.M = M; P.N = nB * S; P.K = A; P.nk = (A + BK - 1) / BK;
   P.A = Wp; P.a_rs = M;                 // Wp stored [A][M]: reduction-major, m contiguous
@@ -59,6 +61,7 @@ hipError_t conv_att_dgrad(hipStream_t st, int nB, int M, int S, int A, const flo
   P.S = S;
   P.C = dI; P.c_bs = (long)M * S;
   P.v1 = dj; P.v2 = a;
+  if (bf16) return launch_gemm<128, 128, BK, SRC_RC, SRC_RC_FLAT, EPI_OUTER, 1>(st, P, 1);
   return launch_gemm<128, 128, BK, SRC_RC, SRC_RC_FLAT, EPI_OUTER>(st, P, 1);
 }
 
@@ -96,7 +99,7 @@ size_t conv_wgrad_slab_floats(int nB, int rowsA, int rowsB, int S) {
 
 // dW[ra, rb] += sum_{b,s} Aop[b,ra,s] * Bop[b,rb,s]; whole samples per split,
 // partial tiles to slabs, fixed-order reduction into dW.
-template <int BKT, int ASRC>
+template <int BKT, int ASRC, int DT = 0>
 static hipError_t conv_wgrad(hipStream_t st, GemmParams P, int nB, int S, float* dW,
                              float* slab) {
   P.S = S;
@@ -111,7 +114,7 @@ static hipError_t conv_wgrad(hipStream_t st, GemmParams P, int nB, int S, float*
   P.nk_per_split = spb * P.cps;
   const int splits = (P.nk + P.nk_per_split - 1) / P.nk_per_split;
   dim3 grid(P.tiles_m * P.tiles_n, 1, splits);
-  hipLaunchKernelGGL((gemm_kernel<128, 128, BKT, ASRC, SRC_SC, EPI_SLAB>), grid, dim3(256), 0,
+  hipLaunchKernelGGL((gemm_kernel<128, 128, BKT, ASRC, SRC_SC, EPI_SLAB, DT>), grid, dim3(256), 0,
                      st, P);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
@@ -119,7 +122,9 @@ static hipError_t conv_wgrad(hipStream_t st, GemmParams P, int nB, int S, float*
 }
 template <int ASRC>
 static hipError_t conv_wgrad_any(hipStream_t st, const GemmParams& P, int nB, int S, float* dW,
-                                 float* slab) {
+                                 float* slab, int bf16) {
+  // bf16 MFMA steps are 16 deep: 32-wide chunks, the last one of a 196-position map zero-filled
+  if (bf16) return conv_wgrad<32, ASRC, 1>(st, P, nB, S, dW, slab);
   // 14x14 maps: 196 = 7 * 28, so a 28-deep K-step wastes no MFMA work on padding
   if (S % 28 == 0) return conv_wgrad<28, ASRC>(st, P, nB, S, dW, slab);
   return conv_wgrad<32, ASRC>(st, P, nB, S, dW, slab);
@@ -127,23 +132,23 @@ static hipError_t conv_wgrad_any(hipStream_t st, const GemmParams& P, int nB, in
 
 // dWp[k,m] += sum_{b,s} dS[b,k,s] I[b,m,s]
 hipError_t conv_att_wgrad(hipStream_t st, int nB, int M, int S, int A, const float* dS,
-                          const float* I, float* dWp, float* slab) {
+                          const float* I, float* dWp, float* slab, int bf16) {
   GemmParams P{};
   P.M = A; P.N = M;
   P.A = dS; P.a_bs = (long)A * S;
   P.B = I; P.b_bs = (long)M * S;
-  return conv_wgrad_any<SRC_SC>(st, P, nB, S, dWp, slab);
+  return conv_wgrad_any<SRC_SC>(st, P, nB, S, dWp, slab, bf16);
 }
 
 // dWi[m,d] += sum_{b,s} dZ[b,m,s] X'[b,d,s] with dZ = dI * (1 - I^2) formed while
 // staging the operand (nB may be a group of hops)
 hipError_t conv_embed_wgrad(hipStream_t st, int nB, int D, int S, int M, const float* dI,
-                            const float* I, const float* X, float* dWi, float* slab) {
+                            const float* I, const float* X, float* dWi, float* slab, int bf16) {
   GemmParams P{};
   P.M = M; P.N = D;
   P.A = dI; P.A2 = I; P.a_bs = (long)M * S;
   P.B = X; P.b_bs = (long)D * S;
-  return conv_wgrad_any<SRC_SC_DTANH>(st, P, nB, S, dWi, slab);
+  return conv_wgrad_any<SRC_SC_DTANH>(st, P, nB, S, dWi, slab, bf16);
 }
 
 }  // namespace rau

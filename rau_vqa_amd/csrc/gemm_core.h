@@ -21,6 +21,21 @@ namespace rau {
 
 constexpr int LPAD = 4;   // row padding (floats): keeps 16-B alignment
 
+// ---- bf16-operand mode (rau_dtype RAU_BF16): operands are rounded to bf16 (RNE) while they
+// are staged into LDS, products accumulate in f32 (v_mfma_f32_32x32x16_bf16, 16x the f32 MFMA
+// rate, so these kernels become HBM-bound).  LDS image of a [BT rows][BKT k] operand tile:
+// BKT/4 planes of (BT + BPAD) 8-byte elements, element (p, r) = the four bf16 values
+// k = 4p..4p+3 of row r.  A lane's MFMA fragment (8 consecutive k of one row) is two
+// conflict-free ds_read_b64 from planes 2h and 2h+1.
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+constexpr int BPAD = 4;
+__device__ __forceinline__ uint2 pack_bf16x4(float a, float b, float c, float d) {
+  bf16x4 v;
+  v[0] = (__bf16)a; v[1] = (__bf16)b; v[2] = (__bf16)c; v[3] = (__bf16)d;
+  return __builtin_bit_cast(uint2, v);
+}
+
 // Superset of the arguments any loader/epilogue combination needs.
 struct GemmParams {
   int M, N, K;          // output rows / cols, reduction length (per sample in SC mode)
@@ -95,15 +110,25 @@ struct LoadKC {
       d[3 * (BT + LPAD)] = R.v[i].w;
     }
   }
+  __device__ __forceinline__ void store_bf16(uint2* img, int tid, const Regs& R) const {
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int r = tid / LPR + i * RPP;
+      img[(tid % LPR) * (BT + BPAD) + r] = pack_bf16x4(R.v[i].x, R.v[i].y, R.v[i].z, R.v[i].w);
+    }
+  }
 };
 
 // Operand stored [K][cols], cols contiguous.  FLAT: cols are a flattened
 // (sample, position) index, element (k, n) at base + (n/S)*bs + k*rs + n%S.
-template <int BT, int BKT, bool FLAT>
+// K4 (bf16 mode): a thread's NI rows are the consecutive k = 4*kr .. 4*kr+3 instead of
+// kr + i*RPP, so that it holds a whole 4-k plane element for each of its four columns.
+template <int BT, int BKT, bool FLAT, bool K4 = false>
 struct LoadRC {
   static constexpr int CPR = BT / 4;
   static constexpr int RPP = 256 / CPR;
   static constexpr int NI = BKT / RPP;
+  static_assert(!K4 || NI == 4, "K4 mapping needs four rows per thread");
   struct Regs { float4 v[NI]; };
   const float* p;
   long rs;
@@ -126,14 +151,15 @@ struct LoadRC {
   __device__ __forceinline__ void load(int step, Regs& R) const {
     const int k0 = step * BKT;
     if (FAST) {  // interior tile: no predicates, one pointer per step
-      const float* q = p + (long)(k0 + kr) * rs;
+      const float* q = p + (long)(k0 + (K4 ? 4 * kr : kr)) * rs;
 #pragma unroll
-      for (int i = 0; i < NI; ++i) R.v[i] = *reinterpret_cast<const float4*>(q + (long)i * RPP * rs);
+      for (int i = 0; i < NI; ++i)
+        R.v[i] = *reinterpret_cast<const float4*>(q + (long)i * (K4 ? 1 : RPP) * rs);
       return;
     }
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
-      const int k = k0 + kr + i * RPP;
+      const int k = K4 ? k0 + 4 * kr + i : k0 + kr + i * RPP;
       R.v[i] = (ok && k < K) ? *reinterpret_cast<const float4*>(p + (long)k * rs)
                              : make_float4(0.f, 0.f, 0.f, 0.f);
     }
@@ -142,6 +168,15 @@ struct LoadRC {
 #pragma unroll
     for (int i = 0; i < NI; ++i)
       *reinterpret_cast<float4*>(lds + (kr + i * RPP) * (BT + LPAD) + c4) = R.v[i];
+  }
+  __device__ __forceinline__ void store_bf16(uint2* img, int tid, const Regs& R) const {
+    if constexpr (K4) {
+      uint2* d = img + kr * (BT + BPAD) + c4;   // plane kr, columns c4..c4+3
+      d[0] = pack_bf16x4(R.v[0].x, R.v[1].x, R.v[2].x, R.v[3].x);
+      d[1] = pack_bf16x4(R.v[0].y, R.v[1].y, R.v[2].y, R.v[3].y);
+      d[2] = pack_bf16x4(R.v[0].z, R.v[1].z, R.v[2].z, R.v[3].z);
+      d[3] = pack_bf16x4(R.v[0].w, R.v[1].w, R.v[2].w, R.v[3].w);
+    }
   }
 };
 
@@ -221,6 +256,21 @@ struct LoadSC {
       d[3 * (BT + LPAD)] = x.w;
     }
   }
+  __device__ __forceinline__ void store_bf16(uint2* img, int tid, const Regs& R) const {
+    if (kc >= BKT) return;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int r = tid / LPR + i * RPP;
+      float4 x = R.v[i];
+      if (DT) {
+        x.x *= (1.f - R.y[i].x * R.y[i].x);
+        x.y *= (1.f - R.y[i].y * R.y[i].y);
+        x.z *= (1.f - R.y[i].z * R.y[i].z);
+        x.w *= (1.f - R.y[i].w * R.y[i].w);
+      }
+      img[(kc >> 2) * (BT + BPAD) + r] = pack_bf16x4(x.x, x.y, x.z, x.w);
+    }
+  }
 };
 
 // A/B "source kinds" used to pick a loader in the kernel template.
@@ -231,12 +281,12 @@ enum Src : int {
   SRC_SC = 3,        // [sample][rows][S], reduction over (sample, position)
   SRC_SC_DTANH = 4   // same, operand = A * (1 - A2^2)
 };
-template <int BT, int BKT, int SRC> struct LoaderOf;
-template <int BT, int BKT> struct LoaderOf<BT, BKT, SRC_KC> { using type = LoadKC<BT, BKT>; };
-template <int BT, int BKT> struct LoaderOf<BT, BKT, SRC_RC> { using type = LoadRC<BT, BKT, false>; };
-template <int BT, int BKT> struct LoaderOf<BT, BKT, SRC_RC_FLAT> { using type = LoadRC<BT, BKT, true>; };
-template <int BT, int BKT> struct LoaderOf<BT, BKT, SRC_SC> { using type = LoadSC<BT, BKT>; };
-template <int BT, int BKT> struct LoaderOf<BT, BKT, SRC_SC_DTANH> { using type = LoadSC<BT, BKT, true>; };
+template <int BT, int BKT, int SRC, bool K4 = false> struct LoaderOf;
+template <int BT, int BKT, bool K4> struct LoaderOf<BT, BKT, SRC_KC, K4> { using type = LoadKC<BT, BKT>; };
+template <int BT, int BKT, bool K4> struct LoaderOf<BT, BKT, SRC_RC, K4> { using type = LoadRC<BT, BKT, false, K4>; };
+template <int BT, int BKT, bool K4> struct LoaderOf<BT, BKT, SRC_RC_FLAT, K4> { using type = LoadRC<BT, BKT, true, K4>; };
+template <int BT, int BKT, bool K4> struct LoaderOf<BT, BKT, SRC_SC, K4> { using type = LoadSC<BT, BKT>; };
+template <int BT, int BKT, bool K4> struct LoaderOf<BT, BKT, SRC_SC_DTANH, K4> { using type = LoadSC<BT, BKT, true>; };
 
 // -------------------------------------------------------------- epilogues
 enum Epi : int {
@@ -246,9 +296,10 @@ enum Epi : int {
   EPI_OUTER = 3      // C = acc + dj[b,m] a[n]   (dI' of the attention backward)
 };
 
-template <int BM, int BN, int BKT, int ASRC, int BSRC, int EPI>
-__global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams P) {
+template <int BM, int BN, int BKT, int ASRC, int BSRC, int EPI, int DT = 0 /* 1: bf16 operands */>
+__global__ __launch_bounds__(256, DT ? 3 : 2) void gemm_kernel(const GemmParams P) {
   constexpr int BK = BKT;
+  static_assert(DT == 0 || (BM == 128 && BN == 128 && BKT == 32), "bf16 mode: 128x128x32 tiles");
   // long-reduction kernels (conv weight gradients) only: measured +9% there, 0 on the short-K convs
   constexpr bool PIN = (ASRC == SRC_SC || ASRC == SRC_SC_DTANH);
   if (BM < 128) RAU_CHAIN_PRIO();  // skinny tiles = chain-stream GEMMs
@@ -260,13 +311,18 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams P) {
   // footprint under 12 KB lets two chain workgroups share a CU, and these launches are
   // latency-bound, so the second barrier per K-step costs nothing measurable.
   constexpr int NST = BM >= 128 ? 2 : 1;
-  constexpr int kStage = NST * BK * LDA + NST * BK * LDB;  // floats of operand staging
+  // bf16 mode: BK/4 planes of (BT + BPAD) 8-byte elements per operand and stage
+  constexpr int PLA = (BM + BPAD) * (BK / 4), PLB = (BN + BPAD) * (BK / 4);   // uint2 per stage
+  constexpr int kStage = DT ? 2 * NST * (PLA + PLB)
+                            : NST * BK * LDA + NST * BK * LDB;  // floats of operand staging
   // epilogue scratch lives in the (then idle) staging area: per-row vectors,
   // per-(sample,row) vectors of the samples this tile's columns touch, column sums
   constexpr int kUCap = kStage - BM;
   __shared__ __attribute__((aligned(16))) float smem[kStage];
   float* As = smem;
   float* Bs = smem + NST * BK * LDA;
+  uint2* Ab16 = reinterpret_cast<uint2*>(smem);
+  uint2* Bb16 = Ab16 + NST * PLA;
 
   const int tid = threadIdx.x;
   const int l = tid & 63, w = tid >> 6;
@@ -281,8 +337,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams P) {
   int nsteps = P.nk - step0;
   if (nsteps > P.nk_per_split) nsteps = P.nk_per_split;
 
-  typename LoaderOf<BM, BKT, ASRC>::type LA;
-  typename LoaderOf<BN, BKT, BSRC>::type LB;
+  typename LoaderOf<BM, BKT, ASRC, DT != 0>::type LA;
+  typename LoaderOf<BN, BKT, BSRC, DT != 0>::type LB;
   const float* Abase = P.nbatch ? P.Ab[blockIdx.y] : P.A;
   const float* Bbase = P.nbatch ? P.Bb[blockIdx.y] : P.B;
   LA.init(P, Abase, P.a_rs, P.a_bs, m0, P.M, tid);
@@ -328,8 +384,36 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams P) {
     }
   };
 
-  using LAT = typename LoaderOf<BM, BKT, ASRC>::type;
-  using LBT = typename LoaderOf<BN, BKT, BSRC>::type;
+  // bf16 mode: per 16-deep k-step, fragment = planes 4s+2h and 4s+2h+1 of the lane's row
+  auto compute_bf16 = [&](int cur) {
+    const int r = l & 31, h = l >> 5;
+    const uint2* as = Ab16 + cur * PLA + wm * WM + r;
+    const uint2* bs = Bb16 + cur * PLB + wn * WN + r;
+#pragma unroll
+    for (int s = 0; s < BK / 16; ++s) {
+      bf16x8 a[IM], b[JN];
+#pragma unroll
+      for (int i = 0; i < IM; ++i) {
+        const uint2 lo = as[(4 * s + 2 * h) * (BM + BPAD) + i * 32];
+        const uint2 hi = as[(4 * s + 2 * h + 1) * (BM + BPAD) + i * 32];
+        a[i] = __builtin_bit_cast(bf16x8, make_uint4(lo.x, lo.y, hi.x, hi.y));
+      }
+#pragma unroll
+      for (int j = 0; j < JN; ++j) {
+        const uint2 lo = bs[(4 * s + 2 * h) * (BN + BPAD) + j * 32];
+        const uint2 hi = bs[(4 * s + 2 * h + 1) * (BN + BPAD) + j * 32];
+        b[j] = __builtin_bit_cast(bf16x8, make_uint4(lo.x, lo.y, hi.x, hi.y));
+      }
+#pragma unroll
+      for (int i = 0; i < IM; ++i)
+#pragma unroll
+        for (int j = 0; j < JN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+  };
+
+  using LAT = typename LoaderOf<BM, BKT, ASRC, DT != 0>::type;
+  using LBT = typename LoaderOf<BN, BKT, BSRC, DT != 0>::type;
   typename LAT::Regs ra0;
   typename LBT::Regs rb0;
   // Interior tiles (every row/column valid, reduction a whole number of K-steps: all
@@ -342,8 +426,13 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams P) {
     if (nsteps > 0) {
       LA.template load<FAST>(step0, ra0);
       LB.template load<FAST>(step0, rb0);
-      LA.store(As, tid, ra0);
-      LB.store(Bs, tid, rb0);
+      if constexpr (DT != 0) {
+        LA.store_bf16(Ab16, tid, ra0);
+        LB.store_bf16(Bb16, tid, rb0);
+      } else {
+        LA.store(As, tid, ra0);
+        LB.store(Bs, tid, rb0);
+      }
     }
     __syncthreads();
     for (int it = 0; it < nsteps; ++it) {
@@ -353,11 +442,16 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams P) {
         LA.template load<FAST>(step0 + it + 1, ra0);
         LB.template load<FAST>(step0 + it + 1, rb0);
       }
-      compute(cur);
+      if constexpr (DT != 0) compute_bf16(cur); else compute(cur);
       if (NST == 1) __syncthreads();   // everyone is done reading the single stage
       if (more && !(P.dbg & 1)) {
-        LA.store(As + (NST == 2 ? (cur ^ 1) * BK * LDA : 0), tid, ra0);
-        LB.store(Bs + (NST == 2 ? (cur ^ 1) * BK * LDB : 0), tid, rb0);
+        if constexpr (DT != 0) {
+          LA.store_bf16(Ab16 + (cur ^ 1) * PLA, tid, ra0);
+          LB.store_bf16(Bb16 + (cur ^ 1) * PLB, tid, rb0);
+        } else {
+          LA.store(As + (NST == 2 ? (cur ^ 1) * BK * LDA : 0), tid, ra0);
+          LB.store(Bs + (NST == 2 ? (cur ^ 1) * BK * LDB : 0), tid, rb0);
+        }
       }
       if (!(P.dbg & 2)) __syncthreads();
     }
@@ -461,7 +555,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams P) {
 }
 
 // ------------------------------------------------------------ host launch
-template <int BM, int BN, int BKT, int ASRC, int BSRC, int EPI>
+template <int BM, int BN, int BKT, int ASRC, int BSRC, int EPI, int DT = 0>
 inline hipError_t launch_gemm(hipStream_t st, GemmParams P, int splits) {
   P.tiles_m = (P.M + BM - 1) / BM;
   P.tiles_n = (P.N + BN - 1) / BN;
@@ -470,7 +564,7 @@ inline hipError_t launch_gemm(hipStream_t st, GemmParams P, int splits) {
   P.nk_per_split = (P.nk + splits - 1) / splits;
   splits = P.nk_per_split > 0 ? (P.nk + P.nk_per_split - 1) / P.nk_per_split : 1;
   dim3 grid(P.tiles_m * P.tiles_n, P.nbatch ? P.nbatch : 1, splits);
-  hipLaunchKernelGGL((gemm_kernel<BM, BN, BKT, ASRC, BSRC, EPI>), grid, dim3(256), 0, st, P);
+  hipLaunchKernelGGL((gemm_kernel<BM, BN, BKT, ASRC, BSRC, EPI, DT>), grid, dim3(256), 0, st, P);
   return hipGetLastError();
 }
 

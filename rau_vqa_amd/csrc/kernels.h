@@ -53,17 +53,20 @@ hipError_t gemm_tn_acc(hipStream_t st, int M, int N, int K, const float* A, long
 // ----------------------------------------------------------- conv GEMMs (gemm_conv.hip)
 // I[b,m,s] = tanh(sum_d Wi[m,d] * X'[b,d,s] + bi[m])   (reference SS:238-242; X' is the
 // feature map with dropout already applied, see dropout_features; nB may be H*B)
+// bf16 != 0 (rau_dtype RAU_BF16) on the five hop-batched conv GEMMs: operands rounded to bf16
+// while staged into LDS, f32 accumulate (v_mfma_f32_32x32x16_bf16); tensors in HBM stay f32.
 hipError_t conv_embed_fwd(hipStream_t st, int nB, int D, int S, int M, const float* X,
-                          const float* WiT /* [D][M] */, const float* bi, float* I);
+                          const float* WiT /* [D][M] */, const float* bi, float* I, int bf16 = 0);
 // P[b,k,s] = sum_m Wp[k,m] I[b,m,s] + bp[k]   (hop-invariant half of SS:244-252)
 hipError_t conv_att_pre(hipStream_t st, int nB, int M, int S, int A, const float* I,
-                        const float* WpT /* [M][A] */, const float* bp, float* P);
+                        const float* WpT /* [M][A] */, const float* bp, float* P, int bf16 = 0);
 // out[c][r] = in[r][c]  (rows x cols -> cols x rows); used once per step on the two
 // 1x1-conv weights so the forward conv GEMMs get a row-contiguous A operand
 hipError_t transpose2d(hipStream_t st, int rows, int cols, const float* in, float* out);
 // dI[b,m,s] = sum_k Wp[k,m] dS[b,k,s] + dj[b,m] a[b,s]   (gradient at i_embed's output)
 hipError_t conv_att_dgrad(hipStream_t st, int nB, int M, int S, int A, const float* dS,
-                          const float* Wp, const float* dj, const float* a, float* dI);
+                          const float* Wp, const float* dj, const float* a, float* dI,
+                          int bf16 = 0);
 // dX'[b,d,s] = sum_m Wi[m,d] dZ[b,m,s]   (dead in feval, SS:579; module-level API only)
 hipError_t conv_embed_dgrad(hipStream_t st, int nB, int D, int S, int M, const float* dZ,
                             const float* Wi, float* dX);
@@ -71,9 +74,10 @@ hipError_t conv_embed_dgrad(hipStream_t st, int nB, int D, int S, int M, const f
 // dWi[m,d] += sum_{b,s} dZ[b,m,s] X'[b,d,s]
 size_t conv_wgrad_slab_floats(int nB, int rowsA, int rowsB, int S);
 hipError_t conv_att_wgrad(hipStream_t st, int nB, int M, int S, int A, const float* dS,
-                          const float* I, float* dWp, float* slab);
+                          const float* I, float* dWp, float* slab, int bf16 = 0);
 hipError_t conv_embed_wgrad(hipStream_t st, int nB, int D, int S, int M, const float* dI,
-                            const float* I, const float* X, float* dWi, float* slab);
+                            const float* I, const float* X, float* dWi, float* slab,
+                            int bf16 = 0);
 
 // --------------------------------------------------------- pointwise (kernels.hip)
 enum GateOrder { GATES_ATT = 0 /* i g f o, ATTLSTM.lua:12-19 */,

@@ -69,6 +69,7 @@ struct ProfCls {
 struct rau_ctx {
   rau_config cfg;
   int Q;
+  int bf16 = 0;               // cfg.dtype == RAU_BF16: bf16-operand conv GEMMs
   hipStream_t st = nullptr;    // chain stream: recurrences, small GEMMs; what callers order against
   hipStream_t st2 = nullptr;   // bulk stream: hop-batched 1x1-conv GEMMs, overlapped with the chain
   hipStream_t st3 = nullptr;   // weight-gradient stream: throughput GEMMs nobody waits for until the end

@@ -85,7 +85,7 @@ int rau_create(const rau_config* cfg, rau_ctx** out) {
   NEED(c.Rq > 0 && c.Rq % 4 == 0 && c.R > 0 && c.R % 4 == 0 && c.M > 0 && c.M % 4 == 0 &&
            c.A > 0 && c.A % 4 == 0 && c.D > 0 && c.D % 4 == 0,
        "rau_create: Rq,R,M,A,D must be positive multiples of 4");
-  NEED(c.dtype == RAU_F32, "rau_create: dtype %d not supported", c.dtype);
+  NEED(c.dtype == RAU_F32 || c.dtype == RAU_BF16, "rau_create: dtype %d not supported", c.dtype);
   const float ps[5] = {c.p_we, c.p_rnn, c.p_q, c.p_x, c.p_mf};
   for (float p : ps) NEED(p >= 0.f && p < 1.f, "rau_create: dropout p=%f out of [0,1)", p);
 
@@ -105,6 +105,7 @@ int rau_create(const rau_config* cfg, rau_ctx** out) {
   rau_ctx* ctx = new rau_ctx();
   ctx->cfg = c;
   ctx->Q = 4 * c.Rq;
+  ctx->bf16 = c.dtype == RAU_BF16;
   for (int i = 0; i < 5; ++i) ctx->mp[i] = ps[i];
   *out = nullptr;
 #define CK(x)                \
@@ -765,10 +766,10 @@ int rau_forward(rau_ctx* ctx) {
       float* Pg = ctx->I_shared ? ctx->P0 : ctx->T + hb * A * S;
       RUNS(sb, "conv_embed_fwd", gflop(M, (double)nBI * S, D),
            ((double)nBI * D * S + (double)nBI * M * S) * 4,
-           conv_embed_fwd(sb, nBI, D, S, M, xin, ctx->WiT, ctx->i_embed.b, Ig));
+           conv_embed_fwd(sb, nBI, D, S, M, xin, ctx->WiT, ctx->i_embed.b, Ig, ctx->bf16));
       RUNS(sb, "conv_att_pre", gflop(A, (double)nBI * S, M),
            ((double)nBI * M * S + (double)nBI * A * S) * 4,
-           conv_att_pre(sb, nBI, M, S, A, Ig, ctx->WpT, ctx->att_i.b, Pg));
+           conv_att_pre(sb, nBI, M, S, A, Ig, ctx->WpT, ctx->att_i.b, Pg, ctx->bf16));
       HIPC(hipEventRecord(ctx->evF[h0], sb));
     }
   }
@@ -929,26 +930,27 @@ int rau_backward(rau_ctx* ctx, const float* hop_w) {
         RUNS(sb, "conv_att_dgrad", gflop(M, (double)nH * S, A),
              ((double)nH * A * S + 2.0 * nH * M * S) * 4,
              conv_att_dgrad(sb, nH, M, S, A, ctx->T + hb * A * S, ctx->att_i.W, ctx->dj + hb * M,
-                            ctx->a + hb * S, ctx->dZ + hb * M * S));
+                            ctx->a + hb * S, ctx->dZ + hb * M * S, ctx->bf16));
         RUNS(sb, "conv_att_wgrad", gflop(A, M, (double)nH * S),
              ((double)nH * A * S + (double)nH * M * S) * 4,
              conv_att_wgrad(sb, nH, M, S, A, ctx->T + hb * A * S, ctx->I + hb * M * S,
-                            ctx->att_i.dW, ctx->slab2));
+                            ctx->att_i.dW, ctx->slab2, ctx->bf16));
         RUNS(sb, "conv_embed_wgrad", gflop(M, D, (double)nH * S),
              ((double)nH * M * S + (double)nH * D * S) * 4,
              conv_embed_wgrad(sb, nH, D, S, M, ctx->dZ + hb * M * S, ctx->I + hb * M * S,
-                              ctx->xd + hb * D * S, ctx->i_embed.dW, ctx->slab2));
+                              ctx->xd + hb * D * S, ctx->i_embed.dW, ctx->slab2, ctx->bf16));
       } else {
         for (int hh2 = 0; hh2 < H; ++hh2) {  // evaluate mode: I (and X) shared by all hops
           float* Th2 = ctx->T + (size_t)hh2 * B * A * S;
           float* dZh = ctx->dZ + (size_t)hh2 * BM_ * S;
           RUNS(sb, "conv_att_dgrad", gflop(M, (double)B * S, A), ((double)B * A * S + 2.0 * BM_ * S) * 4,
                conv_att_dgrad(sb, B, M, S, A, Th2, ctx->att_i.W, ctx->dj + (size_t)hh2 * BM_,
-                              ctx->a + (size_t)hh2 * BS_, dZh));
+                              ctx->a + (size_t)hh2 * BS_, dZh, ctx->bf16));
           RUNS(sb, "conv_att_wgrad", gflop(A, M, (double)B * S), ((double)B * A * S + BM_ * S) * 4,
-               conv_att_wgrad(sb, B, M, S, A, Th2, ctx->I, ctx->att_i.dW, ctx->slab2));
+               conv_att_wgrad(sb, B, M, S, A, Th2, ctx->I, ctx->att_i.dW, ctx->slab2, ctx->bf16));
           RUNS(sb, "conv_embed_wgrad", gflop(M, D, (double)B * S), (BM_ * S + (double)B * D * S) * 4,
-               conv_embed_wgrad(sb, B, D, S, M, dZh, ctx->I, ctx->feats, ctx->i_embed.dW, ctx->slab2));
+               conv_embed_wgrad(sb, B, D, S, M, dZh, ctx->I, ctx->feats, ctx->i_embed.dW, ctx->slab2,
+                                ctx->bf16));
         }
       }
     }

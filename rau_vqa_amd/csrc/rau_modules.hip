@@ -286,9 +286,9 @@ int rau_multimodal_forward(rau_ctx* ctx, int h, const float* q, const float* X, 
   float* Ih = ctx->I + (size_t)h * BM_ * S;
   float* Th = ctx->T + (size_t)h * B * A * S;
   RUN("conv_embed_fwd", gflop(M, (double)B * S, D), ((double)B * D * S + BM_ * S) * 4,
-      conv_embed_fwd(st, B, D, S, M, xin, ctx->WiT, ctx->i_embed.b, Ih));
+      conv_embed_fwd(st, B, D, S, M, xin, ctx->WiT, ctx->i_embed.b, Ih, ctx->bf16));
   RUN("conv_att_pre", gflop(A, (double)B * S, M), (BM_ * S + (double)B * A * S) * 4,
-      conv_att_pre(st, B, M, S, A, Ih, ctx->WpT, ctx->att_i.b, Th));
+      conv_att_pre(st, B, M, S, A, Ih, ctx->WpT, ctx->att_i.b, Th, ctx->bf16));
   float* co = ctx->cc + (size_t)(h + 1) * BR_;
   float* ho = ctx->hh + (size_t)(h + 1) * BR_;
   if (int rc = hop_forward(ctx, h, c_prev, h_prev, co, ho, Ih, Th, nullptr)) return rc;
@@ -354,11 +354,11 @@ int rau_multimodal_backward(rau_ctx* ctx, int h, const float* q, const float* X,
   // dWi += (dI (1-I^2)) X'^T; bias gradients
   RUN("conv_att_dgrad", gflop(M, (double)B * S, A), ((double)B * A * S + 2.0 * BM_ * S) * 4,
       conv_att_dgrad(st, B, M, S, A, Th, ctx->att_i.W, ctx->dj + (size_t)h * BM_,
-                     ctx->a + (size_t)h * BS_, dZh));
+                     ctx->a + (size_t)h * BS_, dZh, ctx->bf16));
   RUN("conv_att_wgrad", gflop(A, M, (double)B * S), ((double)B * A * S + BM_ * S) * 4,
-      conv_att_wgrad(st, B, M, S, A, Th, Ih, ctx->att_i.dW, ctx->slab2));
+      conv_att_wgrad(st, B, M, S, A, Th, Ih, ctx->att_i.dW, ctx->slab2, ctx->bf16));
   RUN("conv_embed_wgrad", gflop(M, D, (double)B * S), (BM_ * S + (double)B * D * S) * 4,
-      conv_embed_wgrad(st, B, D, S, M, dZh, Ih, xin, ctx->i_embed.dW, ctx->slab2));
+      conv_embed_wgrad(st, B, D, S, M, dZh, Ih, xin, ctx->i_embed.dW, ctx->slab2, ctx->bf16));
   RUN("row_sums", 0, BM_ * S * 8.0, row_sums(st, B * M, S, dZh, Ih, ctx->rsum + (size_t)h * BM_));
   RUN("colsum", 0, (double)BM_ * 4,
       colsum_acc(st, B, M, ctx->rsum + (size_t)h * BM_, M, ctx->i_embed.db, ctx->coltmp3));

@@ -1,0 +1,98 @@
+"""rau_dtype RAU_BF16 (BASELINE.json configs[2]: bf16-operand MFMA on the 1x1-conv GEMMs).
+
+Two bars.  (1) Against the autograd restatement with the SAME rounding emulated
+(oracle/ref_torch.py bf16=True: every operand of the five conv GEMMs rounded to bfloat16,
+exact accumulation): 5e-4 max-norm relative -- what is left is f32 accumulation order plus the
+rare operand whose f32 value sits on a bf16 rounding boundary.  (2) Against the exact fp64
+oracle: 3e-2 -- the size of the bf16 rounding itself (about 1e-3 on these shapes), i.e. the
+mode is a precision trade, not a different computation.  Answer indices: exact wherever the
+emulated oracle's top-2 margin is decisive.
+"""
+import numpy as np
+import pytest
+
+from oracle import ref_torch as RT
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+TOL_EMU = 5e-4
+TOL_EXACT = 3e-2
+
+
+def run(dims, scale, mode="train", lens="ragged"):
+    from rau_vqa_amd.model import RAU, Config
+    sh = util.shapes(dims)
+    batch, params, masks = util.make_problem(sh, lens=lens, scale=scale)
+    hop_w = np.full(sh.H, float(sh.H), np.float32)
+    mk = masks if mode == "train" else None
+    args = (sh, params, batch["feats"], batch["tokens"], batch["lens"], batch["labels"], mk, hop_w)
+    emu = RT.step(*args, bf16=True)
+    exact = RT.step(*args)
+    cfg = Config(**{k: getattr(sh, k) for k in
+                    ("B", "T", "V", "E", "Rq", "D", "S", "M", "A", "R", "K", "H",
+                     "p_we", "p_rnn", "p_q", "p_x", "p_mf")}, dtype="bf16")
+    m = RAU(cfg)
+    m.set_params(params)
+    if mode == "train":
+        m.training()
+        m.set_masks(masks)
+    else:
+        m.evaluate()
+    m.set_batch(batch["feats"], batch["tokens"], batch["lens"], batch["labels"])
+    m.zero_grads()
+    m.forward()
+    got = m.outputs()
+    m.backward(hop_w)
+    g = m.get_grads()
+    layouts = {k: m.layout(k) for k in ("embed", "rnn", "mult")}
+    m.close()
+    for ref, tol, what in ((emu, TOL_EMU, "emulated"), (exact, TOL_EXACT, "exact")):
+        errs = {k: util.rel_err(got[k], ref[k]) for k in util.OUT_KEYS}
+        for grp in layouts:
+            for name, sl in util.layer_slices(layouts[grp]):
+                r = ref["g_" + grp][sl]
+                errs[name] = (float(np.max(np.abs(g[grp][sl] - r))) if np.max(np.abs(r)) < 1e-12
+                              else util.rel_err(g[grp][sl], r))
+        bad = {k: v for k, v in errs.items() if not v < tol}
+        assert not bad, f"vs {what} oracle above {tol}: {bad}\nall: {errs}"
+    ok, _, _ = util.argmax_margin_ok(emu["logits"], got["argmax"], emu["argmax"], margin=5e-3)
+    assert ok
+
+
+def test_bf16_small_train():
+    run(util.SMALL, 0.5)
+
+
+def test_bf16_small_eval():
+    run(util.SMALL, 0.5, mode="eval")
+
+
+def test_bf16_medium_s196_k1000():
+    run(util.MEDIUM, 0.2)
+
+
+def test_bf16_resnet_channels_d2048():
+    dims = dict(B=6, T=4, V=40, E=200, Rq=32, D=2048, S=196, M=64, A=32, R=32, K=1000, H=2)
+    run(dims, 0.05)
+
+
+def test_f32_results_do_not_depend_on_the_bf16_code_path():
+    """dtype f32 stays the exact path: bitwise equal outputs from two f32 contexts, and different
+    from the bf16 context's (guards against the flag leaking into the default mode)."""
+    from rau_vqa_amd.model import RAU, Config
+    sh = util.shapes(util.SMALL)
+    batch, params, masks = util.make_problem(sh, scale=0.5)
+    outs = []
+    for dt in ("f32", "f32", "bf16"):
+        m = RAU(Config(**{k: getattr(sh, k) for k in
+                          ("B", "T", "V", "E", "Rq", "D", "S", "M", "A", "R", "K", "H")}, dtype=dt))
+        m.set_params(params)
+        m.training()
+        m.set_masks(masks)
+        m.set_batch(batch["feats"], batch["tokens"], batch["lens"], batch["labels"])
+        m.forward()
+        outs.append(m.logits())
+        m.close()
+    assert np.array_equal(outs[0], outs[1])
+    assert not np.array_equal(outs[0], outs[2])
