@@ -3,6 +3,8 @@
 // allows), one wave per row for row reductions (64-lane shuffle trees), and
 // two-stage deterministic reductions instead of float atomics.
 #include "common.h"
+#include <cstdlib>
+
 #include "kernels.h"
 #include "philox.h"
 
@@ -355,17 +357,32 @@ hipError_t lstm_bwd_multi(hipStream_t st, int order, int nB, int R, const LstmBw
 // sample keep enough loads in flight to stream the ~0.8 MB a sample touches.
 // Wave w owns rows w, w+NW, ...; lane l owns the float4 column groups l, l+64, ...
 // Cross-wave sums go through LDS and are added in wave order (deterministic).
-constexpr int kAttWaves = 16;
-constexpr int kAttThreads = kAttWaves * 64;
+// waves per sample: 16 streams a sample fastest when the kernel has the GPU to itself, but a
+// 16-wave workgroup needs 4 x its VGPRs per SIMD and cannot start next to two resident
+// bulk-GEMM workgroups (2 x 144..168 of 512 VGPRs): it then waits for a bulk tile to retire.
+// Measured in the overlapped step: forward 0.94 ms with 16 waves vs 1.14 with 8; backward 1.00 ms
+// with 8 vs 1.07-1.25 with 16 (it runs next to the 160-VGPR weight-gradient GEMMs) -- but the
+// backward phase is throughput-bound, the step does not move (11.2-11.3 ms either way), so both
+// stay at 16.  RAU_ATT_WAVES_FWD / RAU_ATT_WAVES_BWD (4, 8 or 16) override.
+static int att_waves(bool bwd) {
+  static const int v[2] = {
+      [] { const char* e = std::getenv("RAU_ATT_WAVES_FWD"); const int n = e ? std::atoi(e) : 0;
+           return (n == 4 || n == 8 || n == 16) ? n : 16; }(),
+      [] { const char* e = std::getenv("RAU_ATT_WAVES_BWD"); const int n = e ? std::atoi(e) : 0;
+           return (n == 4 || n == 8 || n == 16) ? n : 16; }()};
+  return v[bwd ? 1 : 0];
+}
 
+template <int NW>
 __device__ __forceinline__ float block_sum_ordered(const float* red, int S, int s) {
   float v = red[s];
 #pragma unroll
-  for (int w = 1; w < kAttWaves; ++w) v += red[(size_t)w * S + s];
+  for (int w = 1; w < NW; ++w) v += red[(size_t)w * S + s];
   return v;
 }
 
-__global__ __launch_bounds__(kAttThreads) void k_att_fwd_fused(
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void k_att_fwd_fused(
     int M, int A, int S, const float* __restrict__ P, const float* __restrict__ u,
     const float* __restrict__ ws, const float* __restrict__ bs, const float* __restrict__ zm,
     const float* __restrict__ I, const float* __restrict__ qf, float* __restrict__ T,
@@ -373,7 +390,7 @@ __global__ __launch_bounds__(kAttThreads) void k_att_fwd_fused(
   RAU_CHAIN_PRIO();
   extern __shared__ __attribute__((aligned(16))) float sm[];
   float* red = sm;                     // [NW][S]
-  float* as = sm + kAttWaves * S;      // [S]
+  float* as = sm + NW * S;      // [S]
   float* sc = as + S;                  // [2*NW] block scalars
   const int b = blockIdx.x, tid = threadIdx.x, l = tid & 63, w = tid >> 6;
   const int S4 = S >> 2;
@@ -385,7 +402,7 @@ __global__ __launch_bounds__(kAttThreads) void k_att_fwd_fused(
     const int q = q0 + l;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     if (q < S4) {
-      for (int k = w; k < A; k += kAttWaves) {
+      for (int k = w; k < A; k += NW) {
         const float4 p = reinterpret_cast<const float4*>(Pb + (size_t)k * S)[q];
         const float uk = ub[k], wk = ws[k];
         float4 t;
@@ -400,8 +417,8 @@ __global__ __launch_bounds__(kAttThreads) void k_att_fwd_fused(
   __syncthreads();
   // ---- phase 2: a = softmax(e + bs + zm)
   float mx = -INFINITY;
-  for (int s = tid; s < S; s += kAttThreads) {
-    const float z = block_sum_ordered(red, S, s) + bs[0] + zm[(size_t)b * S + s];
+  for (int s = tid; s < S; s += (NW * 64)) {
+    const float z = block_sum_ordered<NW>(red, S, s) + bs[0] + zm[(size_t)b * S + s];
     as[s] = z;
     mx = fmaxf(mx, z);
   }
@@ -410,21 +427,21 @@ __global__ __launch_bounds__(kAttThreads) void k_att_fwd_fused(
   __syncthreads();
   mx = sc[0];
 #pragma unroll
-  for (int i = 1; i < kAttWaves; ++i) mx = fmaxf(mx, sc[i]);
+  for (int i = 1; i < NW; ++i) mx = fmaxf(mx, sc[i]);
   float den = 0.f;
-  for (int s = tid; s < S; s += kAttThreads) {
+  for (int s = tid; s < S; s += (NW * 64)) {
     const float ex = expf(as[s] - mx);
     as[s] = ex;
     den += ex;
   }
   den = wave_sum(den);
-  if (l == 0) sc[kAttWaves + w] = den;
+  if (l == 0) sc[NW + w] = den;
   __syncthreads();
-  den = sc[kAttWaves];
+  den = sc[NW];
 #pragma unroll
-  for (int i = 1; i < kAttWaves; ++i) den += sc[kAttWaves + i];
+  for (int i = 1; i < NW; ++i) den += sc[NW + i];
   const float inv = 1.f / den;
-  for (int s = tid; s < S; s += kAttThreads) {
+  for (int s = tid; s < S; s += (NW * 64)) {
     const float v = as[s] * inv;
     as[s] = v;
     a[(size_t)b * S + s] = v;
@@ -432,7 +449,7 @@ __global__ __launch_bounds__(kAttThreads) void k_att_fwd_fused(
   __syncthreads();
   // ---- phase 3: jv[m] = qf[m] + sum_s I[m,s] a[s]; one wave per row, 4 rows in flight
   const float* Ib = I + (size_t)b * M * S;
-  for (int m0 = w * 4; m0 < M; m0 += kAttWaves * 4) {
+  for (int m0 = w * 4; m0 < M; m0 += NW * 4) {
     float part[4] = {0.f, 0.f, 0.f, 0.f};
     for (int q = l; q < S4; q += 64) {
       const float4 av = reinterpret_cast<const float4*>(as)[q];
@@ -453,13 +470,17 @@ __global__ __launch_bounds__(kAttThreads) void k_att_fwd_fused(
 hipError_t att_fwd_fused(hipStream_t st, int nB, int M, int A, int S, const float* P,
                          const float* u, const float* ws, const float* bs, const float* zm,
                          const float* I, const float* qf, float* T, float* a, float* jv) {
-  const size_t lds = ((size_t)(kAttWaves + 1) * S + 2 * kAttWaves) * sizeof(float);
-  hipLaunchKernelGGL(k_att_fwd_fused, dim3(nB), dim3(kAttThreads), lds, st, M, A, S, P, u, ws, bs,
-                     zm, I, qf, T, a, jv);
+  const int nw = att_waves(false);
+  const size_t lds = ((size_t)(nw + 1) * S + 2 * nw) * sizeof(float);
+#define ATT_FWD(NW_) hipLaunchKernelGGL(k_att_fwd_fused<NW_>, dim3(nB), dim3(NW_ * 64), lds, st, M, A, \
+                                        S, P, u, ws, bs, zm, I, qf, T, a, jv)
+  if (nw == 4) ATT_FWD(4); else if (nw == 8) ATT_FWD(8); else ATT_FWD(16);
+#undef ATT_FWD
   return hipGetLastError();
 }
 
-__global__ __launch_bounds__(kAttThreads) void k_att_bwd_fused(
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void k_att_bwd_fused(
     int M, int A, int S, const float* __restrict__ I, const float* __restrict__ dj,
     const float* __restrict__ a, const float* __restrict__ da_lin, const float* __restrict__ ws,
     float* __restrict__ T, float* __restrict__ dz, float* __restrict__ du,
@@ -467,7 +488,7 @@ __global__ __launch_bounds__(kAttThreads) void k_att_bwd_fused(
   RAU_CHAIN_PRIO();
   extern __shared__ __attribute__((aligned(16))) float sm[];
   float* red = sm;                     // [NW][S]
-  float* dzs = sm + kAttWaves * S;     // [S]
+  float* dzs = sm + NW * S;     // [S]
   float* sc = dzs + S;                 // [NW]
   const int b = blockIdx.x, tid = threadIdx.x, l = tid & 63, w = tid >> 6;
   const int S4 = S >> 2;
@@ -478,7 +499,7 @@ __global__ __launch_bounds__(kAttThreads) void k_att_bwd_fused(
     const int q = q0 + l;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     if (q < S4) {
-      for (int m = w; m < M; m += kAttWaves) {
+      for (int m = w; m < M; m += NW) {
         const float d = djb[m];
         const float4 x = reinterpret_cast<const float4*>(Ib + (size_t)m * S)[q];
         acc.x += d * x.x; acc.y += d * x.y; acc.z += d * x.z; acc.w += d * x.w;
@@ -489,8 +510,8 @@ __global__ __launch_bounds__(kAttThreads) void k_att_bwd_fused(
   __syncthreads();
   // ---- phase 2: dz = a * (da - sum_s a da)
   float dot = 0.f;
-  for (int s = tid; s < S; s += kAttThreads) {
-    const float d = da_lin[(size_t)b * S + s] + block_sum_ordered(red, S, s);
+  for (int s = tid; s < S; s += (NW * 64)) {
+    const float d = da_lin[(size_t)b * S + s] + block_sum_ordered<NW>(red, S, s);
     dzs[s] = d;
     dot += a[(size_t)b * S + s] * d;
   }
@@ -499,8 +520,8 @@ __global__ __launch_bounds__(kAttThreads) void k_att_bwd_fused(
   __syncthreads();
   dot = sc[0];
 #pragma unroll
-  for (int i = 1; i < kAttWaves; ++i) dot += sc[i];
-  for (int s = tid; s < S; s += kAttThreads) {
+  for (int i = 1; i < NW; ++i) dot += sc[i];
+  for (int s = tid; s < S; s += (NW * 64)) {
     const float v = a[(size_t)b * S + s] * (dzs[s] - dot);
     dzs[s] = v;
     dz[(size_t)b * S + s] = v;
@@ -508,7 +529,7 @@ __global__ __launch_bounds__(kAttThreads) void k_att_bwd_fused(
   __syncthreads();
   // ---- phase 3: T -> dS in place, du[k] = sum_s dS, dwsp[k] = sum_s dz T; wave per row
   float* Tb = T + (size_t)b * A * S;
-  for (int k = w; k < A; k += kAttWaves) {
+  for (int k = w; k < A; k += NW) {
     const float wk = ws[k];
     float s1 = 0.f, s2 = 0.f;
     for (int q = l; q < S4; q += 64) {
@@ -534,9 +555,12 @@ __global__ __launch_bounds__(kAttThreads) void k_att_bwd_fused(
 hipError_t att_bwd_fused(hipStream_t st, int nB, int M, int A, int S, const float* I,
                          const float* dj, const float* a, const float* da_lin,
                          const float* ws, float* T_to_dS, float* dz, float* du, float* dwsp) {
-  const size_t lds = ((size_t)(kAttWaves + 1) * S + kAttWaves) * sizeof(float);
-  hipLaunchKernelGGL(k_att_bwd_fused, dim3(nB), dim3(kAttThreads), lds, st, M, A, S, I, dj, a,
-                     da_lin, ws, T_to_dS, dz, du, dwsp);
+  const int nw = att_waves(true);
+  const size_t lds = ((size_t)(nw + 1) * S + nw) * sizeof(float);
+#define ATT_BWD(NW_) hipLaunchKernelGGL(k_att_bwd_fused<NW_>, dim3(nB), dim3(NW_ * 64), lds, st, M, A, \
+                                        S, I, dj, a, da_lin, ws, T_to_dS, dz, du, dwsp)
+  if (nw == 4) ATT_BWD(4); else if (nw == 8) ATT_BWD(8); else ATT_BWD(16);
+#undef ATT_BWD
   return hipGetLastError();
 }
 
