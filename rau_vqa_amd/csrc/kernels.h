@@ -129,9 +129,14 @@ hipError_t lstm_bwd_multi(hipStream_t st, int order, int nB, int R, const LstmBw
 // One workgroup per sample: T = tanh(P + u[b,:,None]) (attbycontent, SS:250),
 // e = ws . T + bs (SS:251), a = softmax(e + zm) (attbymemory, SS:288-289),
 // jv = qf + sum_s I a (attselect SS:254-263 + first CAddTable SS:270).
+// ap: u and/or zm may be handed over as K-split GEMM partials ([split][nB][A] / [split][nB][S],
+// passed in the u / zm arguments) plus the Linear's bias, summed in order by the kernel itself --
+// two reduce launches less on the recurrence's critical path.
+struct AttPartials { int u_ns = 0; const float* u_bias = nullptr; int z_ns = 0; const float* z_bias = nullptr; };
 hipError_t att_fwd_fused(hipStream_t st, int nB, int M, int A, int S, const float* P,
                          const float* u, const float* ws, const float* bs, const float* zm,
-                         const float* I, const float* qf, float* T, float* a, float* jv);
+                         const float* I, const float* qf, float* T, float* a, float* jv,
+                         const AttPartials& ap = AttPartials());
 // One workgroup per sample, backward of the above: da = da_lin + sum_m dj I;
 // dz = softmax'(da); T -> dS = dz ws (1-T^2) in place; du = sum_s dS; dwsp = sum_s dz T.
 hipError_t att_bwd_fused(hipStream_t st, int nB, int M, int A, int S, const float* I,
@@ -147,9 +152,13 @@ hipError_t colsum_acc(hipStream_t st, int rows, int N, const float* X, long ld, 
                       float* tmp);
 // per-row CE: argmax (1-based, first max), loss row, dl = (softmax - onehot)/nB, do_pred
 // (labels == nullptr: no loss/dl; mf == nullptr: no do_pred)
+// nsplit > 0: the logits arrive as K-split partials `part` [split][nB][K] (+ bias) and are
+// finished here into logits_out
 hipError_t ce_fwd(hipStream_t st, int nB, int K, int M, const float* logits,
                   const int32_t* labels, const float* mf, const float* wd, const float* bd,
-                  float* dl, float* lossrow, int32_t* argmax, float* dopred);
+                  float* dl, float* lossrow, int32_t* argmax, float* dopred,
+                  const float* part = nullptr, int nsplit = 0, const float* bias = nullptr,
+                  float* logits_out = nullptr);
 hipError_t loss_reduce(hipStream_t st, int H, int nB, const float* lossrow, float* losses);
 hipError_t scale_hops(hipStream_t st, int H, size_t per_hop, const float* w_dev, float* x);
 hipError_t gather_q(hipStream_t st, int nB, int Rq, int T, const int32_t* lens, const float* c1,

@@ -386,7 +386,7 @@ __global__ __launch_bounds__(NW * 64) void k_att_fwd_fused(
     int M, int A, int S, const float* __restrict__ P, const float* __restrict__ u,
     const float* __restrict__ ws, const float* __restrict__ bs, const float* __restrict__ zm,
     const float* __restrict__ I, const float* __restrict__ qf, float* __restrict__ T,
-    float* __restrict__ a, float* __restrict__ jv) {
+    float* __restrict__ a, float* __restrict__ jv, AttPartials ap) {
   RAU_CHAIN_PRIO();
   extern __shared__ __attribute__((aligned(16))) float sm[];
   float* red = sm;                     // [NW][S]
@@ -397,6 +397,24 @@ __global__ __launch_bounds__(NW * 64) void k_att_fwd_fused(
   const float* Pb = P + (size_t)b * A * S;
   float* Tb = T + (size_t)b * A * S;
   const float* ub = u + (size_t)b * A;
+  // K-split partials of u / zm (+ bias) are finished here, once, into LDS
+  float* us = sc + 2 * NW;             // [A]
+  float* zs = us + A;                  // [S]
+  if (ap.u_ns) {
+    for (int k = tid; k < A; k += NW * 64) {
+      float v = ap.u_bias[k];
+      for (int sp = 0; sp < ap.u_ns; ++sp) v += u[((size_t)sp * gridDim.x + b) * A + k];
+      us[k] = v;
+    }
+  }
+  if (ap.z_ns) {
+    for (int s = tid; s < S; s += NW * 64) {
+      float v = ap.z_bias[s];
+      for (int sp = 0; sp < ap.z_ns; ++sp) v += zm[((size_t)sp * gridDim.x + b) * S + s];
+      zs[s] = v;
+    }
+  }
+  if (ap.u_ns || ap.z_ns) __syncthreads();
   // ---- phase 1: T = tanh(P + u), e[s] = sum_k ws[k] T[k,s]
   for (int q0 = 0; q0 < S4; q0 += 64) {
     const int q = q0 + l;
@@ -404,7 +422,8 @@ __global__ __launch_bounds__(NW * 64) void k_att_fwd_fused(
     if (q < S4) {
       for (int k = w; k < A; k += NW) {
         const float4 p = reinterpret_cast<const float4*>(Pb + (size_t)k * S)[q];
-        const float uk = ub[k], wk = ws[k];
+        const float uk = ap.u_ns ? us[k] : ub[k];
+        const float wk = ws[k];
         float4 t;
         t.x = tanh_fast(p.x + uk); t.y = tanh_fast(p.y + uk);
         t.z = tanh_fast(p.z + uk); t.w = tanh_fast(p.w + uk);
@@ -418,7 +437,8 @@ __global__ __launch_bounds__(NW * 64) void k_att_fwd_fused(
   // ---- phase 2: a = softmax(e + bs + zm)
   float mx = -INFINITY;
   for (int s = tid; s < S; s += (NW * 64)) {
-    const float z = block_sum_ordered<NW>(red, S, s) + bs[0] + zm[(size_t)b * S + s];
+    const float zmv = ap.z_ns ? zs[s] : zm[(size_t)b * S + s];
+    const float z = block_sum_ordered<NW>(red, S, s) + bs[0] + zmv;
     as[s] = z;
     mx = fmaxf(mx, z);
   }
@@ -469,11 +489,12 @@ __global__ __launch_bounds__(NW * 64) void k_att_fwd_fused(
 }
 hipError_t att_fwd_fused(hipStream_t st, int nB, int M, int A, int S, const float* P,
                          const float* u, const float* ws, const float* bs, const float* zm,
-                         const float* I, const float* qf, float* T, float* a, float* jv) {
+                         const float* I, const float* qf, float* T, float* a, float* jv,
+                         const AttPartials& ap) {
   const int nw = att_waves(false);
-  const size_t lds = ((size_t)(nw + 1) * S + 2 * nw) * sizeof(float);
+  const size_t lds = ((size_t)(nw + 2) * S + 2 * nw + A) * sizeof(float);
 #define ATT_FWD(NW_) hipLaunchKernelGGL(k_att_fwd_fused<NW_>, dim3(nB), dim3(NW_ * 64), lds, st, M, A, \
-                                        S, P, u, ws, bs, zm, I, qf, T, a, jv)
+                                        S, P, u, ws, bs, zm, I, qf, T, a, jv, ap)
   if (nw == 4) ATT_FWD(4); else if (nw == 8) ATT_FWD(8); else ATT_FWD(16);
 #undef ATT_FWD
   return hipGetLastError();
@@ -732,13 +753,24 @@ __global__ void k_ce_fwd(int nB, int K, int M, const float* __restrict__ logits,
                          const int32_t* __restrict__ labels, const float* __restrict__ mf,
                          const float* __restrict__ wd, const float* __restrict__ bd,
                          float* __restrict__ dl, float* __restrict__ lossrow,
-                         int32_t* __restrict__ argmax, float* __restrict__ dopred) {
+                         int32_t* __restrict__ argmax, float* __restrict__ dopred,
+                         const float* __restrict__ part, int nsplit,
+                         const float* __restrict__ bias, float* __restrict__ logits_out) {
   RAU_CHAIN_PRIO();
   __shared__ float s_val[4];
   __shared__ int s_idx[4];
   __shared__ float s_sum[4];
   const int b = blockIdx.x;
   const int tid = threadIdx.x, l = tid & 63, w = tid >> 6;
+  if (nsplit) {  // logits arrive as K-split partials [split][nB][K] of mf Wc^T: finish them here
+    for (int k = tid; k < K; k += 256) {
+      float v = bias[k];
+      for (int sp = 0; sp < nsplit; ++sp) v += part[((size_t)sp * nB + b) * K + k];
+      logits_out[(size_t)b * K + k] = v;
+    }
+    __syncthreads();   // the label's logit below is read by thread 0
+    logits = logits_out;
+  }
   const float* lg = logits + (size_t)b * K;
   // max + first argmax
   float mx = -INFINITY;
@@ -789,9 +821,10 @@ __global__ void k_ce_fwd(int nB, int K, int M, const float* __restrict__ logits,
 }
 hipError_t ce_fwd(hipStream_t st, int nB, int K, int M, const float* logits,
                   const int32_t* labels, const float* mf, const float* wd, const float* bd,
-                  float* dl, float* lossrow, int32_t* argmax, float* dopred) {
+                  float* dl, float* lossrow, int32_t* argmax, float* dopred, const float* part,
+                  int nsplit, const float* bias, float* logits_out) {
   hipLaunchKernelGGL(k_ce_fwd, dim3(nB), dim3(256), 0, st, nB, K, M, logits, labels, mf, wd, bd,
-                     dl, lossrow, argmax, dopred);
+                     dl, lossrow, argmax, dopred, part, nsplit, bias, logits_out);
   return hipGetLastError();
 }
 

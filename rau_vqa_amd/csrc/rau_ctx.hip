@@ -565,52 +565,71 @@ int hop_forward(rau_ctx* ctx, int h, const float* cp, const float* hp, float* c_
   float* g4 = ctx->g4 + (size_t)h * B * 4 * R;
   float* mfh = ctx->mf + (size_t)h * BM_;
   float* lg = ctx->logits + (size_t)h * B * K;
+  // Split-K partials of several of these GEMMs are summed by their CONSUMER kernel instead of a
+  // reduce launch (each launch on this dependent chain costs 8-20 us next to the bulk GEMMs):
+  // the slab is carved into four regions so that partials can stay alive side by side.
+  const size_t reg = ctx->slab_floats / 4;
+  float *slab_u = ctx->slab + reg, *slab_z = ctx->slab + 2 * reg, *slab_g = ctx->slab + 3 * reg;
+  int ns_u = 0, ns_z = 0, ns_h = 0, ns_i = 0, ns_c = 0;
   {  // q_embed SS:231-236
     LINOPTS(o);
+    o.slab_floats = reg;
     o.addend = ctx->Yq + (size_t)h * BM_;
     o.add_rs = M;
     o.act = 1;
     RUN("small_gemm", gflop(B, M, R), 0, gemm_nt(st, B, M, R, hp, R, ctx->h_proj.W, R, qf, M, o));
   }
-  {  // attbycontent SS:244-252
-    LINOPTS(o);
-    o.bias = ctx->att_q.b;
+  {  // attbycontent SS:244-252: u = qf Wa^T (+ ba inside att_fwd_fused)
+    LinOpts o;
+    o.slab = slab_u; o.slab_floats = reg; o.defer_splits = &ns_u;
     RUN("small_gemm", gflop(B, A, M), 0, gemm_nt(st, B, A, M, qf, M, ctx->att_q.W, M, ctx->u, A, o));
   }
-  {  // attbymemory SS:285-290 (linear part)
-    LINOPTS(o);
-    o.bias = ctx->att_mem.b;
+  {  // attbymemory SS:285-290 (linear part; + bm inside att_fwd_fused)
+    LinOpts o;
+    o.slab = slab_z; o.slab_floats = reg; o.defer_splits = &ns_z;
     RUN("small_gemm", gflop(B, S, R), 0, gemm_nt(st, B, S, R, hp, R, ctx->att_mem.W, R, ctx->zm, S, o));
   }
+  {  // attention LSTM's recurrent half h_prev Wr^T (ATTLSTM.lua:7): partials first in slab_g
+    LinOpts o;
+    o.slab = slab_g; o.slab_floats = reg / 2; o.defer_splits = &ns_h;
+    RUN("small_gemm", gflop(B, 4 * R, R), 0,
+        gemm_nt(st, B, 4 * R, R, hp, R, ctx->lstm_h2h.W, R, g4, 4 * R, o));
+  }
   // tanh(P+u), score, softmax, attention-weighted sum: one pass per sample
-  RUN("att_fwd_fused", 2.0 * B * S * (A + M), ((double)B * A * S * 2 + BM_ * S) * 4,
-      att_fwd_fused(st, B, M, A, S, Pin, ctx->u, ctx->att_score.W,
-                    ctx->att_score.b, ctx->zm, Ih, qf, Th, ah, ctx->jv));
+  {
+    AttPartials ap;
+    ap.u_ns = ns_u; ap.u_bias = ctx->att_q.b;
+    ap.z_ns = ns_z; ap.z_bias = ctx->att_mem.b;
+    RUN("att_fwd_fused", 2.0 * B * S * (A + M), ((double)B * A * S * 2 + BM_ * S) * 4,
+        att_fwd_fused(st, B, M, A, S, Pin, slab_u, ctx->att_score.W, ctx->att_score.b, slab_z, Ih, qf,
+                      Th, ah, ctx->jv, ap));
+  }
   {  // classifier SS:265-283
     LINOPTS(o);
+    o.slab_floats = reg;
     o.bias = ctx->feat_attprob.b;
     o.addend = ctx->jv;
     o.add_rs = M;
     RUN("small_gemm", gflop(B, M, S), 0, gemm_nt(st, B, M, S, ah, S, ctx->feat_attprob.W, S, jh, M, o));
   }
-  {
-    LINOPTS(o);
-    o.bias = ctx->lstm_i2h.b;
-    o.bias2 = ctx->lstm_h2h.b;
+  {  // j Wx^T partials right behind the recurrent ones; the cell kernel sums both + both biases
+    LinOpts o;
+    o.slab = slab_g + (size_t)ns_h * B * 4 * R; o.slab_floats = reg / 2; o.defer_splits = &ns_i;
     RUN("small_gemm", gflop(B, 4 * R, M), 0,
         gemm_nt(st, B, 4 * R, M, jh, M, ctx->lstm_i2h.W, M, g4, 4 * R, o));
-    int nsp = 0;
-    LINOPTS(oa);
-    oa.defer_splits = &nsp;
-    RUN("small_gemm", gflop(B, 4 * R, R), 0,
-        gemm_nt(st, B, 4 * R, R, hp, R, ctx->lstm_h2h.W, R, g4, 4 * R, oa));
-    RUN("lstm_fwd", 0, BR_ * 4.0 * 10,
-        lstm_fwd(st, GATES_ATT, B, R, g4, cp, R, c_out, R,
-                 h_out, R, ctx->tc + (size_t)h * BR_, nullptr, nullptr,
-                 0, 1.f, ctx->slab, nsp));
+    LstmFwdCells cells{};
+    cells.n = 1;
+    LstmFwdCell& C = cells.c[0];
+    C.g4 = g4; C.has_input = 0; C.b1 = ctx->lstm_i2h.b; C.b2 = ctx->lstm_h2h.b;
+    C.slab = slab_g; C.nsplit = ns_h + ns_i;
+    C.c_prev = cp; C.cp_rs = R; C.c = c_out; C.c_rs = R; C.h = h_out; C.h_rs = R;
+    C.tanhc = ctx->tc + (size_t)h * BR_;
+    C.drop_out = nullptr; C.mask = nullptr; C.mask_e0 = 0; C.mscale = 1.f;
+    RUN("lstm_fwd", 0, BR_ * 4.0 * 10, lstm_fwd_multi(st, GATES_ATT, B, R, cells));
   }
   {
     LINOPTS(o);
+    o.slab_floats = reg;
     o.bias = ctx->lstm_out.b;
     o.addend = jh;
     o.add_rs = M;
@@ -620,15 +639,16 @@ int hop_forward(rau_ctx* ctx, int h, const float* cp, const float* hp, float* c_
     RUN("small_gemm", gflop(B, M, R), 0,
         gemm_nt(st, B, M, R, h_out, R, ctx->lstm_out.W, R, mfh, M, o));
   }
-  {
-    LINOPTS(o);
-    o.bias = ctx->cls.b;
+  {  // out_score SS:280: partials finished (+ bias) by the criterion-head kernel
+    LinOpts o;
+    o.slab = slab_u; o.slab_floats = reg; o.defer_splits = &ns_c;
     RUN("small_gemm", gflop(B, K, M), 0, gemm_nt(st, B, K, M, mfh, M, ctx->cls.W, M, lg, K, o));
   }
   RUN("ce_fwd", 0, (double)B * K * 12,
       ce_fwd(st, B, K, M, lg, labels, mfh, ctx->do_pred.W,
              ctx->do_pred.b, ctx->dl + (size_t)h * B * K, ctx->lossrow + (size_t)h * B,
-             ctx->argmax_d + (size_t)h * B, ctx->dopred + (size_t)h * B));
+             ctx->argmax_d + (size_t)h * B, ctx->dopred + (size_t)h * B, slab_u, ns_c, ctx->cls.b,
+             lg));
   return RAU_OK;
 }
 
