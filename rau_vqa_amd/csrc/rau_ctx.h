@@ -76,8 +76,10 @@ struct rau_ctx {
   hipEvent_t evA = nullptr, evD = nullptr, evW = nullptr, evE = nullptr, evW3 = nullptr,
              evM3 = nullptr, evEnd = nullptr;
   std::vector<hipEvent_t> evF, evK;  // per hop group: forward bulk done / backward chain done
-  int cur_group = 1;                 // group size used by the last forward
-  int hop_group = 1;                 // hops per bulk launch (pipelines bulk GEMMs with the hop loops)
+  // hops per bulk launch (pipelines the bulk GEMMs with the hop loops): gsize[h] = n if hops
+  // [h, h+n) form one launch group, else 0.  `groups` is the configured partition, `cur` the one
+  // the last forward used (evaluate mode: one group of H).
+  std::vector<int> groups, cur;
   std::vector<void*> allocs;
   Group grp[3];
   // mult

@@ -153,10 +153,33 @@ int rau_create(const rau_config* cfg, rau_ctx** out) {
     hipDeviceGetStreamPriorityRange(&plo, &phi);
     hipStreamCreateWithPriority(&ctx->st3, hipStreamNonBlocking, plo);
   }
-  ctx->hop_group = (c.H % 2 == 0) ? 2 : 1;
-  if (const char* eg = std::getenv("RAU_HOP_GROUP")) {  // tuning knob: hops per bulk launch
-    const int g = std::atoi(eg);
-    if (g >= 1 && g <= c.H && c.H % g == 0) ctx->hop_group = g;
+  // Default partition: pairs, then the last two hops alone.  The forward phase ends one hop after
+  // the last group's GEMMs and the backward bulk work can start one hop into the backward chain
+  // (measured on H = 8: 2,2,2,1,1 vs 2,2,2,2); pairs elsewhere keep the launches large.
+  // RAU_HOP_GROUPS="4,2,1,1" overrides (sizes must sum to H).
+  {
+    std::vector<int> sizes;
+    if (const char* eg = std::getenv("RAU_HOP_GROUPS")) {
+      int sum = 0;
+      for (const char* p = eg; *p;) {
+        const int v = std::atoi(p);
+        if (v < 1) { sizes.clear(); break; }
+        sizes.push_back(v);
+        sum += v;
+        while (*p && *p != ',') ++p;
+        if (*p == ',') ++p;
+      }
+      if (sum != c.H) sizes.clear();
+    }
+    if (sizes.empty()) {
+      int left = c.H;
+      while (left > 3) { sizes.push_back(2); left -= 2; }
+      while (left > 0) { sizes.push_back(1); left -= 1; }
+      if (c.H == 2) sizes = {1, 1};
+    }
+    ctx->groups.assign(c.H, 0);
+    int h0 = 0;
+    for (int n : sizes) { ctx->groups[h0] = n; h0 += n; }
   }
   ctx->evF.resize(c.H);
   ctx->evK.resize(c.H);
@@ -767,8 +790,13 @@ int rau_forward(rau_ctx* ctx) {
   // Hops are launched in groups of `hop_group` so hop h's chain can start as soon
   // as its group is done while the bulk stream works on the later groups.
   ctx->I_shared = (m_x == nullptr);
-  const int GH = ctx->I_shared ? H : ctx->hop_group;   // hops per bulk launch
-  ctx->cur_group = GH;
+  if (ctx->I_shared) {   // evaluate mode: one launch group
+    ctx->cur.assign(H, 0);
+    ctx->cur[0] = H;
+  } else {
+    ctx->cur = ctx->groups;
+  }
+  const std::vector<int>& gsz = ctx->cur;
   {
     hipStream_t sb = ctx->st2;
     HIPC(hipEventRecord(ctx->evA, st));
@@ -778,8 +806,8 @@ int rau_forward(rau_ctx* ctx) {
     if (m_x)
       RUNS(sb, "dropout_features", 0, (double)(H + 1) * B * D * S * 4,
            dropout_features(sb, H, (size_t)B * D * S, ctx->feats, m_x, sc(RAU_MASK_X), ctx->xd));
-    for (int h0 = 0; h0 < H; h0 += GH) {
-      const int nBI = ctx->I_shared ? B : GH * B;
+    for (int h0 = 0; h0 < H; h0 += gsz[h0]) {
+      const int nBI = ctx->I_shared ? B : gsz[h0] * B;
       const size_t hb = ctx->I_shared ? 0 : (size_t)h0 * B;  // first (hop, sample) row
       const float* xin = m_x ? ctx->xd + hb * D * S : ctx->feats;
       float* Ig = ctx->I + hb * M * S;
@@ -876,7 +904,7 @@ int rau_forward(rau_ctx* ctx) {
   HIPC(hipMemsetAsync(ctx->cc, 0, BR_ * sizeof(float), st));  // att_c, att_h zeros SS:362-365
   HIPC(hipMemsetAsync(ctx->hh, 0, BR_ * sizeof(float), st));
   for (int h = 0; h < H; ++h) {
-    if (h % GH == 0) HIPC(hipStreamWaitEvent(st, ctx->evF[h], 0));  // this group's I and P are ready
+    if (gsz[h]) HIPC(hipStreamWaitEvent(st, ctx->evF[h], 0));  // this group's I and P are ready
     if (int rc = hop_forward(ctx, h, ctx->cc + (size_t)h * BR_, ctx->hh + (size_t)h * BR_,
                              ctx->cc + (size_t)(h + 1) * BR_, ctx->hh + (size_t)(h + 1) * BR_,
                              ctx->I + (ctx->I_shared ? 0 : (size_t)h * BM_ * S),
@@ -899,7 +927,7 @@ int rau_backward(rau_ctx* ctx, const float* hop_w) {
   const int B = c.B, E = c.E, Rq = c.Rq, D = c.D, S = c.S, M = c.M, A = c.A, R = c.R, K = c.K,
             H = c.H, Q = ctx->Q;
   const int TL = ctx->max_len;
-  const int GH = ctx->cur_group;
+  const std::vector<int>& gsz = ctx->cur;
   hipStream_t st = ctx->st;
   const bool tr = ctx->mode == RAU_MODE_TRAIN;
   auto mk = [&](int site) -> const uint32_t* {
@@ -940,12 +968,12 @@ int rau_backward(rau_ctx* ctx, const float* hop_w) {
     // SS:579, never formed).  As soon as a hop group's chain is done its conv gradients
     // start on the bulk stream, overlapping the remaining hops and the encoder BPTT:
     // dZ = (Wp^T dS + dj (x) a)(1 - I^2); dWp += dS I^T; dWi += dZ X'^T.
-    if (h % GH == 0) {
+    if (gsz[h]) {   // h is the first hop of its group: the whole group's chain is done
       hipStream_t sb = ctx->st2;
       HIPC(hipEventRecord(ctx->evK[h], st));
       HIPC(hipStreamWaitEvent(sb, ctx->evK[h], 0));
       if (!ctx->I_shared) {
-        const int nH = GH * B;
+        const int nH = gsz[h] * B;
         const size_t hb = (size_t)h * B;
         RUNS(sb, "conv_att_dgrad", gflop(M, (double)nH * S, A),
              ((double)nH * A * S + 2.0 * nH * M * S) * 4,
