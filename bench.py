@@ -206,6 +206,18 @@ def main():
             m.update(step_t=i)
         fence()
         extra["step_incl_update_ms"] = (time.perf_counter() - t1) / 5 * 1e3
+        # inference (predict_result, SS:633-705: evaluate mode, forward only, i_embed / ifeatproj
+        # hoisted out of the hop loop), reported separately
+        m.evaluate()
+        for i in range(2):
+            m.forward()
+        fence()
+        t2 = time.perf_counter()
+        for i in range(10):
+            m.forward()
+        fence()
+        extra["inference_qa_per_s"] = cfg.B * 10 / (time.perf_counter() - t2)
+        m.training()
         if world == 1 and not args.no_cpu_baseline:
             extra["cpu_baseline"] = cpu_baseline(cfgd)
     elif world > 1:
@@ -217,6 +229,11 @@ def main():
             step(2000 + i)
             m.update(step_t=i)
         fence()
+        m.evaluate()
+        for i in range(12):
+            m.forward()
+        fence()
+        m.training()
 
     if rank == 0:
         qa = cfg.B * world * args.steps / dt
