@@ -94,14 +94,15 @@ static int conv_wgrad_splits(int nB, int rowsA, int rowsB) {
   return s;
 }
 size_t conv_wgrad_slab_floats(int nB, int rowsA, int rowsB, int S) {
-  return (size_t)conv_wgrad_splits(nB, rowsA, rowsB) * rowsA * rowsB;
+  // split partials of the product + of the A operand's row sums (i_embed bias gradient)
+  return (size_t)conv_wgrad_splits(nB, rowsA, rowsB) * ((size_t)rowsA * rowsB + rowsA);
 }
 
 // dW[ra, rb] += sum_{b,s} Aop[b,ra,s] * Bop[b,rb,s]; whole samples per split,
 // partial tiles to slabs, fixed-order reduction into dW.
 template <int BKT, int ASRC, int DT = 0>
 static hipError_t conv_wgrad(hipStream_t st, GemmParams P, int nB, int S, float* dW,
-                             float* slab) {
+                             float* slab, float* drow = nullptr) {
   P.S = S;
   P.cps = (S + BKT - 1) / BKT;
   P.K = S;
@@ -113,21 +114,24 @@ static hipError_t conv_wgrad(hipStream_t st, GemmParams P, int nB, int S, float*
   P.tiles_n = (P.N + 127) / 128;
   P.nk_per_split = spb * P.cps;
   const int splits = (P.nk + P.nk_per_split - 1) / P.nk_per_split;
+  P.rs_out = drow ? slab + (size_t)splits * P.M * P.N : nullptr;
   dim3 grid(P.tiles_m * P.tiles_n, 1, splits);
   hipLaunchKernelGGL((gemm_kernel<128, 128, BKT, ASRC, SRC_SC, EPI_SLAB, DT>), grid, dim3(256), 0,
                      st, P);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
-  return splitk_reduce_acc(st, (size_t)P.M * P.N, splits, slab, (size_t)P.M * P.N, dW);
+  e = splitk_reduce_acc(st, (size_t)P.M * P.N, splits, slab, (size_t)P.M * P.N, dW);
+  if (e != hipSuccess || !drow) return e;
+  return splitk_reduce_acc(st, (size_t)P.M, splits, P.rs_out, (size_t)P.M, drow);
 }
 template <int ASRC>
 static hipError_t conv_wgrad_any(hipStream_t st, const GemmParams& P, int nB, int S, float* dW,
-                                 float* slab, int bf16) {
+                                 float* slab, int bf16, float* drow = nullptr) {
   // bf16 MFMA steps are 16 deep: 32-wide chunks, the last one of a 196-position map zero-filled
-  if (bf16) return conv_wgrad<32, ASRC, 1>(st, P, nB, S, dW, slab);
+  if (bf16) return conv_wgrad<32, ASRC, 1>(st, P, nB, S, dW, slab, drow);
   // 14x14 maps: 196 = 7 * 28, so a 28-deep K-step wastes no MFMA work on padding
-  if (S % 28 == 0) return conv_wgrad<28, ASRC>(st, P, nB, S, dW, slab);
-  return conv_wgrad<32, ASRC>(st, P, nB, S, dW, slab);
+  if (S % 28 == 0) return conv_wgrad<28, ASRC>(st, P, nB, S, dW, slab, drow);
+  return conv_wgrad<32, ASRC>(st, P, nB, S, dW, slab, drow);
 }
 
 // dWp[k,m] += sum_{b,s} dS[b,k,s] I[b,m,s]
@@ -143,12 +147,13 @@ hipError_t conv_att_wgrad(hipStream_t st, int nB, int M, int S, int A, const flo
 // dWi[m,d] += sum_{b,s} dZ[b,m,s] X'[b,d,s] with dZ = dI * (1 - I^2) formed while
 // staging the operand (nB may be a group of hops)
 hipError_t conv_embed_wgrad(hipStream_t st, int nB, int D, int S, int M, const float* dI,
-                            const float* I, const float* X, float* dWi, float* slab, int bf16) {
+                            const float* I, const float* X, float* dWi, float* slab, int bf16,
+                            float* dbi) {
   GemmParams P{};
   P.M = M; P.N = D;
   P.A = dI; P.A2 = I; P.a_bs = (long)M * S;
   P.B = X; P.b_bs = (long)D * S;
-  return conv_wgrad_any<SRC_SC_DTANH>(st, P, nB, S, dWi, slab, bf16);
+  return conv_wgrad_any<SRC_SC_DTANH>(st, P, nB, S, dWi, slab, bf16, dbi);
 }
 
 }  // namespace rau

@@ -63,6 +63,7 @@ struct GemmParams {
   // conv epilogue extras
   const float* v1;     // dj [sample][M]
   const float* v2;     // a  [sample][S]
+  float* rs_out;       // SC_DTANH A operand: row sums of the staged operand, partial [split][M]
   int dbg;             // tools/kbench only: 1 = no global loads in the loop, 2 = no barriers
 };
 
@@ -198,6 +199,7 @@ struct LoadSC {
   const float* base2;
   long bs;
   int kc, S, cps;
+  mutable float rsum[NI];   // DT: running sum over k of this thread's share of row r (bias gradient)
   __device__ __forceinline__ void init(const GemmParams& P, const float* base_, long rs,
                                        long bs_, int row0, int rows, int tid) {
     base = base_;
@@ -211,6 +213,7 @@ struct LoadSC {
       const int r = tid / LPR + i * RPP;
       ok[i] = row0 + r < rows;
       roff[i] = (long)(row0 + r) * S + kc;
+      rsum[i] = 0.f;
     }
   }
   template <bool FAST>
@@ -248,6 +251,7 @@ struct LoadSC {
         x.y *= (1.f - R.y[i].y * R.y[i].y);
         x.z *= (1.f - R.y[i].z * R.y[i].z);
         x.w *= (1.f - R.y[i].w * R.y[i].w);
+        rsum[i] += (x.x + x.y) + (x.z + x.w);
       }
       float* d = lds + kc * (BT + LPAD) + r;
       d[0] = x.x;
@@ -267,6 +271,7 @@ struct LoadSC {
         x.y *= (1.f - R.y[i].y * R.y[i].y);
         x.z *= (1.f - R.y[i].z * R.y[i].z);
         x.w *= (1.f - R.y[i].w * R.y[i].w);
+        rsum[i] += (x.x + x.y) + (x.z + x.w);
       }
       img[(kc >> 2) * (BT + BPAD) + r] = pack_bf16x4(x.x, x.y, x.z, x.w);
     }
@@ -460,6 +465,24 @@ __global__ __launch_bounds__(256, DT ? 3 : 2) void gemm_kernel(const GemmParams 
     mainloop(std::true_type{});
   else
     mainloop(std::false_type{});
+
+  // i_embed bias gradient for free: the staged A operand of the i_embed weight gradient IS
+  // dZ = dI (1 - I^2); the workgroups of the first tile column hand back its row sums over
+  // their K range (fixed-order lane tree, then a split reduction by the launcher).
+  if constexpr (ASRC == SRC_SC_DTANH) {
+    if (P.rs_out && tn == 0) {
+      constexpr int NIA = LAT::NI;
+#pragma unroll
+      for (int i = 0; i < NIA; ++i) {
+        float v = LA.rsum[i];
+        v += __shfl_xor(v, 1, 64);
+        v += __shfl_xor(v, 2, 64);
+        v += __shfl_xor(v, 4, 64);
+        const int m = m0 + tid / 8 + i * 32;
+        if ((tid & 7) == 0 && m < P.M) P.rs_out[(long)blockIdx.z * P.M + m] = v;
+      }
+    }
+  }
 
   // ------------------------------------------------------------ epilogue
   // accumulator element r of block (i,j): row = (r&3) + 8*(r>>2) + 4*(l>>5), col = l&31

@@ -77,7 +77,7 @@ hipError_t conv_att_wgrad(hipStream_t st, int nB, int M, int S, int A, const flo
                           const float* I, float* dWp, float* slab, int bf16 = 0);
 hipError_t conv_embed_wgrad(hipStream_t st, int nB, int D, int S, int M, const float* dI,
                             const float* I, const float* X, float* dWi, float* slab,
-                            int bf16 = 0);
+                            int bf16 = 0, float* dbi = nullptr /* += sum_{b,s} dZ[b,m,s] */);
 
 // --------------------------------------------------------- pointwise (kernels.hip)
 enum GateOrder { GATES_ATT = 0 /* i g f o, ATTLSTM.lua:12-19 */,

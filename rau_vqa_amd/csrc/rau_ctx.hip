@@ -986,7 +986,8 @@ int rau_backward(rau_ctx* ctx, const float* hop_w) {
         RUNS(sb, "conv_embed_wgrad", gflop(M, D, (double)nH * S),
              ((double)nH * M * S + (double)nH * D * S) * 4,
              conv_embed_wgrad(sb, nH, D, S, M, ctx->dZ + hb * M * S, ctx->I + hb * M * S,
-                              ctx->xd + hb * D * S, ctx->i_embed.dW, ctx->slab2, ctx->bf16));
+                              ctx->xd + hb * D * S, ctx->i_embed.dW, ctx->slab2, ctx->bf16,
+                              ctx->i_embed.db));
       } else {
         for (int hh2 = 0; hh2 < H; ++hh2) {  // evaluate mode: I (and X) shared by all hops
           float* Th2 = ctx->T + (size_t)hh2 * B * A * S;
@@ -998,7 +999,7 @@ int rau_backward(rau_ctx* ctx, const float* hop_w) {
                conv_att_wgrad(sb, B, M, S, A, Th2, ctx->I, ctx->att_i.dW, ctx->slab2, ctx->bf16));
           RUNS(sb, "conv_embed_wgrad", gflop(M, D, (double)B * S), (BM_ * S + (double)B * D * S) * 4,
                conv_embed_wgrad(sb, B, D, S, M, dZh, ctx->I, ctx->feats, ctx->i_embed.dW, ctx->slab2,
-                                ctx->bf16));
+                                ctx->bf16, ctx->i_embed.db));
         }
       }
     }
@@ -1010,21 +1011,10 @@ int rau_backward(rau_ctx* ctx, const float* hop_w) {
     RUN("dq_reduce", 0, (double)H * B * Q * 4,
         dq_reduce(st, H, (size_t)B * Q, ctx->dQD, m_q, sc(RAU_MASK_Q), ctx->dq));
   }
-  // bulk stream tail: i_embed bias gradient over all hops, then the join event
+  // bulk stream tail: the join event (the i_embed bias gradient comes out of conv_embed_wgrad:
+  // row sums of its staged dZ operand)
   {
     hipStream_t sb = ctx->st2;
-    // i_embed bias gradient: sum_s dI (1 - I^2) per (hop, sample, channel) row
-    if (!ctx->I_shared) {
-      RUNS(sb, "row_sums", 0, (double)H * BM_ * S * 8.0,
-           row_sums(sb, H * B * M, S, ctx->dZ, ctx->I, ctx->rsum));
-    } else {
-      for (int h2 = 0; h2 < H; ++h2)
-        RUNS(sb, "row_sums", 0, BM_ * S * 8.0,
-             row_sums(sb, B * M, S, ctx->dZ + (size_t)h2 * BM_ * S, ctx->I,
-                      ctx->rsum + (size_t)h2 * BM_));
-    }
-    RUNS(sb, "colsum", 0, (double)H * B * M * 4,
-         colsum_acc(sb, H * B, M, ctx->rsum, M, ctx->i_embed.db, ctx->coltmp2));
     HIPC(hipEventRecord(ctx->evD, sb));
   }
   // ---------------- mult-group weight gradients, one GEMM per weight over all hops.

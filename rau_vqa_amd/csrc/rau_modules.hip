@@ -358,10 +358,8 @@ int rau_multimodal_backward(rau_ctx* ctx, int h, const float* q, const float* X,
   RUN("conv_att_wgrad", gflop(A, M, (double)B * S), ((double)B * A * S + BM_ * S) * 4,
       conv_att_wgrad(st, B, M, S, A, Th, Ih, ctx->att_i.dW, ctx->slab2, ctx->bf16));
   RUN("conv_embed_wgrad", gflop(M, D, (double)B * S), (BM_ * S + (double)B * D * S) * 4,
-      conv_embed_wgrad(st, B, D, S, M, dZh, Ih, xin, ctx->i_embed.dW, ctx->slab2, ctx->bf16));
-  RUN("row_sums", 0, BM_ * S * 8.0, row_sums(st, B * M, S, dZh, Ih, ctx->rsum + (size_t)h * BM_));
-  RUN("colsum", 0, (double)BM_ * 4,
-      colsum_acc(st, B, M, ctx->rsum + (size_t)h * BM_, M, ctx->i_embed.db, ctx->coltmp3));
+      conv_embed_wgrad(st, B, D, S, M, dZh, Ih, xin, ctx->i_embed.dW, ctx->slab2, ctx->bf16,
+                       ctx->i_embed.db));
   // ---- gradient w.r.t. q through q_embed's dropout
   float* dqo = ctx->m_dq + (size_t)h * B * Q;
   {
