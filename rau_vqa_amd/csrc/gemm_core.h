@@ -124,7 +124,9 @@ struct LoadKC {
 // (sample, position) index, element (k, n) at base + (n/S)*bs + k*rs + n%S.
 // K4 (bf16 mode): a thread's NI rows are the consecutive k = 4*kr .. 4*kr+3 instead of
 // kr + i*RPP, so that it holds a whole 4-k plane element for each of its four columns.
-template <int BT, int BKT, bool FLAT, bool K4 = false>
+// CS: keep running column sums of everything staged (the bias gradient of a Linear falls out of
+// its weight-gradient GEMM's dY operand).
+template <int BT, int BKT, bool FLAT, bool K4 = false, bool CS = false>
 struct LoadRC {
   static constexpr int CPR = BT / 4;
   static constexpr int RPP = 256 / CPR;
@@ -135,10 +137,12 @@ struct LoadRC {
   long rs;
   bool ok;
   int kr, c4, K;
+  mutable float4 csum;
   __device__ __forceinline__ void init(const GemmParams& P, const float* base, long rs_,
                                        long bs, int col0, int cols, int tid) {
     K = P.K;
     rs = rs_;
+    csum = make_float4(0.f, 0.f, 0.f, 0.f);
     c4 = (tid % CPR) * 4;
     kr = tid / CPR;
     const int col = col0 + c4;
@@ -167,8 +171,12 @@ struct LoadRC {
   }
   __device__ __forceinline__ void store(float* lds, int tid, const Regs& R) const {
 #pragma unroll
-    for (int i = 0; i < NI; ++i)
+    for (int i = 0; i < NI; ++i) {
       *reinterpret_cast<float4*>(lds + (kr + i * RPP) * (BT + LPAD) + c4) = R.v[i];
+      if (CS) {
+        csum.x += R.v[i].x; csum.y += R.v[i].y; csum.z += R.v[i].z; csum.w += R.v[i].w;
+      }
+    }
   }
   __device__ __forceinline__ void store_bf16(uint2* img, int tid, const Regs& R) const {
     if constexpr (K4) {
@@ -284,7 +292,8 @@ enum Src : int {
   SRC_RC = 1,        // [K][cols]
   SRC_RC_FLAT = 2,   // [sample][K][S], flattened columns
   SRC_SC = 3,        // [sample][rows][S], reduction over (sample, position)
-  SRC_SC_DTANH = 4   // same, operand = A * (1 - A2^2)
+  SRC_SC_DTANH = 4,  // same, operand = A * (1 - A2^2)
+  SRC_RC_SUM = 5     // [K][cols] + column sums of the operand handed back (P.rs_out)
 };
 template <int BT, int BKT, int SRC, bool K4 = false> struct LoaderOf;
 template <int BT, int BKT, bool K4> struct LoaderOf<BT, BKT, SRC_KC, K4> { using type = LoadKC<BT, BKT>; };
@@ -292,6 +301,7 @@ template <int BT, int BKT, bool K4> struct LoaderOf<BT, BKT, SRC_RC, K4> { using
 template <int BT, int BKT, bool K4> struct LoaderOf<BT, BKT, SRC_RC_FLAT, K4> { using type = LoadRC<BT, BKT, true, K4>; };
 template <int BT, int BKT, bool K4> struct LoaderOf<BT, BKT, SRC_SC, K4> { using type = LoadSC<BT, BKT>; };
 template <int BT, int BKT, bool K4> struct LoaderOf<BT, BKT, SRC_SC_DTANH, K4> { using type = LoadSC<BT, BKT, true>; };
+template <int BT, int BKT, bool K4> struct LoaderOf<BT, BKT, SRC_RC_SUM, K4> { using type = LoadRC<BT, BKT, false, K4, true>; };
 
 // -------------------------------------------------------------- epilogues
 enum Epi : int {
@@ -480,6 +490,34 @@ __global__ __launch_bounds__(256, DT ? 3 : 2) void gemm_kernel(const GemmParams 
         v += __shfl_xor(v, 4, 64);
         const int m = m0 + tid / 8 + i * 32;
         if ((tid & 7) == 0 && m < P.M) P.rs_out[(long)blockIdx.z * P.M + m] = v;
+      }
+    }
+  }
+
+  // Linear bias gradient for free: column sums of the staged dY operand (first tile column
+  // only), combined over the RPP threads of a column group through the idle staging LDS in
+  // fixed order, one partial row per K split.
+  if constexpr (ASRC == SRC_RC_SUM) {
+    if (P.rs_out && tn == 0) {
+      float4* red = reinterpret_cast<float4*>(smem);        // [RPP][BM/4]
+      red[LA.kr * (BM / 4) + (LA.c4 >> 2)] = LA.csum;
+      __syncthreads();
+      if (tid < BM / 4) {
+        float4 v = red[tid];
+#pragma unroll
+        for (int q = 1; q < LAT::RPP; ++q) {
+          const float4 w4 = red[q * (BM / 4) + tid];
+          v.x += w4.x; v.y += w4.y; v.z += w4.z; v.w += w4.w;
+        }
+        const int m = m0 + tid * 4;
+        float* o = P.rs_out + (long)blockIdx.z * P.M + m;
+        if (m + 3 < P.M) {
+          o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+        } else {
+          if (m < P.M) o[0] = v.x;
+          if (m + 1 < P.M) o[1] = v.y;
+          if (m + 2 < P.M) o[2] = v.z;
+        }
       }
     }
   }

@@ -140,23 +140,33 @@ static int tn_splits(int M, int N, int K) {
 }
 size_t gemm_tn_slab_floats(int M, int N, int K) {
   const int s = tn_splits(M, N, K);
-  return s > 1 ? (size_t)s * M * N : 0;
+  // product partials (when split) + per-split column sums of A (the bias gradient)
+  return (s > 1 ? (size_t)s * M * N : 0) + (size_t)s * M;
 }
 hipError_t gemm_tn_acc(hipStream_t st, int M, int N, int K, const float* A, long lda,
-                       const float* B, long ldb, float* C, long ldc, float* slab) {
+                       const float* B, long ldb, float* C, long ldc, float* slab, float* dbias) {
   LinOpts o;
   o.accumulate = 1;
   const int s = tn_splits(M, N, K);
+  float* rs = dbias ? slab + (s > 1 ? (size_t)s * M * N : 0) : nullptr;
+  hipError_t e;
   if (s <= 1) {
     GemmParams P = lin_params(M, N, K, A, lda, B, ldb, C, ldc, o);
-    return launch_gemm<128, 128, BK, SRC_RC, SRC_RC, EPI_LIN>(st, P, 1);
+    P.rs_out = rs;
+    e = dbias ? launch_gemm<128, 128, BK, SRC_RC_SUM, SRC_RC, EPI_LIN>(st, P, 1)
+              : launch_gemm<128, 128, BK, SRC_RC, SRC_RC, EPI_LIN>(st, P, 1);
+  } else {
+    if (ldc != N) return hipErrorInvalidValue;
+    GemmParams P = lin_params(M, N, K, A, lda, B, ldb, slab, N, o);
+    P.slab_stride = (long)M * N;
+    P.rs_out = rs;
+    e = dbias ? launch_gemm<128, 128, BK, SRC_RC_SUM, SRC_RC, EPI_SLAB>(st, P, s)
+              : launch_gemm<128, 128, BK, SRC_RC, SRC_RC, EPI_SLAB>(st, P, s);
+    if (e != hipSuccess) return e;
+    e = splitk_reduce_acc(st, (size_t)M * N, s, slab, (size_t)M * N, C);
   }
-  if (ldc != N) return hipErrorInvalidValue;
-  GemmParams P = lin_params(M, N, K, A, lda, B, ldb, slab, N, o);
-  P.slab_stride = (long)M * N;
-  hipError_t e = launch_gemm<128, 128, BK, SRC_RC, SRC_RC, EPI_SLAB>(st, P, s);
-  if (e != hipSuccess) return e;
-  return splitk_reduce_acc(st, (size_t)M * N, s, slab, (size_t)M * N, C);
+  if (e != hipSuccess || !dbias) return e;
+  return splitk_reduce_acc(st, (size_t)M, s, rs, (size_t)M, dbias);
 }
 
 }  // namespace rau

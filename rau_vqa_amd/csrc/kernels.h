@@ -47,8 +47,10 @@ hipError_t gemm_nn_batched_deferred(hipStream_t st, int nb, int M, int N, int K,
 // C[M,N] += A[K,M]^T * B[K,N]          (Linear weight gradient; deterministic split-K
 // through `slab`, which must hold gemm_tn_slab_floats(M,N,K) floats)
 size_t gemm_tn_slab_floats(int M, int N, int K);
+// dbias (optional): dbias[m] += sum_k A[k, m], from the same pass over A (Linear bias gradient)
 hipError_t gemm_tn_acc(hipStream_t st, int M, int N, int K, const float* A, long lda,
-                       const float* B, long ldb, float* C, long ldc, float* slab);
+                       const float* B, long ldb, float* C, long ldc, float* slab,
+                       float* dbias = nullptr);
 
 // ----------------------------------------------------------- conv GEMMs (gemm_conv.hip)
 // I[b,m,s] = tanh(sum_d Wi[m,d] * X'[b,d,s] + bi[m])   (reference SS:238-242; X' is the

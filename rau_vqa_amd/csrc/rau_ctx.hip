@@ -1035,11 +1035,10 @@ int rau_backward(rau_ctx* ctx, const float* hop_w) {
         {&ctx->att_q, ctx->du, ctx->qf},         {&ctx->q_proj, ctx->dqt, ctx->qd},
         {&ctx->h_proj, ctx->dqt, hprev}};
     for (const WG& w : wgs) {
+      // dW += dY^T X, and db += column sums of dY from the same pass over dY
       RUNS(sw, "wgrad_gemm", gflop(w.l->out, w.l->in, rows), 0,
           gemm_tn_acc(sw, w.l->out, w.l->in, rows, w.dY, w.l->out, w.X, w.l->in, w.l->dW, w.l->in,
-                      ctx->slab3));
-      RUNS(sw, "colsum", 0, (double)rows * w.l->out * 4,
-          colsum_acc(sw, rows, w.l->out, w.dY, w.l->out, w.l->db, ctx->coltmp3));
+                      ctx->slab3, w.l->db));
     }
     // att_score: dws = sum dz T ; dbs = sum dz.  att_i bias: sum dS.  i_embed bias: sum dZ.
     RUNS(sw, "colsum", 0, (double)rows * A * 4, colsum_acc(sw, rows, A, ctx->dwsp, A, ctx->att_score.dW, ctx->coltmp3));
@@ -1121,11 +1120,10 @@ int rau_backward(rau_ctx* ctx, const float* hop_w) {
     const WG wgs[] = {{&ctx->i2h[0], ctx->dG1, ctx->we}, {&ctx->h2h[0], ctx->dG1, ctx->h1},
                       {&ctx->i2h[1], ctx->dG2, ctx->x2}, {&ctx->h2h[1], ctx->dG2, ctx->h2}};
     for (const WG& w : wgs) {
+      // dW += dY^T X, and db += column sums of dY from the same pass over dY
       RUNS(sw, "wgrad_gemm", gflop(w.l->out, w.l->in, rows), 0,
           gemm_tn_acc(sw, w.l->out, w.l->in, rows, w.dY, w.l->out, w.X, w.l->in, w.l->dW, w.l->in,
-                      ctx->slab3));
-      RUNS(sw, "colsum", 0, (double)rows * w.l->out * 4,
-          colsum_acc(sw, rows, w.l->out, w.dY, w.l->out, w.l->db, ctx->coltmp3));
+                      ctx->slab3, w.l->db));
     }
   }
   HIPC(hipEventRecord(ctx->evW3, ctx->st3));

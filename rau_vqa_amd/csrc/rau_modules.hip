@@ -63,10 +63,8 @@ Masks masks_of(rau_ctx* ctx) {
 int lin_wgrad(rau_ctx* ctx, Lin& l, const float* dY, const float* X, long ldx, bool bias = true) {
   const int B = ctx->cfg.B;
   RUN("wgrad_gemm", 2.0 * l.out * l.in * B, 0,
-      gemm_tn_acc(ctx->st, l.out, l.in, B, dY, l.out, X, ldx, l.dW, l.in, ctx->slab3));
-  if (bias)
-    RUN("colsum", 0, (double)B * l.out * 4,
-        colsum_acc(ctx->st, B, l.out, dY, l.out, l.db, ctx->coltmp3));
+      gemm_tn_acc(ctx->st, l.out, l.in, B, dY, l.out, X, ldx, l.dW, l.in, ctx->slab3,
+                  bias ? l.db : nullptr));
   return 0;
 }
 
