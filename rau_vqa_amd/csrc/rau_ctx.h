@@ -74,7 +74,7 @@ struct rau_ctx {
   hipStream_t st2 = nullptr;   // bulk stream: hop-batched 1x1-conv GEMMs, overlapped with the chain
   hipStream_t st3 = nullptr;   // weight-gradient stream: throughput GEMMs nobody waits for until the end
   hipEvent_t evA = nullptr, evD = nullptr, evW = nullptr, evE = nullptr, evW3 = nullptr,
-             evM3 = nullptr, evEnd = nullptr;
+             evM3 = nullptr, evEnd = nullptr, evE1 = nullptr;
   std::vector<hipEvent_t> evF, evK;  // per hop group: forward bulk done / backward chain done
   // hops per bulk launch (pipelines the bulk GEMMs with the hop loops): gsize[h] = n if hops
   // [h, h+n) form one launch group, else 0.  `groups` is the configured partition, `cur` the one

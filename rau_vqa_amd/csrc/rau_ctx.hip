@@ -146,7 +146,7 @@ int rau_create(const rau_config* cfg, rau_ctx** out) {
   hipEventCreate(&ctx->ev0);
   hipEventCreate(&ctx->ev1);
   const unsigned evflags = hipEventDisableTiming;
-  for (hipEvent_t* e : {&ctx->evA, &ctx->evD, &ctx->evW, &ctx->evE, &ctx->evW3, &ctx->evM3, &ctx->evEnd})
+  for (hipEvent_t* e : {&ctx->evA, &ctx->evD, &ctx->evW, &ctx->evE, &ctx->evW3, &ctx->evM3, &ctx->evEnd, &ctx->evE1})
     hipEventCreateWithFlags(e, evflags);
   {
     int plo = 0, phi = 0;
@@ -366,7 +366,7 @@ void rau_destroy(rau_ctx* ctx) {
   for (auto e : ctx->evpool) hipEventDestroy(e);
   if (ctx->ev0) hipEventDestroy(ctx->ev0);
   if (ctx->ev1) hipEventDestroy(ctx->ev1);
-  for (hipEvent_t e : {ctx->evA, ctx->evD, ctx->evW, ctx->evE, ctx->evW3, ctx->evM3, ctx->evEnd})
+  for (hipEvent_t e : {ctx->evA, ctx->evD, ctx->evW, ctx->evE, ctx->evW3, ctx->evM3, ctx->evEnd, ctx->evE1})
     if (e) hipEventDestroy(e);
   if (ctx->st3) hipStreamDestroy(ctx->st3);
   for (hipEvent_t e : ctx->evF) hipEventDestroy(e);
@@ -1058,6 +1058,30 @@ int rau_backward(rau_ctx* ctx, const float* hop_w) {
   if (TL > 0) {
     const int rows = TL * B;
     const size_t G4 = (size_t)B * 4 * Rq;
+    // Encoder weight gradients, also on the weight-gradient stream.  Optionally (RAU_ENC_CHUNK)
+    // in two time chunks -- the gradients of tokens t > uc are final once wavefront step uc is
+    // done -- but running the first chunk under the second half of the BPTT slows that chain by
+    // more than the shorter tail saves (measured 11.05 vs 10.6 ms), so the default is one chunk
+    // behind the BPTT.
+    auto enc_wgrads = [&](int t_lo, int t_hi, hipEvent_t ev) -> int {   // tokens t_lo < t <= t_hi
+      if (t_hi <= t_lo) return 0;
+      hipStream_t sw = ctx->st3;
+      HIPC(hipEventRecord(ev, st));
+      HIPC(hipStreamWaitEvent(sw, ev, 0));
+      const size_t r0 = (size_t)t_lo * B;
+      const int nr = (t_hi - t_lo) * B;
+      struct WG { Lin* l; const float* dY; const float* X; };
+      const WG wgs[] = {{&ctx->i2h[0], ctx->dG1, ctx->we}, {&ctx->h2h[0], ctx->dG1, ctx->h1},
+                        {&ctx->i2h[1], ctx->dG2, ctx->x2}, {&ctx->h2h[1], ctx->dG2, ctx->h2}};
+      for (const WG& w : wgs) {
+        // dW += dY^T X, and db += column sums of dY from the same pass over dY
+        RUNS(sw, "wgrad_gemm", gflop(w.l->out, w.l->in, nr), 0,
+            gemm_tn_acc(sw, w.l->out, w.l->in, nr, w.dY + r0 * w.l->out, w.l->out,
+                        w.X + r0 * w.l->in, w.l->in, w.l->dW, w.l->in, ctx->slab3, w.l->db));
+      }
+      return 0;
+    };
+    const int uc = std::getenv("RAU_ENC_CHUNK") ? TL / 2 : 0;   // chunking measured slower (11.05 vs 10.6 ms): it crowds the BPTT
     for (int u = TL; u >= 0; --u) {
       const float* Ap[3];
       const float* Wp[3];
@@ -1103,6 +1127,8 @@ int rau_backward(rau_ctx* ctx, const float* hop_w) {
         C1.t = t; C1.dq_c = ctx->dq; C1.dq_h = ctx->dq + Rq;
       }
       RUN("lstm_bwd", 0, BRq * 4.0 * 12 * cells.n, lstm_bwd_multi(st, GATES_DEEP, B, Rq, cells));
+      if (u == uc && uc > 0)
+        if (int rc = enc_wgrads(uc, TL, ctx->evE1)) return rc;
     }
     {  // gradient w.r.t. the word embeddings' tanh output, all tokens at once
       LINOPTS(o);
@@ -1112,19 +1138,7 @@ int rau_backward(rau_ctx* ctx, const float* hop_w) {
     RUN("embed_bwd", 0, (double)rows * E * 12,
         embed_bwd(st, ctx->nuniq, E, ctx->utok, ctx->ustart, ctx->upos, ctx->dwe, ctx->we, m_we,
                   sc(RAU_MASK_WE), ctx->grp[RAU_GROUP_EMBED].g));
-    // encoder weight gradients: also on the weight-gradient stream
-    hipStream_t sw = ctx->st3;
-    HIPC(hipEventRecord(ctx->evE, st));
-    HIPC(hipStreamWaitEvent(sw, ctx->evE, 0));
-    struct WG { Lin* l; const float* dY; const float* X; };
-    const WG wgs[] = {{&ctx->i2h[0], ctx->dG1, ctx->we}, {&ctx->h2h[0], ctx->dG1, ctx->h1},
-                      {&ctx->i2h[1], ctx->dG2, ctx->x2}, {&ctx->h2h[1], ctx->dG2, ctx->h2}};
-    for (const WG& w : wgs) {
-      // dW += dY^T X, and db += column sums of dY from the same pass over dY
-      RUNS(sw, "wgrad_gemm", gflop(w.l->out, w.l->in, rows), 0,
-          gemm_tn_acc(sw, w.l->out, w.l->in, rows, w.dY, w.l->out, w.X, w.l->in, w.l->dW, w.l->in,
-                      ctx->slab3, w.l->db));
-    }
+    if (int rc = enc_wgrads(0, uc > 0 ? uc : TL, ctx->evE)) return rc;
   }
   HIPC(hipEventRecord(ctx->evW3, ctx->st3));
   HIPC(hipStreamWaitEvent(st, ctx->evW3, 0));
