@@ -83,7 +83,8 @@ typedef struct rau_config {
   int32_t E;    /* embed_dim = 200, SS:202 */
   int32_t Rq;   /* rnn_size = 512, SS:209 (nrnn_layer fixed at 2, SS:210) */
   int32_t D;    /* cnnout_dim 512 | 2048, SS:216 */
-  int32_t S;    /* cnnout_w*cnnout_h = 196, SS:219 (must be a multiple of 4) */
+  int32_t S;    /* cnnout_w*cnnout_h = 196 (14x14) or 49 (7x7, the scripts' default), SS:219;
+                 * not a multiple of 4: padded internally, module-level calls unavailable */
   int32_t M;    /* multfeat_dim = 512, SS:220 */
   int32_t A;    /* attfeat_dim = 256, SS:221 */
   int32_t R;    /* att_rnn_size = 512, SS:225 (1 layer, dropout 0) */

@@ -134,7 +134,9 @@ hipError_t lstm_bwd_multi(hipStream_t st, int order, int nB, int R, const LstmBw
 // ap: u and/or zm may be handed over as K-split GEMM partials ([split][nB][A] / [split][nB][S],
 // passed in the u / zm arguments) plus the Linear's bias, summed in order by the kernel itself --
 // two reduce launches less on the recurrence's critical path.
-struct AttPartials { int u_ns = 0; const float* u_bias = nullptr; int z_ns = 0; const float* z_bias = nullptr; };
+// SL: logical number of positions when the tensors' pitch S is padded (7x7 maps); positions
+// [SL, S) get zero attention.
+struct AttPartials { int u_ns = 0; const float* u_bias = nullptr; int z_ns = 0; const float* z_bias = nullptr; int SL = 0; };
 hipError_t att_fwd_fused(hipStream_t st, int nB, int M, int A, int S, const float* P,
                          const float* u, const float* ws, const float* bs, const float* zm,
                          const float* I, const float* qf, float* T, float* a, float* jv,
@@ -145,8 +147,10 @@ hipError_t att_bwd_fused(hipStream_t st, int nB, int M, int A, int S, const floa
                          const float* dj, const float* a, const float* da_lin,
                          const float* ws, float* T_to_dS, float* dz, float* du, float* dwsp);
 // xd[h][i] = X[i] * keep(h, i) * scale for h < H, i < per_hop (feature-map dropout, SS:239)
+// SL != Sp: rows of SL logical positions at pitch Sp (mask indexed logically, pad columns zeroed)
 hipError_t dropout_features(hipStream_t st, int H, size_t per_hop, const float* X,
-                            const uint32_t* mask, float mscale, float* xd, size_t mask_e0 = 0);
+                            const uint32_t* mask, float mscale, float* xd, size_t mask_e0 = 0,
+                            int SL = 0, int Sp = 0);
 // rs[row] = sum_s X[row, s] * (1 - Y[row, s]^2)   (Y = nullptr: plain row sums)
 hipError_t row_sums(hipStream_t st, int rows, int S, const float* X, const float* Y, float* rs);
 // dst[n] += sum_rows X[row*ld + n]   (two-stage, deterministic; tmp >= 32*N floats)

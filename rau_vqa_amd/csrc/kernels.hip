@@ -407,10 +407,11 @@ __global__ __launch_bounds__(NW * 64) void k_att_fwd_fused(
       us[k] = v;
     }
   }
+  const int SL = ap.SL > 0 ? ap.SL : S;   // logical positions; [SL, S) are pad columns
   if (ap.z_ns) {
-    for (int s = tid; s < S; s += NW * 64) {
+    for (int s = tid; s < SL; s += NW * 64) {
       float v = ap.z_bias[s];
-      for (int sp = 0; sp < ap.z_ns; ++sp) v += zm[((size_t)sp * gridDim.x + b) * S + s];
+      for (int sp = 0; sp < ap.z_ns; ++sp) v += zm[((size_t)sp * gridDim.x + b) * SL + s];
       zs[s] = v;
     }
   }
@@ -437,8 +438,11 @@ __global__ __launch_bounds__(NW * 64) void k_att_fwd_fused(
   // ---- phase 2: a = softmax(e + bs + zm)
   float mx = -INFINITY;
   for (int s = tid; s < S; s += (NW * 64)) {
-    const float zmv = ap.z_ns ? zs[s] : zm[(size_t)b * S + s];
-    const float z = block_sum_ordered<NW>(red, S, s) + bs[0] + zmv;
+    float z = -INFINITY;   // pad positions take no attention (and so no gradient)
+    if (s < SL) {
+      const float zmv = ap.z_ns ? zs[s] : zm[(size_t)b * S + s];
+      z = block_sum_ordered<NW>(red, S, s) + bs[0] + zmv;
+    }
     as[s] = z;
     mx = fmaxf(mx, z);
   }
@@ -622,8 +626,33 @@ __global__ void k_dropout_features(int H, size_t per4, const float4* __restrict_
     }
   }
 }
+// Pitched rows (S not a multiple of 4): the mask is defined over the LOGICAL tensor
+// [.., rows, SL], the data has row pitch Sp; pad columns are written as zeros.
+__global__ void k_dropout_features_pitch(int H, size_t rows, int SL, int Sp,
+                                         const float* __restrict__ X,
+                                         const uint32_t* __restrict__ mask, size_t e0, float mscale,
+                                         float* __restrict__ xd) {
+  const size_t n = rows * Sp;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const size_t r = i / Sp;
+    const int s = (int)(i - r * Sp);
+    const float x = X[i];
+    for (int h = 0; h < H; ++h) {
+      float o = 0.f;
+      if (s < SL) o = mask_bit(mask, e0 + ((size_t)h * rows + r) * SL + s) ? x * mscale : 0.f;
+      xd[(size_t)h * n + i] = o;
+    }
+  }
+}
 hipError_t dropout_features(hipStream_t st, int H, size_t per_hop, const float* X,
-                            const uint32_t* mask, float mscale, float* xd, size_t mask_e0) {
+                            const uint32_t* mask, float mscale, float* xd, size_t mask_e0, int SL,
+                            int Sp) {
+  if (SL != Sp) {
+    hipLaunchKernelGGL(k_dropout_features_pitch, dim3(grid_for(per_hop)), dim3(256), 0, st, H,
+                       per_hop / Sp, SL, Sp, X, mask, mask_e0, mscale, xd);
+    return hipGetLastError();
+  }
   hipLaunchKernelGGL(k_dropout_features, dim3(grid_for(per_hop / 4)), dim3(256), 0, st, H,
                      per_hop / 4, reinterpret_cast<const float4*>(X), mask, mask_e0, mscale,
                      reinterpret_cast<float4*>(xd));

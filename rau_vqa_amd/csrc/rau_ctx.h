@@ -69,6 +69,8 @@ struct ProfCls {
 struct rau_ctx {
   rau_config cfg;
   int Q;
+  int Sp = 0;                 // position pitch: cfg.S rounded up to a multiple of 4 (7x7 maps: 49 -> 52);
+                              // every [.., S]-shaped device tensor uses it, pad columns hold zeros
   int bf16 = 0;               // cfg.dtype == RAU_BF16: bf16-operand conv GEMMs
   hipStream_t st = nullptr;    // chain stream: recurrences, small GEMMs; what callers order against
   hipStream_t st2 = nullptr;   // bulk stream: hop-batched 1x1-conv GEMMs, overlapped with the chain

@@ -80,7 +80,7 @@ int rau_create(const rau_config* cfg, rau_ctx** out) {
   const rau_config& c = *cfg;
   NEED(c.B > 0 && c.T > 0 && c.V > 1 && c.H > 0, "rau_create: B,T,H must be > 0 and V > 1");
   NEED(c.E > 0 && c.E % 4 == 0, "rau_create: E=%d must be a positive multiple of 4", c.E);
-  NEED(c.S > 0 && c.S % 4 == 0, "rau_create: S=%d must be a positive multiple of 4", c.S);
+  NEED(c.S > 0, "rau_create: S=%d must be positive", c.S);
   NEED(c.K > 0 && c.K % 4 == 0, "rau_create: K=%d must be a positive multiple of 4", c.K);
   NEED(c.Rq > 0 && c.Rq % 4 == 0 && c.R > 0 && c.R % 4 == 0 && c.M > 0 && c.M % 4 == 0 &&
            c.A > 0 && c.A % 4 == 0 && c.D > 0 && c.D % 4 == 0,
@@ -105,6 +105,7 @@ int rau_create(const rau_config* cfg, rau_ctx** out) {
   rau_ctx* ctx = new rau_ctx();
   ctx->cfg = c;
   ctx->Q = 4 * c.Rq;
+  ctx->Sp = (c.S + 3) & ~3;
   ctx->bf16 = c.dtype == RAU_BF16;
   for (int i = 0; i < 5; ++i) ctx->mp[i] = ps[i];
   *out = nullptr;
@@ -188,8 +189,11 @@ int rau_create(const rau_config* cfg, rau_ctx** out) {
     hipEventCreateWithFlags(&ctx->evK[i], evflags);
   }
 
-  const int B = c.B, T = c.T, E = c.E, Rq = c.Rq, D = c.D, S = c.S, M = c.M, A = c.A, R = c.R,
-            K = c.K, H = c.H, Q = ctx->Q;
+  // S below is the position PITCH of the device tensors; SL the logical number of positions
+  // (they differ only for maps like 7x7 = 49 -> 52: pad columns carry zero features, zero
+  // attention and zero gradients, see att_fwd_fused)
+  const int B = c.B, T = c.T, E = c.E, Rq = c.Rq, D = c.D, S = ctx->Sp, SL = c.S, M = c.M, A = c.A,
+            R = c.R, K = c.K, H = c.H, Q = ctx->Q;
   // ---- parameter layouts (weight [out,in] then bias [out])
   {
     Group& g = ctx->grp[RAU_GROUP_EMBED];
@@ -212,8 +216,8 @@ int rau_create(const rau_config* cfg, rau_ctx** out) {
     ctx->att_q = lb.take("attbycontent.qfeatatt", A, M);    // SS:246
     ctx->att_i = lb.take("attbycontent.ifeatproj", A, M);   // SS:247
     ctx->att_score = lb.take("attbycontent.attscore", 1, A);  // SS:251
-    ctx->att_mem = lb.take("attbymemory.linear", S, R);     // SS:287
-    ctx->feat_attprob = lb.take("classifier.feat_attprob", M, S);  // SS:271
+    ctx->att_mem = lb.take("attbymemory.linear", SL, R);     // SS:287
+    ctx->feat_attprob = lb.take("classifier.feat_attprob", M, SL);  // SS:271
     ctx->lstm_i2h = lb.take("classifier.attlstm.i2h", 4 * R, M);   // ATTLSTM.lua:6
     ctx->lstm_h2h = lb.take("classifier.attlstm.h2h", 4 * R, R);   // ATTLSTM.lua:7
     ctx->lstm_out = lb.take("classifier.lstm_out", M, R);          // SS:279
@@ -246,7 +250,7 @@ int rau_create(const rau_config* cfg, rau_ctx** out) {
   ctx->mcount[RAU_MASK_WE] = (size_t)T * B * E;
   ctx->mcount[RAU_MASK_RNN] = (size_t)T * B * Rq;
   ctx->mcount[RAU_MASK_Q] = (size_t)H * B * Q;
-  ctx->mcount[RAU_MASK_X] = (size_t)H * B * D * S;
+  ctx->mcount[RAU_MASK_X] = (size_t)H * B * D * SL;
   ctx->mcount[RAU_MASK_MF] = (size_t)H * B * M;
   for (int i = 0; i < 5; ++i) CK(dalloc(ctx, &ctx->mbits[i], (ctx->mcount[i] + 31) / 32 + 1));
   // ---- encoder
@@ -538,9 +542,10 @@ int rau_set_batch(rau_ctx* ctx, const float* feats, const int32_t* tokens, const
   }
   ustart.push_back((int32_t)pos.size());
   ctx->nuniq = (int)utok.size();
-  if (feats)
-    HIPC(hipMemcpyAsync(ctx->feats, feats, (size_t)c.B * c.D * c.S * sizeof(float),
-                        hipMemcpyHostToDevice, ctx->st));
+  if (feats)   // rows of S positions into rows of Sp (pad columns stay zero)
+    HIPC(hipMemcpy2DAsync(ctx->feats, (size_t)ctx->Sp * sizeof(float), feats,
+                          (size_t)c.S * sizeof(float), (size_t)c.S * sizeof(float),
+                          (size_t)c.B * c.D, hipMemcpyHostToDevice, ctx->st));
   HIPC(hipMemcpyAsync(ctx->tokens, tokens, (size_t)c.T * c.B * 4, hipMemcpyHostToDevice, ctx->st));
   HIPC(hipMemcpyAsync(ctx->lens_d, lens, (size_t)c.B * 4, hipMemcpyHostToDevice, ctx->st));
   if (labels)
@@ -574,7 +579,7 @@ int rau_batch_feats(rau_ctx* ctx, float** feats_dev) {
 int hop_forward(rau_ctx* ctx, int h, const float* cp, const float* hp, float* c_out, float* h_out,
                 const float* Ih, const float* Pin, const int32_t* labels) {
   const rau_config& c = ctx->cfg;
-  const int B = c.B, S = c.S, M = c.M, A = c.A, R = c.R, K = c.K;
+  const int B = c.B, S = ctx->Sp, SL = c.S, M = c.M, A = c.A, R = c.R, K = c.K;
   hipStream_t st = ctx->st;
   const bool tr = ctx->mode == RAU_MODE_TRAIN;
   const uint32_t* m_mf = (tr && ctx->mp[RAU_MASK_MF] > 0.f) ? ctx->mbits[RAU_MASK_MF] : nullptr;
@@ -610,7 +615,7 @@ int hop_forward(rau_ctx* ctx, int h, const float* cp, const float* hp, float* c_
   {  // attbymemory SS:285-290 (linear part; + bm inside att_fwd_fused)
     LinOpts o;
     o.slab = slab_z; o.slab_floats = reg; o.defer_splits = &ns_z;
-    RUN("small_gemm", gflop(B, S, R), 0, gemm_nt(st, B, S, R, hp, R, ctx->att_mem.W, R, ctx->zm, S, o));
+    RUN("small_gemm", gflop(B, SL, R), 0, gemm_nt(st, B, SL, R, hp, R, ctx->att_mem.W, R, ctx->zm, S, o));
   }
   {  // attention LSTM's recurrent half h_prev Wr^T (ATTLSTM.lua:7): partials first in slab_g
     LinOpts o;
@@ -623,6 +628,7 @@ int hop_forward(rau_ctx* ctx, int h, const float* cp, const float* hp, float* c_
     AttPartials ap;
     ap.u_ns = ns_u; ap.u_bias = ctx->att_q.b;
     ap.z_ns = ns_z; ap.z_bias = ctx->att_mem.b;
+    ap.SL = SL;
     RUN("att_fwd_fused", 2.0 * B * S * (A + M), ((double)B * A * S * 2 + BM_ * S) * 4,
         att_fwd_fused(st, B, M, A, S, Pin, slab_u, ctx->att_score.W, ctx->att_score.b, slab_z, Ih, qf,
                       Th, ah, ctx->jv, ap));
@@ -633,7 +639,7 @@ int hop_forward(rau_ctx* ctx, int h, const float* cp, const float* hp, float* c_
     o.bias = ctx->feat_attprob.b;
     o.addend = ctx->jv;
     o.add_rs = M;
-    RUN("small_gemm", gflop(B, M, S), 0, gemm_nt(st, B, M, S, ah, S, ctx->feat_attprob.W, S, jh, M, o));
+    RUN("small_gemm", gflop(B, M, SL), 0, gemm_nt(st, B, M, SL, ah, S, ctx->feat_attprob.W, SL, jh, M, o));
   }
   {  // j Wx^T partials right behind the recurrent ones; the cell kernel sums both + both biases
     LinOpts o;
@@ -681,7 +687,7 @@ int hop_forward(rau_ctx* ctx, int h, const float* cp, const float* hp, float* c_
 // 1x1-conv gradients are formed by the callers from those slots.
 int hop_backward(rau_ctx* ctx, int h, const float* cp, const float* Ih, const HopGrad& g) {
   const rau_config& c = ctx->cfg;
-  const int B = c.B, S = c.S, M = c.M, A = c.A, R = c.R, K = c.K;
+  const int B = c.B, S = ctx->Sp, SL = c.S, M = c.M, A = c.A, R = c.R, K = c.K;
   hipStream_t st = ctx->st;
   const bool tr = ctx->mode == RAU_MODE_TRAIN;
   const uint32_t* m_mf = (tr && ctx->mp[RAU_MASK_MF] > 0.f) ? ctx->mbits[RAU_MASK_MF] : nullptr;
@@ -733,8 +739,8 @@ int hop_backward(rau_ctx* ctx, int h, const float* cp, const float* Ih, const Ho
     LINOPTS(o);
     o.addend = g.da_out;
     o.add_rs = S;
-    RUN("small_gemm", gflop(B, S, M), 0,
-        gemm_nn(st, B, S, M, djh, M, ctx->feat_attprob.W, S, ctx->da_lin, S, o));
+    RUN("small_gemm", gflop(B, SL, M), 0,
+        gemm_nn(st, B, SL, M, djh, M, ctx->feat_attprob.W, SL, ctx->da_lin, S, o));
   }
   RUN("att_bwd_fused", 2.0 * B * S * (A + M), ((double)B * A * S * 2 + BM_ * S) * 4,
       att_bwd_fused(st, B, M, A, S, Ih, djh, ah, ctx->da_lin, ctx->att_score.W, Th, dzh, duh,
@@ -742,7 +748,7 @@ int hop_backward(rau_ctx* ctx, int h, const float* cp, const float* Ih, const Ho
   {  // dh_prev += dz Wm
     LINOPTS(o);
     o.accumulate = 1;
-    RUN("small_gemm", gflop(B, R, S), 0, gemm_nn(st, B, R, S, dzh, S, ctx->att_mem.W, R, dh_out, R, o));
+    RUN("small_gemm", gflop(B, R, SL), 0, gemm_nn(st, B, R, SL, dzh, S, ctx->att_mem.W, R, dh_out, R, o));
   }
   {  // dq~ = (dj + du Wa) (1 - qf^2)
     LINOPTS(o);
@@ -765,8 +771,8 @@ int rau_forward(rau_ctx* ctx) {
   NEED(ctx, "null ctx");
   if (!ctx->have_batch) return fail(RAU_ERR_STATE, "rau_forward: no batch (call rau_set_batch)");
   const rau_config& c = ctx->cfg;
-  const int B = c.B, E = c.E, Rq = c.Rq, D = c.D, S = c.S, M = c.M, A = c.A, R = c.R, H = c.H,
-            Q = ctx->Q;
+  const int B = c.B, E = c.E, Rq = c.Rq, D = c.D, S = ctx->Sp, SL = c.S, M = c.M, A = c.A, R = c.R,
+            H = c.H, Q = ctx->Q;
   const int TL = ctx->max_len;
   hipStream_t st = ctx->st;
   if (int rc = gen_masks(ctx)) return rc;
@@ -805,7 +811,8 @@ int rau_forward(rau_ctx* ctx) {
     RUNS(sb, "transpose", 0, (double)A * M * 8, transpose2d(sb, A, M, ctx->att_i.W, ctx->WpT));
     if (m_x)
       RUNS(sb, "dropout_features", 0, (double)(H + 1) * B * D * S * 4,
-           dropout_features(sb, H, (size_t)B * D * S, ctx->feats, m_x, sc(RAU_MASK_X), ctx->xd));
+           dropout_features(sb, H, (size_t)B * D * S, ctx->feats, m_x, sc(RAU_MASK_X), ctx->xd, 0, SL,
+                            S));
     for (int h0 = 0; h0 < H; h0 += gsz[h0]) {
       const int nBI = ctx->I_shared ? B : gsz[h0] * B;
       const size_t hb = ctx->I_shared ? 0 : (size_t)h0 * B;  // first (hop, sample) row
@@ -924,8 +931,8 @@ int rau_backward(rau_ctx* ctx, const float* hop_w) {
   if (!ctx->fwd_done) return fail(RAU_ERR_STATE, "rau_backward: call rau_forward first");
   if (!ctx->have_labels) return fail(RAU_ERR_STATE, "rau_backward: batch has no labels");
   const rau_config& c = ctx->cfg;
-  const int B = c.B, E = c.E, Rq = c.Rq, D = c.D, S = c.S, M = c.M, A = c.A, R = c.R, K = c.K,
-            H = c.H, Q = ctx->Q;
+  const int B = c.B, E = c.E, Rq = c.Rq, D = c.D, S = ctx->Sp, SL = c.S, M = c.M, A = c.A, R = c.R,
+            K = c.K, H = c.H, Q = ctx->Q;
   const int TL = ctx->max_len;
   const std::vector<int>& gsz = ctx->cur;
   hipStream_t st = ctx->st;
@@ -1027,24 +1034,25 @@ int rau_backward(rau_ctx* ctx, const float* hop_w) {
     const int rows = H * B;
     const float* hprev = ctx->hh;            // h_{0..H-1}
     const float* hnew = ctx->hh + BR_;       // h_{1..H}
-    struct WG { Lin* l; const float* dY; const float* X; };
+    struct WG { Lin* l; const float* dY; long ldy; const float* X; long ldx; };
     const WG wgs[] = {
-        {&ctx->cls, ctx->dl, ctx->mf},           {&ctx->lstm_out, ctx->dpre, hnew},
-        {&ctx->lstm_i2h, ctx->dg4, ctx->j},      {&ctx->lstm_h2h, ctx->dg4, hprev},
-        {&ctx->feat_attprob, ctx->dj, ctx->a},   {&ctx->att_mem, ctx->dz, hprev},
-        {&ctx->att_q, ctx->du, ctx->qf},         {&ctx->q_proj, ctx->dqt, ctx->qd},
-        {&ctx->h_proj, ctx->dqt, hprev}};
+        {&ctx->cls, ctx->dl, K, ctx->mf, M},             {&ctx->lstm_out, ctx->dpre, M, hnew, R},
+        {&ctx->lstm_i2h, ctx->dg4, 4 * R, ctx->j, M},    {&ctx->lstm_h2h, ctx->dg4, 4 * R, hprev, R},
+        {&ctx->feat_attprob, ctx->dj, M, ctx->a, S},     {&ctx->att_mem, ctx->dz, S, hprev, R},
+        {&ctx->att_q, ctx->du, A, ctx->qf, M},           {&ctx->q_proj, ctx->dqt, M, ctx->qd, Q},
+        {&ctx->h_proj, ctx->dqt, M, hprev, R}};
     for (const WG& w : wgs) {
-      // dW += dY^T X, and db += column sums of dY from the same pass over dY
+      // dW += dY^T X, and db += column sums of dY from the same pass over dY (dz and a are
+      // pitched: their leading dimension is the position pitch, the Linear's size the logical S)
       RUNS(sw, "wgrad_gemm", gflop(w.l->out, w.l->in, rows), 0,
-          gemm_tn_acc(sw, w.l->out, w.l->in, rows, w.dY, w.l->out, w.X, w.l->in, w.l->dW, w.l->in,
+          gemm_tn_acc(sw, w.l->out, w.l->in, rows, w.dY, w.ldy, w.X, w.ldx, w.l->dW, w.l->in,
                       ctx->slab3, w.l->db));
     }
     // att_score: dws = sum dz T ; dbs = sum dz.  att_i bias: sum dS.  i_embed bias: sum dZ.
     RUNS(sw, "colsum", 0, (double)rows * A * 4, colsum_acc(sw, rows, A, ctx->dwsp, A, ctx->att_score.dW, ctx->coltmp3));
     HIPC(hipMemsetAsync(ctx->tmpS, 0, S * sizeof(float), sw));
-    RUNS(sw, "colsum", 0, (double)rows * S * 4, colsum_acc(sw, rows, S, ctx->dz, S, ctx->tmpS, ctx->coltmp3));
-    RUNS(sw, "colsum", 0, S * 4.0, colsum_acc(sw, S, 1, ctx->tmpS, 1, ctx->att_score.db, ctx->coltmp3));
+    RUNS(sw, "colsum", 0, (double)rows * S * 4, colsum_acc(sw, rows, SL, ctx->dz, S, ctx->tmpS, ctx->coltmp3));
+    RUNS(sw, "colsum", 0, S * 4.0, colsum_acc(sw, SL, 1, ctx->tmpS, 1, ctx->att_score.db, ctx->coltmp3));
     RUNS(sw, "colsum", 0, (double)rows * A * 4, colsum_acc(sw, rows, A, ctx->du, A, ctx->att_i.db, ctx->coltmp3));
     HIPC(hipEventRecord(ctx->evM3, sw));   // with evD: the mult group's gradients are final
     return 0;
@@ -1193,7 +1201,12 @@ int rau_get_dopred(rau_ctx* ctx, float* dopred) {
 }
 int rau_get_attention(rau_ctx* ctx, float* att) {
   NEED(ctx, "null ctx");
-  return d2h(ctx, att, ctx->a, (size_t)ctx->cfg.H * ctx->cfg.B * ctx->cfg.S * 4);
+  NEED(att, "null argument");
+  HIPC(hipMemcpy2DAsync(att, (size_t)ctx->cfg.S * 4, ctx->a, (size_t)ctx->Sp * 4,
+                        (size_t)ctx->cfg.S * 4, (size_t)ctx->cfg.H * ctx->cfg.B,
+                        hipMemcpyDeviceToHost, ctx->st));
+  HIPC(hipStreamSynchronize(ctx->st));
+  return RAU_OK;
 }
 int rau_get_question_state(rau_ctx* ctx, float* q) {
   NEED(ctx, "null ctx");

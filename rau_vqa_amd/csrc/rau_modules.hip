@@ -19,6 +19,8 @@ bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) ==
 
 int mod_alloc(rau_ctx* ctx) {
   if (ctx->mod_ready) return 0;
+  // callers hand in / get back DENSE [.., S] tensors; the step-level path pads S internally
+  NEED(ctx->Sp == ctx->cfg.S, "module-level entry points need S %% 4 == 0 (S = %d)", ctx->cfg.S);
   const rau_config& c = ctx->cfg;
   const size_t B = c.B, Q = ctx->Q;
   const size_t wide = std::max<size_t>({(size_t)c.Rq, (size_t)c.R, (size_t)c.M});

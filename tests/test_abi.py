@@ -49,7 +49,7 @@ def test_create_rejects_bad_config_or_missing_device():
     l = _lib.lib()
     cfg = _lib.RauConfig()
     l.rau_default_config(C.byref(cfg))
-    cfg.S = 195  # not a multiple of 4
+    cfg.E = 198  # not a multiple of 4
     h = C.c_void_p()
     assert l.rau_create(C.byref(cfg), C.byref(h)) == -1
     assert b"multiple of 4" in l.rau_last_error()

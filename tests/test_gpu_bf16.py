@@ -77,6 +77,11 @@ def test_bf16_resnet_channels_d2048():
     run(dims, 0.05)
 
 
+def test_bf16_7x7_feature_map_s49():
+    dims = dict(B=6, T=5, V=40, E=8, Rq=16, D=24, S=49, M=40, A=20, R=16, K=12, H=3)
+    run(dims, 0.5)
+
+
 def test_f32_results_do_not_depend_on_the_bf16_code_path():
     """dtype f32 stays the exact path: bitwise equal outputs from two f32 contexts, and different
     from the bf16 context's (guards against the flag leaking into the default mode)."""

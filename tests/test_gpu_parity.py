@@ -99,6 +99,19 @@ def test_batch_100_default_sizes_of_heads():
     check(util.shapes(dims), scale=0.1)
 
 
+def test_7x7_feature_map_s49():
+    """cnnout_w = cnnout_h = 7 is the scripts' own default (SS:36-37, 224x224 pool5 features):
+    S = 49 is not a multiple of 4, the library pads the position pitch to 52 internally."""
+    dims = dict(B=6, T=5, V=40, E=8, Rq=16, D=24, S=49, M=40, A=20, R=16, K=12, H=3)
+    check(util.shapes(dims), scale=0.5)
+    check(util.shapes(dims), mode="eval", scale=0.5)
+
+
+def test_7x7_full_width_heads():
+    dims = dict(B=20, T=5, V=60, E=200, Rq=32, D=512, S=49, M=128, A=64, R=32, K=1000, H=2)
+    check(util.shapes(dims), scale=0.1)
+
+
 def test_snapshot_round_trip_through_t7(tmp_path):
     """torch.save(checkpoint) / embed_param:copy(snap.params[1]) (SS:1188-1197, Eval.lua:344-347)."""
     from rau_vqa_amd.model import RAU, Config
