@@ -121,8 +121,10 @@ def main():
     hop_w = hop_weights("SS", cfg.H)
     reducer = None
     if world > 1:
-        from rau_vqa_amd.dist import GradAllReduce
-        reducer = GradAllReduce(m)
+        from rau_vqa_amd.dist import GradAllReduce, NativeGradAllReduce
+        # RAU_DP=native: the C ABI's own RCCL binding (rau_allreduce_grads) instead of
+        # torch.distributed collectives on views of the same buffers
+        reducer = (NativeGradAllReduce if os.environ.get("RAU_DP") == "native" else GradAllReduce)(m)
 
     def step(i):
         m.set_dropout_seed(123, i)

@@ -76,6 +76,10 @@ int rau_noise_clip_adam(rau_ctx* ctx, int64_t step_t, float lr, float mult_lr,
                         float clip, uint64_t noise_seed, float* out_norms);
 int rau_stream(rau_ctx* ctx, void** hip_stream);
 int rau_wait_grads(rau_ctx* ctx, int group, void* hip_stream);
+int rau_comm_unique_id(void* id, size_t bytes);
+int rau_comm_init(rau_ctx* ctx, int nranks, int rank, const void* id, size_t bytes);
+int rau_allreduce_grads(rau_ctx* ctx);
+int rau_comm_destroy(rau_ctx* ctx);
 int rau_timer_begin(rau_ctx* ctx);
 int rau_timer_end(rau_ctx* ctx, float* ms);
 ]]
@@ -155,6 +159,17 @@ function RAU:answers(out) check(C.rau_get_argmax(self.h, out:data())); return ou
 function RAU:logits(out) check(C.rau_get_logits(self.h, out:data())); return out end
 function RAU:attention(out) check(C.rau_get_attention(self.h, out:data())); return out end
 function RAU:sync() check(C.rau_sync(self.h)) end
+
+-- data parallel (one process per GPU): rank 0 calls RAU.commId() and ships the 128-byte string
+-- to the other ranks (file, socket, ...); every rank then calls rau:commInit(n, rank, id) once
+-- and rau:allreduceGrads() between rau:backward(w) and rau:update(...)
+function RAU.commId()
+  local id = ffi.new('char[128]')
+  check(C.rau_comm_unique_id(id, 128))
+  return ffi.string(id, 128)
+end
+function RAU:commInit(nranks, rank, id) check(C.rau_comm_init(self.h, nranks, rank, id, #id)) end
+function RAU:allreduceGrads() check(C.rau_allreduce_grads(self.h)) end
 
 -- Module-level clones ---------------------------------------------------------
 -- For scripts that keep feval's own loops (SS:443-596).  Arguments and results are

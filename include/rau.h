@@ -234,6 +234,19 @@ int rau_noise_clip_adam(rau_ctx* ctx, int64_t step_t, float lr, float mult_lr,
                         float gamma, float clip, uint64_t noise_seed,
                         float* out_norms);
 
+/* ---- data-parallel exchange (new: the reference is single-GPU) --------------------
+ * One process and one rau_ctx per GPU.  Rank 0 obtains a communicator id and hands it to
+ * the other ranks by any host channel (file, socket, MPI, torch.distributed); every rank
+ * then calls rau_comm_init.  rau_allreduce_grads averages the three flat gradient buffers
+ * in place over RCCL/xGMI after rau_backward -- the mult bucket underneath the encoder
+ * BPTT, everything ordered by stream events -- after which every rank applies the
+ * identical rau_noise_clip_adam (same noise_seed).  RCCL is bound at first use. */
+#define RAU_COMM_ID_BYTES 128
+int rau_comm_unique_id(void* id, size_t bytes /* >= RAU_COMM_ID_BYTES */);
+int rau_comm_init(rau_ctx* ctx, int nranks, int rank, const void* id, size_t bytes);
+int rau_allreduce_grads(rau_ctx* ctx);
+int rau_comm_destroy(rau_ctx* ctx);
+
 /* ---- timing / interop ---------------------------------------------------------
  * The ctx's hipStream_t (as void*) so a host can order its own work (e.g. an
  * RCCL all-reduce of the flat grad buffers issued through torch.distributed)

@@ -97,6 +97,10 @@ _SIGS = {
                             [C.c_uint64, C.c_void_p]),
     "rau_stream": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
     "rau_wait_grads": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    "rau_comm_unique_id": (C.c_int, [C.c_void_p, C.c_size_t]),
+    "rau_comm_init": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t]),
+    "rau_allreduce_grads": (C.c_int, [C.c_void_p]),
+    "rau_comm_destroy": (C.c_int, [C.c_void_p]),
     "rau_timer_begin": (C.c_int, [C.c_void_p]),
     "rau_timer_end": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
     "rau_prof_enable": (C.c_int, [C.c_void_p, C.c_int]),

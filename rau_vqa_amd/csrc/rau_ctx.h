@@ -133,6 +133,11 @@ struct rau_ctx {
   uint64_t mod_masks_seed = 0;                     // (seed, step) the device masks were drawn for
   uint32_t mod_masks_step = 0;
   bool mod_masks_valid = false;
+  // native data-parallel exchange (rau_comm_*; RCCL loaded with dlopen on first use)
+  void* comm = nullptr;          // ncclComm_t
+  hipStream_t st_comm = nullptr;
+  hipEvent_t evC = nullptr;
+  int comm_ranks = 0;
   // update
   float *npart = nullptr, *norms_d = nullptr;
   bool fwd_done = false, bwd_done = false;

@@ -359,6 +359,9 @@ int rau_create(const rau_config* cfg, rau_ctx** out) {
 
 void rau_destroy(rau_ctx* ctx) {
   if (!ctx) return;
+  rau_comm_destroy(ctx);
+  if (ctx->st_comm) hipStreamDestroy(ctx->st_comm);
+  if (ctx->evC) hipEventDestroy(ctx->evC);
   if (ctx->st) hipStreamSynchronize(ctx->st);
   if (ctx->st2) hipStreamSynchronize(ctx->st2);
   if (ctx->st3) hipStreamSynchronize(ctx->st3);

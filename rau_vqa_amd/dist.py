@@ -100,3 +100,19 @@ class GradAllReduce:
                 for t in self.grads.values():
                     t.mul_(1.0 / world)
         self.stream.wait_stream(self.comm)
+
+
+class NativeGradAllReduce:
+    """Same exchange through librau's own RCCL binding (rau_comm_init / rau_allreduce_grads):
+    what a host without torch.distributed (the LuaJIT shim) uses.  Here the communicator id
+    travels over the already initialised torch.distributed group; any host channel works."""
+
+    def __init__(self, rau, group=None):
+        self.rau = rau
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        box = [rau.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0, group=group)
+        rau.comm_init(world, rank, box[0])
+
+    def __call__(self):
+        self.rau.allreduce_grads()

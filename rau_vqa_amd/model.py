@@ -261,6 +261,24 @@ class RAU:
         L.check(self._lib.rau_stream(self._h, C.byref(s)))
         return s.value or 0
 
+    # ---- native data-parallel exchange (RCCL inside librau, no torch.distributed needed)
+    @staticmethod
+    def comm_unique_id() -> bytes:
+        buf = C.create_string_buffer(128)
+        L.check(L.lib().rau_comm_unique_id(buf, 128))
+        return buf.raw
+
+    def comm_init(self, nranks: int, rank: int, uid: bytes):
+        L.check(self._lib.rau_comm_init(self._h, nranks, rank, uid, len(uid)))
+
+    def allreduce_grads(self):
+        """Average the three flat gradient buffers over all ranks, in place, ordered on the
+        ctx stream (mult bucket overlapped with the encoder BPTT)."""
+        L.check(self._lib.rau_allreduce_grads(self._h))
+
+    def comm_destroy(self):
+        L.check(self._lib.rau_comm_destroy(self._h))
+
     def wait_grads(self, group: str, hip_stream: int):
         """Order `hip_stream` after the last backward's gradients of `group` (no host sync)."""
         L.check(self._lib.rau_wait_grads(self._h, L.GROUPS[group], C.c_void_p(hip_stream)))

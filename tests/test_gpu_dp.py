@@ -98,3 +98,35 @@ def test_device_view_aliases_librau_buffers():
     torch.cuda.synchronize()
     assert np.all(m.get_grads()["rnn"] == 0.25)
     m.close()
+
+
+def test_native_rccl_binding_single_rank():
+    """rau_comm_* / rau_allreduce_grads (RCCL bound inside librau): with one rank the average is
+    the identity, which exercises id creation, communicator init, the three collectives on the
+    side stream, the event ordering against rau_backward and the update that follows.  More
+    ranks need more GPUs (RCCL refuses two ranks on one device): the driver's scaling run."""
+    from rau_vqa_amd.model import RAU, Config
+    from tests import util
+    sh = util.shapes(DIMS)
+    batch, params, _ = util.make_problem(sh, scale=0.5)
+    m = RAU(Config(**DIMS))
+    m.set_params(params)
+    m.evaluate()
+    m.set_batch(**batch)
+    hop_w = np.full(sh.H, float(sh.H), np.float32)
+    m.zero_grads(); m.forward(); m.backward(hop_w)
+    ref = m.get_grads()
+    uid = RAU.comm_unique_id()
+    assert len(uid) == 128
+    m.comm_init(1, 0, uid)
+    m.zero_grads(); m.forward(); m.backward(hop_w)
+    m.allreduce_grads()
+    got = m.get_grads()                          # ordered on the ctx stream behind the collectives
+    norms = m.update(step_t=0, eta=0.0)          # the update that follows in a training step
+    assert np.all(np.isfinite(norms))
+    m.comm_destroy()
+    with pytest.raises(Exception, match="rau_comm_init"):
+        m.allreduce_grads()
+    m.close()
+    for k in ref:
+        np.testing.assert_array_equal(got[k], ref[k])
