@@ -49,8 +49,8 @@ hipError_t conv_att_pre(hipStream_t st, int nB, int M, int S, int A, const float
 
 // backward of attbycontent + attselect into the gradient w.r.t. i_embed's OUTPUT:
 // dI[b,m,s] = sum_k Wp[k,m] dS[b,k,s] + dj[b,m] a[b,s].  The tanh derivative
-// (1 - I^2) is applied where dI is consumed (conv_embed_wgrad's operand loader,
-// row_sums_dtanh), not here: reading I in this short-K GEMM's epilogue cost more
+// (1 - I^2) is applied where dI is consumed (conv_embed_wgrad's operand loader, which
+// also yields the bias gradient), not here: reading I in this short-K GEMM's epilogue cost more
 // than the GEMM itself.
 hipError_t conv_att_dgrad(hipStream_t st, int nB, int M, int S, int A, const float* dS,
                           const float* Wp, const float* dj, const float* a, float* dI, int bf16) {

@@ -151,8 +151,6 @@ hipError_t att_bwd_fused(hipStream_t st, int nB, int M, int A, int S, const floa
 hipError_t dropout_features(hipStream_t st, int H, size_t per_hop, const float* X,
                             const uint32_t* mask, float mscale, float* xd, size_t mask_e0 = 0,
                             int SL = 0, int Sp = 0);
-// rs[row] = sum_s X[row, s] * (1 - Y[row, s]^2)   (Y = nullptr: plain row sums)
-hipError_t row_sums(hipStream_t st, int rows, int S, const float* X, const float* Y, float* rs);
 // dst[n] += sum_rows X[row*ld + n]   (two-stage, deterministic; tmp >= 32*N floats)
 hipError_t colsum_acc(hipStream_t st, int rows, int N, const float* X, long ld, float* dst,
                       float* tmp);

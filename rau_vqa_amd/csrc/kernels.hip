@@ -659,35 +659,6 @@ hipError_t dropout_features(hipStream_t st, int H, size_t per_hop, const float* 
   return hipGetLastError();
 }
 
-__global__ void k_row_sums(int rows, int S, const float* __restrict__ X,
-                           const float* __restrict__ Y, float* __restrict__ rs) {
-  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  if (row >= rows) return;
-  const int l = threadIdx.x & 63;
-  const int S4 = S >> 2;
-  const float4* xr = reinterpret_cast<const float4*>(X + (size_t)row * S);
-  float acc = 0.f;
-  if (Y) {
-    const float4* yr = reinterpret_cast<const float4*>(Y + (size_t)row * S);
-    for (int q = l; q < S4; q += 64) {
-      const float4 x = xr[q], y = yr[q];
-      acc += (x.x * (1.f - y.x * y.x) + x.y * (1.f - y.y * y.y)) +
-             (x.z * (1.f - y.z * y.z) + x.w * (1.f - y.w * y.w));
-    }
-  } else {
-    for (int q = l; q < S4; q += 64) {
-      const float4 x = xr[q];
-      acc += (x.x + x.y) + (x.z + x.w);
-    }
-  }
-  acc = wave_sum(acc);
-  if (l == 0) rs[row] = acc;
-}
-hipError_t row_sums(hipStream_t st, int rows, int S, const float* X, const float* Y, float* rs) {
-  hipLaunchKernelGGL(k_row_sums, dim3((rows + 3) / 4), dim3(256), 0, st, rows, S, X, Y, rs);
-  return hipGetLastError();
-}
-
 // ----------------------------------------------- deterministic column sums
 // dst[n] += sum_r X[r, n]: stage 1 sums kColChunks row chunks (fixed order inside a chunk),
 // stage 2 adds the chunk partials in order.  The vector path (N, ld multiples of 4) gives a

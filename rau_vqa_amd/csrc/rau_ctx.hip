@@ -308,7 +308,6 @@ int rau_create(const rau_config* cfg, rau_ctx** out) {
   CK(dalloc(ctx, &ctx->du, HB * A));
   CK(dalloc(ctx, &ctx->dwsp, HB * A));
   CK(dalloc(ctx, &ctx->dZ, HB * M * S));
-  CK(dalloc(ctx, &ctx->rsum, HB * M));
   CK(dalloc(ctx, &ctx->dqt, HB * M));
   CK(dalloc(ctx, &ctx->dQD, HB * Q));
   CK(dalloc(ctx, &ctx->dq, (size_t)B * Q));
@@ -331,8 +330,6 @@ int rau_create(const rau_config* cfg, rau_ctx** out) {
   }
   {
     const int widest = std::max({4 * R, 4 * Rq, K, M, S, A, Q});
-    CK(dalloc(ctx, &ctx->coltmp, (size_t)32 * widest));
-    CK(dalloc(ctx, &ctx->coltmp2, (size_t)32 * widest));
     CK(dalloc(ctx, &ctx->coltmp3, (size_t)32 * widest));
     CK(dalloc(ctx, &ctx->tmpS, (size_t)S));
   }
