@@ -104,10 +104,18 @@ def main():
     from rau_vqa_amd import synth
     from rau_vqa_amd.model import RAU, Config, hop_weights
 
+    # RAU_DIST_BACKEND=gloo: rehearse the N>1 code path with several ranks on ONE GPU (RCCL
+    # refuses two ranks per device); the default is RCCL, one rank per GPU
+    backend = os.environ.get("RAU_DIST_BACKEND", "nccl")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            local_rank = local_rank % max(torch.cuda.device_count(), 1)
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend)
 
     cfgd = dict(B=args.batch, T=26, V=14000, E=200, Rq=512, D=args.D, S=196, M=512, A=256,
                 R=512, K=1000, H=8)
@@ -232,7 +240,10 @@ def main():
             m.update(step_t=i)
         fence()
         m.evaluate()
-        for i in range(12):
+        for i in range(2):
+            m.forward()
+        fence()
+        for i in range(10):
             m.forward()
         fence()
         m.training()

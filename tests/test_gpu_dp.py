@@ -130,3 +130,24 @@ def test_native_rccl_binding_single_rank():
     m.close()
     for k in ref:
         np.testing.assert_array_equal(got[k], ref[k])
+
+
+def test_bench_flow_with_two_ranks_over_gloo():
+    """bench.py's N > 1 path end to end (rendezvous, per-step gradient exchange, barriers of
+    the timed region and of rank 0's extra measurements, max-over-ranks timing, one JSON line
+    from rank 0) with two ranks sharing the one GPU over gloo: RCCL itself needs one GPU per
+    rank, everything around it is the same code."""
+    import json
+    import subprocess
+    env = dict(os.environ, RAU_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--batch", "32"]
+    out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 64 and d["value"] > 0
+    assert d["scaling"] == "weak" and "roofline" in d
