@@ -44,6 +44,9 @@ struct GemmParams {
   int tiles_m, tiles_n;
   // batched launch (blockIdx.y): same shapes, different operand / slab bases
   int nbatch; const float* Ab[3]; const float* Bb[3]; long slab_batch_stride;
+  // heterogeneous batch (Nb[0] != 0): problem y has Nb[y] output columns and its split-K
+  // partials at C + slab_off[y] ([split][M][Nb[y]]); N is the widest (sizes the grid)
+  int Nb[3]; long slab_off[3];
   // A operand
   const float* A; long a_rs; long a_bs;
   const float* A2;      // SC_DTANH loader: second source, A * (1 - A2^2) (same indexing as A)
@@ -352,12 +355,22 @@ __global__ __launch_bounds__(256, DT ? 3 : 2) void gemm_kernel(const GemmParams 
   int nsteps = P.nk - step0;
   if (nsteps > P.nk_per_split) nsteps = P.nk_per_split;
 
+  int PN = P.N;                 // this problem's output width / row pitch / slab placement
+  long Pcrs = P.c_rs, Pslab_stride = P.slab_stride;
+  long Cbatch = P.nbatch ? (long)blockIdx.y * P.slab_batch_stride : 0;
+  if (P.nbatch && P.Nb[0]) {
+    PN = P.Nb[blockIdx.y];
+    Pcrs = PN;
+    Pslab_stride = (long)P.M * PN;
+    Cbatch = P.slab_off[blockIdx.y];
+    if (n0 >= PN) return;       // tile column beyond this (narrower) problem: whole workgroup
+  }
   typename LoaderOf<BM, BKT, ASRC, DT != 0>::type LA;
   typename LoaderOf<BN, BKT, BSRC, DT != 0>::type LB;
   const float* Abase = P.nbatch ? P.Ab[blockIdx.y] : P.A;
   const float* Bbase = P.nbatch ? P.Bb[blockIdx.y] : P.B;
   LA.init(P, Abase, P.a_rs, P.a_bs, m0, P.M, tid);
-  LB.init(P, Bbase, P.b_rs, P.b_bs, n0, P.N, tid);
+  LB.init(P, Bbase, P.b_rs, P.b_bs, n0, PN, tid);
 
   f32x16 acc[IM][JN];
 #pragma unroll
@@ -435,7 +448,7 @@ __global__ __launch_bounds__(256, DT ? 3 : 2) void gemm_kernel(const GemmParams 
   // the bulk shapes) take unpredicated loads: the per-load exec-mask branches and
   // address recomputation of the general path cost ~15% of the K-loop's issue slots.
   const bool kfull = (ASRC == SRC_SC) || (ASRC == SRC_SC_DTANH) ? (P.S % BKT == 0) : (P.K % BKT == 0);
-  const bool interior = kfull && m0 + BM <= P.M && n0 + BN <= P.N;
+  const bool interior = kfull && m0 + BM <= P.M && n0 + BN <= PN;
   auto mainloop = [&](auto fast_tag) {
     constexpr bool FAST = decltype(fast_tag)::value;
     if (nsteps > 0) {
@@ -528,13 +541,11 @@ __global__ __launch_bounds__(256, DT ? 3 : 2) void gemm_kernel(const GemmParams 
   const int cloc = wn * WN + (l & 31);       // column of j=0 inside the tile
 
   if (EPI == EPI_LIN || EPI == EPI_SLAB) {
-    float* C = P.C + (EPI == EPI_SLAB ? (long)blockIdx.z * P.slab_stride +
-                                        (P.nbatch ? (long)blockIdx.y * P.slab_batch_stride : 0)
-                                      : 0);
+    float* C = P.C + (EPI == EPI_SLAB ? (long)blockIdx.z * Pslab_stride + Cbatch : 0);
 #pragma unroll
     for (int j = 0; j < JN; ++j) {
       const int n = n0 + cloc + j * 32;
-      if (n >= P.N) continue;
+      if (n >= PN) continue;
       float bsum = 0.f;
       if (EPI == EPI_LIN) {
         if (P.bias) bsum += P.bias[n];
@@ -547,7 +558,7 @@ __global__ __launch_bounds__(256, DT ? 3 : 2) void gemm_kernel(const GemmParams 
           const int m = m0 + rloc + i * 32 + (r & 3) + 8 * (r >> 2);
           if (m >= P.M) continue;
           float v = acc[i][j][r];
-          const long ci = (long)m * P.c_rs + n;
+          const long ci = (long)m * Pcrs + n;
           if (EPI == EPI_LIN) {
             v = v * P.alpha + bsum;
             if (P.addend) v += P.addend[(long)m * P.add_rs + n];

@@ -124,6 +124,46 @@ hipError_t gemm_nn_batched_deferred(hipStream_t st, int nb, int M, int N, int K,
   return batched_deferred<SRC_KC, SRC_RC>(st, nb, M, N, K, A, lda, W, ldw, slab, slab_floats, splits);
 }
 
+// nb (<= 3) skinny problems that share A and K but have different widths / weights, in ONE
+// launch; partials stay in the slab, problem i at slab + off[i] laid out [split][M][N[i]].
+hipError_t gemm_nt_hetero_deferred(hipStream_t st, int nb, int M, int K, const float* A, long lda,
+                                   const float* const* W, long ldw, const int* N, float* slab,
+                                   size_t slab_floats, int* splits, size_t* off) {
+  if (nb < 1 || nb > 3) return hipErrorInvalidValue;
+  int nmax = 0, tiles = 0;
+  size_t nsum = 0;
+  for (int i = 0; i < nb; ++i) {
+    nmax = N[i] > nmax ? N[i] : nmax;
+    tiles += ((M + 63) / 64) * ((N[i] + 63) / 64);
+    nsum += (size_t)N[i];
+  }
+  const int nk = (K + BKS - 1) / BKS;
+  int s = (160 * nb + tiles - 1) / tiles;     // the merged launch stands for nb launches
+  if (s > nk / 2) s = nk / 2;
+  if (s < 1) s = 1;
+  while (s > 1 && (size_t)s * M * nsum > slab_floats) --s;
+  if ((size_t)s * M * nsum > slab_floats) return hipErrorInvalidValue;
+  {
+    const int per = (nk + s - 1) / s;
+    s = (nk + per - 1) / per;
+  }
+  LinOpts o;
+  GemmParams P = lin_params(M, nmax, K, A, lda, W[0], ldw, slab, nmax, o);
+  P.nk = nk;
+  P.nbatch = nb;
+  size_t acc = 0;
+  for (int i = 0; i < nb; ++i) {
+    P.Ab[i] = A;
+    P.Bb[i] = W[i];
+    P.Nb[i] = N[i];
+    P.slab_off[i] = (long)acc;
+    off[i] = acc;
+    acc += (size_t)s * M * N[i];
+  }
+  *splits = s;
+  return launch_gemm<64, 64, BKS, SRC_KC, SRC_KC, EPI_SLAB>(st, P, s);
+}
+
 static int tn_splits(int M, int N, int K) {
   const int tiles = ((M + 127) / 128) * ((N + 127) / 128);
   const int nk = (K + BK - 1) / BK;

@@ -44,6 +44,11 @@ hipError_t gemm_nt_batched_deferred(hipStream_t st, int nb, int M, int N, int K,
 hipError_t gemm_nn_batched_deferred(hipStream_t st, int nb, int M, int N, int K,
                                     const float* const* A, long lda, const float* const* W,
                                     long ldw, float* slab, size_t slab_floats, int* splits);
+// nb (<= 3) Linear forwards x W_i^T that share x (and K) but differ in width, one launch;
+// problem i's partials at slab + off[i] as [*splits][M][N[i]]
+hipError_t gemm_nt_hetero_deferred(hipStream_t st, int nb, int M, int K, const float* A, long lda,
+                                   const float* const* W, long ldw, const int* N, float* slab,
+                                   size_t slab_floats, int* splits, size_t* off);
 // C[M,N] += A[K,M]^T * B[K,N]          (Linear weight gradient; deterministic split-K
 // through `slab`, which must hold gemm_tn_slab_floats(M,N,K) floats)
 size_t gemm_tn_slab_floats(int M, int N, int K);

@@ -597,32 +597,30 @@ int hop_forward(rau_ctx* ctx, int h, const float* cp, const float* hp, float* c_
   // reduce launch (each launch on this dependent chain costs 8-20 us next to the bulk GEMMs):
   // the slab is carved into four regions so that partials can stay alive side by side.
   const size_t reg = ctx->slab_floats / 4;
-  float *slab_u = ctx->slab + reg, *slab_z = ctx->slab + 2 * reg, *slab_g = ctx->slab + 3 * reg;
-  int ns_u = 0, ns_z = 0, ns_h = 0, ns_i = 0, ns_c = 0;
-  {  // q_embed SS:231-236
-    LINOPTS(o);
-    o.slab_floats = reg;
+  float *slab_u = ctx->slab + reg, *slab_t = ctx->slab + 2 * reg;
+  int ns_u = 0, ns_t = 0, ns_i = 0, ns_c = 0;
+  size_t off[3];
+  {  // the three Linears fed by h_prev alone -- q_embed's recurrent half (SS:234), attbymemory
+     // (SS:287) and the attention LSTM's h2h (ATTLSTM.lua:7) -- in ONE launch
+    const float* Wt[3] = {ctx->h_proj.W, ctx->att_mem.W, ctx->lstm_h2h.W};
+    const int Nt[3] = {M, SL, 4 * R};
+    RUN("small_gemm", gflop(B, M + SL + 4 * R, R), 0,
+        gemm_nt_hetero_deferred(st, 3, B, R, hp, R, Wt, R, Nt, slab_t, reg + reg / 2, &ns_t, off));
+  }
+  float *slab_z = slab_t + off[1], *slab_g = slab_t + off[2];
+  {  // qf = tanh(Yq + h_prev Wh^T): the q half (with both biases) was computed for all hops at once
+    LinOpts o;
     o.addend = ctx->Yq + (size_t)h * BM_;
     o.add_rs = M;
     o.act = 1;
-    RUN("small_gemm", gflop(B, M, R), 0, gemm_nt(st, B, M, R, hp, R, ctx->h_proj.W, R, qf, M, o));
+    RUN("lin_reduce", 0, 0, lin_reduce_epilogue(st, B, M, ns_t, slab_t + off[0], qf, M, o));
   }
   {  // attbycontent SS:244-252: u = qf Wa^T (+ ba inside att_fwd_fused)
     LinOpts o;
     o.slab = slab_u; o.slab_floats = reg; o.defer_splits = &ns_u;
     RUN("small_gemm", gflop(B, A, M), 0, gemm_nt(st, B, A, M, qf, M, ctx->att_q.W, M, ctx->u, A, o));
   }
-  {  // attbymemory SS:285-290 (linear part; + bm inside att_fwd_fused)
-    LinOpts o;
-    o.slab = slab_z; o.slab_floats = reg; o.defer_splits = &ns_z;
-    RUN("small_gemm", gflop(B, SL, R), 0, gemm_nt(st, B, SL, R, hp, R, ctx->att_mem.W, R, ctx->zm, S, o));
-  }
-  {  // attention LSTM's recurrent half h_prev Wr^T (ATTLSTM.lua:7): partials first in slab_g
-    LinOpts o;
-    o.slab = slab_g; o.slab_floats = reg / 2; o.defer_splits = &ns_h;
-    RUN("small_gemm", gflop(B, 4 * R, R), 0,
-        gemm_nt(st, B, 4 * R, R, hp, R, ctx->lstm_h2h.W, R, g4, 4 * R, o));
-  }
+  const int ns_z = ns_t, ns_h = ns_t;
   // tanh(P+u), score, softmax, attention-weighted sum: one pass per sample
   {
     AttPartials ap;
