@@ -141,7 +141,8 @@ hipError_t lstm_bwd_multi(hipStream_t st, int order, int nB, int R, const LstmBw
 // two reduce launches less on the recurrence's critical path.
 // SL: logical number of positions when the tensors' pitch S is padded (7x7 maps); positions
 // [SL, S) get zero attention.
-struct AttPartials { int u_ns = 0; const float* u_bias = nullptr; int z_ns = 0; const float* z_bias = nullptr; int SL = 0; };
+// u_out: where to keep the finished u rows [nB][A] when T is not stored (T == nullptr).
+struct AttPartials { int u_ns = 0; const float* u_bias = nullptr; int z_ns = 0; const float* z_bias = nullptr; int SL = 0; float* u_out = nullptr; };
 hipError_t att_fwd_fused(hipStream_t st, int nB, int M, int A, int S, const float* P,
                          const float* u, const float* ws, const float* bs, const float* zm,
                          const float* I, const float* qf, float* T, float* a, float* jv,
@@ -150,7 +151,9 @@ hipError_t att_fwd_fused(hipStream_t st, int nB, int M, int A, int S, const floa
 // dz = softmax'(da); T -> dS = dz ws (1-T^2) in place; du = sum_s dS; dwsp = sum_s dz T.
 hipError_t att_bwd_fused(hipStream_t st, int nB, int M, int A, int S, const float* I,
                          const float* dj, const float* a, const float* da_lin,
-                         const float* ws, float* T_to_dS, float* dz, float* du, float* dwsp);
+                         const float* ws, float* T_to_dS, float* dz, float* du, float* dwsp,
+                         const float* Psrc = nullptr /* T not kept: recompute tanh(Psrc + u) */,
+                         const float* u = nullptr);
 // xd[h][i] = X[i] * keep(h, i) * scale for h < H, i < per_hop (feature-map dropout, SS:239)
 // SL != Sp: rows of SL logical positions at pitch Sp (mask indexed logically, pad columns zeroed)
 hipError_t dropout_features(hipStream_t st, int H, size_t per_hop, const float* X,

@@ -387,6 +387,7 @@ __global__ __launch_bounds__(NW * 64) void k_att_fwd_fused(
     const float* __restrict__ ws, const float* __restrict__ bs, const float* __restrict__ zm,
     const float* __restrict__ I, const float* __restrict__ qf, float* __restrict__ T,
     float* __restrict__ a, float* __restrict__ jv, AttPartials ap) {
+  // T == nullptr: tanh(P + u) is not kept (the backward recomputes it from P and ap.u_out)
   RAU_CHAIN_PRIO();
   extern __shared__ __attribute__((aligned(16))) float sm[];
   float* red = sm;                     // [NW][S]
@@ -416,6 +417,8 @@ __global__ __launch_bounds__(NW * 64) void k_att_fwd_fused(
     }
   }
   if (ap.u_ns || ap.z_ns) __syncthreads();
+  if (ap.u_out)   // the finished u row, for the backward's tanh(P + u)
+    for (int k = tid; k < A; k += NW * 64) ap.u_out[(size_t)b * A + k] = ap.u_ns ? us[k] : ub[k];
   // ---- phase 1: T = tanh(P + u), e[s] = sum_k ws[k] T[k,s]
   for (int q0 = 0; q0 < S4; q0 += 64) {
     const int q = q0 + l;
@@ -428,7 +431,7 @@ __global__ __launch_bounds__(NW * 64) void k_att_fwd_fused(
         float4 t;
         t.x = tanh_fast(p.x + uk); t.y = tanh_fast(p.y + uk);
         t.z = tanh_fast(p.z + uk); t.w = tanh_fast(p.w + uk);
-        reinterpret_cast<float4*>(Tb + (size_t)k * S)[q] = t;
+        if (T) reinterpret_cast<float4*>(Tb + (size_t)k * S)[q] = t;
         acc.x += wk * t.x; acc.y += wk * t.y; acc.z += wk * t.z; acc.w += wk * t.w;
       }
       reinterpret_cast<float4*>(red + (size_t)w * S)[q] = acc;
@@ -509,7 +512,7 @@ __global__ __launch_bounds__(NW * 64) void k_att_bwd_fused(
     int M, int A, int S, const float* __restrict__ I, const float* __restrict__ dj,
     const float* __restrict__ a, const float* __restrict__ da_lin, const float* __restrict__ ws,
     float* __restrict__ T, float* __restrict__ dz, float* __restrict__ du,
-    float* __restrict__ dwsp) {
+    float* __restrict__ dwsp, const float* __restrict__ Psrc, const float* __restrict__ u) {
   RAU_CHAIN_PRIO();
   extern __shared__ __attribute__((aligned(16))) float sm[];
   float* red = sm;                     // [NW][S]
@@ -552,13 +555,24 @@ __global__ __launch_bounds__(NW * 64) void k_att_bwd_fused(
     dz[(size_t)b * S + s] = v;
   }
   __syncthreads();
-  // ---- phase 3: T -> dS in place, du[k] = sum_s dS, dwsp[k] = sum_s dz T; wave per row
+  // ---- phase 3: T -> dS in place, du[k] = sum_s dS, dwsp[k] = sum_s dz T; wave per row.
+  // With Psrc the forward did not keep T: it is recomputed as tanh(Psrc + u) (Psrc may be the
+  // very buffer dS is written to: same thread, same address, read first).
   float* Tb = T + (size_t)b * A * S;
+  const float* Pb = Psrc ? Psrc + (size_t)b * A * S : nullptr;
   for (int k = w; k < A; k += NW) {
     const float wk = ws[k];
+    const float uk = Psrc ? u[(size_t)b * A + k] : 0.f;
     float s1 = 0.f, s2 = 0.f;
     for (int q = l; q < S4; q += 64) {
-      const float4 t = reinterpret_cast<const float4*>(Tb + (size_t)k * S)[q];
+      float4 t;
+      if (Psrc) {
+        const float4 p = reinterpret_cast<const float4*>(Pb + (size_t)k * S)[q];
+        t.x = tanh_fast(p.x + uk); t.y = tanh_fast(p.y + uk);
+        t.z = tanh_fast(p.z + uk); t.w = tanh_fast(p.w + uk);
+      } else {
+        t = reinterpret_cast<const float4*>(Tb + (size_t)k * S)[q];
+      }
       const float4 d = reinterpret_cast<const float4*>(dzs)[q];
       float4 o;
       o.x = d.x * wk * (1.f - t.x * t.x);
@@ -579,11 +593,12 @@ __global__ __launch_bounds__(NW * 64) void k_att_bwd_fused(
 }
 hipError_t att_bwd_fused(hipStream_t st, int nB, int M, int A, int S, const float* I,
                          const float* dj, const float* a, const float* da_lin,
-                         const float* ws, float* T_to_dS, float* dz, float* du, float* dwsp) {
+                         const float* ws, float* T_to_dS, float* dz, float* du, float* dwsp,
+                         const float* Psrc, const float* u) {
   const int nw = att_waves(true);
   const size_t lds = ((size_t)(nw + 1) * S + nw) * sizeof(float);
 #define ATT_BWD(NW_) hipLaunchKernelGGL(k_att_bwd_fused<NW_>, dim3(nB), dim3(NW_ * 64), lds, st, M, A, \
-                                        S, I, dj, a, da_lin, ws, T_to_dS, dz, du, dwsp)
+                                        S, I, dj, a, da_lin, ws, T_to_dS, dz, du, dwsp, Psrc, u)
   if (nw == 4) ATT_BWD(4); else if (nw == 8) ATT_BWD(8); else ATT_BWD(16);
 #undef ATT_BWD
   return hipGetLastError();

@@ -274,7 +274,7 @@ int rau_create(const rau_config* cfg, rau_ctx** out) {
   CK(dalloc(ctx, &ctx->xd, HB * D * S));
   CK(dalloc(ctx, &ctx->I, HB * M * S));
   CK(dalloc(ctx, &ctx->T, HB * A * S));
-  CK(dalloc(ctx, &ctx->u, (size_t)B * A));
+  CK(dalloc(ctx, &ctx->u, HB * A));   // finished u = qf Wa^T + ba per hop (the backward's tanh(P + u))
   CK(dalloc(ctx, &ctx->P0, (size_t)B * A * S));
   CK(dalloc(ctx, &ctx->WiT, (size_t)M * D));
   CK(dalloc(ctx, &ctx->WpT, (size_t)A * M));
@@ -587,7 +587,6 @@ int hop_forward(rau_ctx* ctx, int h, const float* cp, const float* hp, float* c_
   auto gflop = [](double m, double n, double k) { return 2.0 * m * n * k; };
   const size_t BM_ = (size_t)B * M, BS_ = (size_t)B * S, BR_ = (size_t)B * R;
   float* qf = ctx->qf + (size_t)h * BM_;
-  float* Th = ctx->T + (size_t)h * B * A * S;
   float* ah = ctx->a + (size_t)h * BS_;
   float* jh = ctx->j + (size_t)h * BM_;
   float* g4 = ctx->g4 + (size_t)h * B * 4 * R;
@@ -627,9 +626,10 @@ int hop_forward(rau_ctx* ctx, int h, const float* cp, const float* hp, float* c_
     ap.u_ns = ns_u; ap.u_bias = ctx->att_q.b;
     ap.z_ns = ns_z; ap.z_bias = ctx->att_mem.b;
     ap.SL = SL;
-    RUN("att_fwd_fused", 2.0 * B * S * (A + M), ((double)B * A * S * 2 + BM_ * S) * 4,
+    ap.u_out = ctx->u + (size_t)h * B * A;   // tanh(P + u) itself is not kept: 25 % less traffic here
+    RUN("att_fwd_fused", 2.0 * B * S * (A + M), ((double)B * A * S + BM_ * S) * 4,
         att_fwd_fused(st, B, M, A, S, Pin, slab_u, ctx->att_score.W, ctx->att_score.b, slab_z, Ih, qf,
-                      Th, ah, ctx->jv, ap));
+                      nullptr, ah, ctx->jv, ap));
   }
   {  // classifier SS:265-283
     LINOPTS(o);
@@ -742,7 +742,8 @@ int hop_backward(rau_ctx* ctx, int h, const float* cp, const float* Ih, const Ho
   }
   RUN("att_bwd_fused", 2.0 * B * S * (A + M), ((double)B * A * S * 2 + BM_ * S) * 4,
       att_bwd_fused(st, B, M, A, S, Ih, djh, ah, ctx->da_lin, ctx->att_score.W, Th, dzh, duh,
-                    ctx->dwsp + (size_t)h * B * A));
+                    ctx->dwsp + (size_t)h * B * A, ctx->I_shared ? ctx->P0 : Th,
+                    ctx->u + (size_t)h * B * A));
   {  // dh_prev += dz Wm
     LINOPTS(o);
     o.accumulate = 1;
