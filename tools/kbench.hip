@@ -34,6 +34,55 @@ static float* dev_rand(size_t n, float scale = 1.f) {
   float* d; CK(hipMalloc(&d, n * 4)); CK(hipMemcpy(d, h.data(), n * 4, hipMemcpyHostToDevice));
   return d;
 }
+
+// LDS-fragment-read + MFMA loop of the 128x128 tile kernel in isolation (same fragment mapping
+// and LDS layout as gemm_kernel::compute): WRITES = re-store the stage each K-step, BAR = barrier
+template <int PINNED, int WRITES, int BAR>
+__global__ __launch_bounds__(256, 2) void k_ldsmfma(int iters, float* out) {
+  constexpr int BK = 32, LD = 132;
+  __shared__ __attribute__((aligned(16))) float smem[2 * 2 * BK * LD];
+  float* As = smem;
+  float* Bs = smem + 2 * BK * LD;
+  const int tid = threadIdx.x, l = tid & 63, w = tid >> 6, wm = w & 1, wn = w >> 1;
+  for (int i = tid; i < 2 * 2 * BK * LD; i += 256) smem[i] = (float)((i * 7 + tid) & 15) * 0.125f;
+  __syncthreads();
+  rau::f32x16 acc[2][2];
+  for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  const int fa = (l >> 5) * LD + wm * 64 + (l & 31);
+  const int fb = (l >> 5) * LD + wn * 64 + (l & 31);
+  float4 wv = make_float4(0.5f, 0.25f, 0.125f, 1.f);
+  for (int it = 0; it < iters; ++it) {
+    const int cur = it & 1;
+    const float* as = As + cur * BK * LD + fa;
+    const float* bs = Bs + cur * BK * LD + fb;
+    float a[2][2], b[2][2];
+    for (int i = 0; i < 2; ++i) a[0][i] = as[i * 32];
+    for (int j = 0; j < 2; ++j) b[0][j] = bs[j * 32];
+#pragma unroll
+    for (int kk = 0; kk < BK / 2; ++kk) {
+      const int c = kk & 1, nx = c ^ 1;
+      if (kk + 1 < BK / 2) {
+        for (int i = 0; i < 2; ++i) a[nx][i] = as[(kk + 1) * 2 * LD + i * 32];
+        for (int j = 0; j < 2; ++j) b[nx][j] = bs[(kk + 1) * 2 * LD + j * 32];
+        if (PINNED) __builtin_amdgcn_sched_barrier(0);
+      }
+      for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c][i], b[c][j], acc[i][j], 0, 0, 0);
+    }
+    if (WRITES) {   // the 8 ds_write_b128 per thread of one K-step, into the other stage
+      float* d = smem + (cur ^ 1) * BK * LD + (tid >> 5) * LD + (tid & 31) * 4;
+      for (int i = 0; i < 4; ++i) *reinterpret_cast<float4*>(d + i * 8 * LD) = wv;
+      float* e = Bs + (cur ^ 1) * BK * LD + (tid >> 5) * LD + (tid & 31) * 4;
+      for (int i = 0; i < 4; ++i) *reinterpret_cast<float4*>(e + i * 8 * LD) = wv;
+    }
+    if (BAR) __syncthreads();
+  }
+  float s = 0.f;
+  for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int r = 0; r < 16; ++r) s += acc[i][j][r];
+  out[blockIdx.x * 256 + tid] = s;
+}
+
 static double timeit(hipStream_t st, int iters, const std::function<hipError_t()>& f) {
   hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
   for (int i = 0; i < 3; ++i) CK(f());
@@ -104,6 +153,18 @@ int main(int argc, char** argv) {
     report("v: KC x RC slab-store", timeit(st, 20, [&] { return launch_gemm<128, 128, 32, SRC_KC, SRC_RC, EPI_SLAB>(st, Q, 1); }), 2.0 * M * NS * D);
     GemmParams R2 = P; R2.A = X; R2.a_rs = M;  // A as [K][M] row-contig
     report("v: RC x RC slab-store", timeit(st, 20, [&] { return launch_gemm<128, 128, 32, SRC_RC, SRC_RC, EPI_SLAB>(st, R2, 1); }), 2.0 * M * NS * D);
+  }
+  if (!strcmp(only, "mb")) {
+    for (int wgs : {256, 512}) {
+      const double fl = (double)wgs * 3000 * 2.0 * 128 * 128 * 32;
+      char nm[64];
+#define MB(P_, W_, B_)                                                                              \
+      snprintf(nm, 64, "lds+mfma pin%d wr%d bar%d g%d", P_, W_, B_, wgs);                           \
+      report(nm, timeit(st, 3, [&] { hipLaunchKernelGGL((k_ldsmfma<P_, W_, B_>), dim3(wgs), dim3(256), 0, st, 3000, I); return hipGetLastError(); }), fl)
+      MB(0, 0, 0); MB(1, 0, 0); MB(0, 1, 0); MB(0, 1, 1); MB(1, 1, 1);
+#undef MB
+    }
+    return 0;
   }
   if (only[0] && strcmp(only, "conv") && strcmp(only, "all")) return 0;
   report("conv_embed_fwd", timeit(st, 20, [&] { return conv_embed_fwd(st, B, D, S, M, X, Wi, bi, I); }), 2.0 * M * NS * D);
