@@ -87,6 +87,10 @@ def main():
     ap.add_argument("--dtype", choices=("f32", "bf16"), default="f32",
                     help="bf16 = BASELINE.json configs[2] mode (use with --D 2048): bf16-operand "
                          "conv GEMMs, f32 accumulate; never the default metric")
+    ap.add_argument("--variant", choices=("SS", "MS", "Full", "ResNet"), default="SS",
+                    help="per-hop loss weights of the four training scripts (SS:569, MS:568-570, "
+                         "Full/ResNet: epoch-gated 0|1, see --epoch)")
+    ap.add_argument("--epoch", type=int, default=0, help="epoch for the Full/ResNet gating vector")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -126,7 +130,7 @@ def main():
                              lens="full")
     m.set_batch(**batch)                          # resident in HBM from here on
     m.training()
-    hop_w = hop_weights("SS", cfg.H)
+    hop_w = hop_weights(args.variant, cfg.H, args.epoch)
     reducer = None
     if world > 1:
         from rau_vqa_amd.dist import GradAllReduce, NativeGradAllReduce
@@ -257,11 +261,13 @@ def main():
                 "dtype": "f32" if args.dtype == "f32" else "bf16 conv-GEMM operands, f32 accumulate",
                 "data": "synthetic",
                 "config": {"workload": "Ours_SS 8-step RAU fwd+bwd (configs[1])"
-                           if (args.dtype, args.D) == ("f32", 512) else
-                           f"8-step RAU fwd+bwd, D={args.D}, {args.dtype} (not the headline config)",
+                           if (args.dtype, args.D, args.variant) == ("f32", 512, "SS") else
+                           f"Ours_{args.variant} 8-step RAU fwd+bwd, D={args.D}, {args.dtype} (not the headline config)",
                            "batch_per_gpu": cfg.B, "global_batch": cfg.B * world, "T": cfg.T,
                            "feature_map": f"14x14x{cfg.D}", "hops": cfg.H,
-                           "parallelism": f"dp{world}", "hop_weights": "SS (x nHop)",
+                           "parallelism": f"dp{world}",
+                           "hop_weights": {"SS": "SS (x nHop)", "MS": "MS (x 1)"}.get(
+                               args.variant, f"{args.variant} gating, epoch {args.epoch}"),
                            "dropout": "train mode, Philox masks per step"}}
         line.update(extra)
         print(json.dumps(line))

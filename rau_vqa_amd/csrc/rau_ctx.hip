@@ -950,10 +950,17 @@ int rau_backward(rau_ctx* ctx, const float* hop_w) {
   HIPC(hipMemcpyAsync(ctx->hopw_d, hop_w, H * sizeof(float), hipMemcpyHostToDevice, st));
   RUN("scale_hops", 0, (double)H * B * K * 8, scale_hops(st, H, (size_t)B * K, ctx->hopw_d, ctx->dl));
 
+  // Hops behind the last one with a non-zero loss weight receive no gradient at all (zero
+  // criterion gradient, zero recurrent gradient: Full/ResNet late-epoch gating, Full:587-589):
+  // their backward is identically zero and is skipped -- HA hops are "active".
+  int HA = 0;
+  for (int h = 0; h < H; ++h)
+    if (hop_w[h] != 0.f) HA = h + 1;
+
   // ---------------- RAU BPTT, SS:561-578
   const float* dc_next = nullptr;  // grad_att_c / grad_att_h zeros, SS:561-562
   const float* dh_next = nullptr;
-  for (int h = H - 1; h >= 0; --h) {
+  for (int h = HA - 1; h >= 0; --h) {
     float* dc_out = ctx->dcn[h & 1];
     float* dh_out = ctx->dhp[h & 1];
     {
@@ -979,7 +986,7 @@ int rau_backward(rau_ctx* ctx, const float* hop_w) {
       HIPC(hipEventRecord(ctx->evK[h], st));
       HIPC(hipStreamWaitEvent(sb, ctx->evK[h], 0));
       if (!ctx->I_shared) {
-        const int nH = gsz[h] * B;
+        const int nH = (std::min(h + gsz[h], HA) - h) * B;   // active hops of this group
         const size_t hb = (size_t)h * B;
         RUNS(sb, "conv_att_dgrad", gflop(M, (double)nH * S, A),
              ((double)nH * A * S + 2.0 * nH * M * S) * 4,
@@ -995,7 +1002,7 @@ int rau_backward(rau_ctx* ctx, const float* hop_w) {
                               ctx->xd + hb * D * S, ctx->i_embed.dW, ctx->slab2, ctx->bf16,
                               ctx->i_embed.db));
       } else {
-        for (int hh2 = 0; hh2 < H; ++hh2) {  // evaluate mode: I (and X) shared by all hops
+        for (int hh2 = 0; hh2 < HA; ++hh2) {  // evaluate mode: I (and X) shared by all hops
           float* Th2 = ctx->T + (size_t)hh2 * B * A * S;
           float* dZh = ctx->dZ + (size_t)hh2 * BM_ * S;
           RUNS(sb, "conv_att_dgrad", gflop(M, (double)B * S, A), ((double)B * A * S + 2.0 * BM_ * S) * 4,
@@ -1012,10 +1019,11 @@ int rau_backward(rau_ctx* ctx, const float* hop_w) {
   }
   {  // dq = sum_h (dq~_h Wq) (.) mask_h     (ConcatTable backward, SS:579)
     LINOPTS(o);
-    RUN("q_proj_dgrad", gflop(H * B, Q, M), 0,
-        gemm_nn(st, H * B, Q, M, ctx->dqt, M, ctx->q_proj.W, Q, ctx->dQD, Q, o));
-    RUN("dq_reduce", 0, (double)H * B * Q * 4,
-        dq_reduce(st, H, (size_t)B * Q, ctx->dQD, m_q, sc(RAU_MASK_Q), ctx->dq));
+    if (HA > 0)
+      RUN("q_proj_dgrad", gflop(HA * B, Q, M), 0,
+          gemm_nn(st, HA * B, Q, M, ctx->dqt, M, ctx->q_proj.W, Q, ctx->dQD, Q, o));
+    RUN("dq_reduce", 0, (double)HA * B * Q * 4,
+        dq_reduce(st, HA, (size_t)B * Q, ctx->dQD, m_q, sc(RAU_MASK_Q), ctx->dq));
   }
   // bulk stream tail: the join event (the i_embed bias gradient comes out of conv_embed_wgrad:
   // row sums of its staged dZ operand)
@@ -1030,7 +1038,11 @@ int rau_backward(rau_ctx* ctx, const float* hop_w) {
   auto mult_wgrads = [&]() -> int {
     hipStream_t sw = ctx->st3;
     HIPC(hipStreamWaitEvent(sw, ctx->evW, 0));
-    const int rows = H * B;
+    const int rows = HA * B;                 // active hops only
+    if (rows == 0) {
+      HIPC(hipEventRecord(ctx->evM3, sw));
+      return 0;
+    }
     const float* hprev = ctx->hh;            // h_{0..H-1}
     const float* hnew = ctx->hh + BR_;       // h_{1..H}
     struct WG { Lin* l; const float* dY; long ldy; const float* X; long ldx; };

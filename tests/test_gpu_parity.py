@@ -87,6 +87,15 @@ def test_zero_length_rows_and_hop_gating():
     check(sh, lens=lens, hop_w=np.array([1.0, 0.0, 1.0], np.float32), scale=0.5)
 
 
+@pytest.mark.parametrize("w", [[1.0, 1.0, 0.0], [3.0, 0.0, 0.0], [0.0, 0.0, 0.0]])
+def test_trailing_hops_gated_off(w):
+    """Full / ResNet late-epoch gating (Full:582-589): hops behind the last weighted one get no
+    gradient at all; the library skips their backward, the result must not change."""
+    sh = util.shapes(util.SMALL)
+    check(sh, hop_w=np.array(w, np.float32), scale=0.5)
+    check(sh, hop_w=np.array(w, np.float32), mode="eval", scale=0.5)
+
+
 def test_resnet_like_channels_d2048():
     """cnnout_dim = 2048 (Ours_ResNet, reference ResNet:38,217): long K loop in i_embed."""
     dims = dict(B=6, T=4, V=40, E=200, Rq=32, D=2048, S=196, M=64, A=32, R=32, K=1000, H=2)
