@@ -91,6 +91,8 @@ def main():
                     help="per-hop loss weights of the four training scripts (SS:569, MS:568-570, "
                          "Full/ResNet: epoch-gated 0|1, see --epoch)")
     ap.add_argument("--epoch", type=int, default=0, help="epoch for the Full/ResNet gating vector")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay each step as one hipGraph launch (rau_graph_step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -131,6 +133,7 @@ def main():
     m.set_batch(**batch)                          # resident in HBM from here on
     m.training()
     hop_w = hop_weights(args.variant, cfg.H, args.epoch)
+    m_prof = [False]   # per-launch event profiling needs the eager path
     reducer = None
     if world > 1:
         from rau_vqa_amd.dist import GradAllReduce, NativeGradAllReduce
@@ -140,9 +143,12 @@ def main():
 
     def step(i):
         m.set_dropout_seed(123, i)
-        m.zero_grads()
-        m.forward()
-        m.backward(hop_w)
+        if args.graph and not m_prof[0]:
+            m.graph_step(hop_w)
+        else:
+            m.zero_grads()
+            m.forward()
+            m.backward(hop_w)
         if reducer is not None:
             reducer()
 
@@ -173,12 +179,14 @@ def main():
         # per-kernel-class device time (HIP events on the ctx stream, outside the timed region)
         m.prof_reset()
         m.prof_enable(True)
+        m_prof[0] = True
         nprof = 3
         for i in range(nprof):
             step(1000 + i)
         m.sync()
         prof = m.prof()
         m.prof_enable(False)
+        m_prof[0] = False
         dom = prof[DOMINANT]
         avg_ms = dom["ms"] / dom["launches"]
         flops_per_launch = dom["flops"] / dom["launches"]
@@ -268,7 +276,8 @@ def main():
                            "parallelism": f"dp{world}",
                            "hop_weights": {"SS": "SS (x nHop)", "MS": "MS (x 1)"}.get(
                                args.variant, f"{args.variant} gating, epoch {args.epoch}"),
-                           "dropout": "train mode, Philox masks per step"}}
+                           "dropout": "train mode, Philox masks per step",
+                           "launch": "hipGraph replay" if args.graph else "eager, 3 streams"}}
         line.update(extra)
         print(json.dumps(line))
     m.close()

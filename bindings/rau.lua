@@ -63,6 +63,7 @@ int rau_criterion_forward(rau_ctx* ctx, int h, const float* logits, const int32_
                           float* loss);
 int rau_criterion_backward(rau_ctx* ctx, int h, const float* logits,
                            const int32_t* labels_dev, float scale, float** d_logits);
+int rau_graph_step(rau_ctx* ctx, const float* hop_w, int zero_grads_first);
 int rau_sync(rau_ctx* ctx);
 int rau_get_losses(rau_ctx* ctx, float* losses);
 int rau_get_argmax(rau_ctx* ctx, int32_t* ans);

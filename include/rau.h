@@ -214,6 +214,13 @@ int rau_criterion_forward(rau_ctx* ctx, int h, const float* logits, const int32_
 int rau_criterion_backward(rau_ctx* ctx, int h, const float* logits,
                            const int32_t* labels_dev, float scale, float** d_logits);
 
+/* rau_zero_grads (optional) + rau_forward + rau_backward as ONE hipGraph launch: the three
+ * streams, their fork/join events and all kernel arguments are captured once per step shape
+ * (mode, longest question, number of active hops, explicit-mask sites) and replayed; the
+ * batch, the Philox key and hop_w are read from device memory, so they may change freely
+ * between launches.  Same results as the two calls, bit for bit. */
+int rau_graph_step(rau_ctx* ctx, const float* hop_w /* [H] host */, int zero_grads_first);
+
 /* ---- results (valid after rau_sync; these calls synchronise themselves) ------ */
 int rau_sync(rau_ctx* ctx);
 int rau_get_losses(rau_ctx* ctx, float* losses /* [H] */);

@@ -85,6 +85,7 @@ _SIGS = {
                                         C.POINTER(C.c_float)]),
     "rau_criterion_backward": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_float,
                                          C.POINTER(C.c_void_p)]),
+    "rau_graph_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     "rau_sync": (C.c_int, [C.c_void_p]),
     "rau_get_losses": (C.c_int, [C.c_void_p, C.c_void_p]),
     "rau_get_argmax": (C.c_int, [C.c_void_p, C.c_void_p]),

@@ -90,8 +90,9 @@ hipError_t conv_embed_wgrad(hipStream_t st, int nB, int D, int S, int M, const f
 enum GateOrder { GATES_ATT = 0 /* i g f o, ATTLSTM.lua:12-19 */,
                  GATES_DEEP = 1 /* i f o g, DeepLSTM.lua:46-54 */ };
 
+// key_dev != nullptr: (seed, step) are read from key_dev[0], key_dev[1] on the device instead
 hipError_t fill_masks(hipStream_t st, uint64_t seed, uint32_t site, uint32_t step, float p,
-                      size_t n, uint32_t* bits);
+                      size_t n, uint32_t* bits, const uint64_t* key_dev = nullptr);
 hipError_t embed_fwd(hipStream_t st, int rows, int E, const float* emb, const int32_t* tokens,
                      const uint32_t* mask, float mscale, float* we, size_t mask_e0 = 0);
 hipError_t embed_bwd_rows(hipStream_t st, int rows, int E, const int32_t* tokens, const float* dwe,

@@ -19,8 +19,13 @@ static inline int grid_for(size_t n, int block = 256, int cap = 256 * 8) {
 
 // ------------------------------------------------------------- dropout masks
 __global__ void k_fill_masks(uint64_t seed, uint32_t site, uint32_t step, uint32_t thr,
-                             size_t nwords, uint32_t* __restrict__ bits) {
+                             size_t nwords, uint32_t* __restrict__ bits,
+                             const uint64_t* __restrict__ key) {
   RAU_CHAIN_PRIO();
+  if (key) {   // (seed, step) live in device memory: a captured graph replays with fresh keys
+    seed = key[0];
+    step = (uint32_t)key[1];
+  }
   for (size_t w = blockIdx.x * (size_t)blockDim.x + threadIdx.x; w < nwords;
        w += (size_t)gridDim.x * blockDim.x) {
     const uint32_t lo = philox_keep16(seed, site, step, 2 * w, thr);
@@ -29,11 +34,11 @@ __global__ void k_fill_masks(uint64_t seed, uint32_t site, uint32_t step, uint32
   }
 }
 hipError_t fill_masks(hipStream_t st, uint64_t seed, uint32_t site, uint32_t step, float p,
-                      size_t n, uint32_t* bits) {
+                      size_t n, uint32_t* bits, const uint64_t* key_dev) {
   const size_t nwords = (n + 31) / 32;
   const uint32_t thr = (uint32_t)lroundf(p * 256.0f);
   hipLaunchKernelGGL(k_fill_masks, dim3(grid_for(nwords)), dim3(256), 0, st, seed, site, step,
-                     thr, nwords, bits);
+                     thr, nwords, bits, key_dev);
   return hipGetLastError();
 }
 
@@ -112,8 +117,9 @@ __global__ void k_embed_bwd(int E, const int32_t* __restrict__ utok,
                             float mscale, float* __restrict__ gE) {
   RAU_CHAIN_PRIO();
   const int u = blockIdx.x;
-  const int tok = utok[u];
   const int p0 = ustart[u], p1 = ustart[u + 1];
+  if (p1 <= p0) return;   // padding entry (the grid may cover the maximum token count)
+  const int tok = utok[u];
   for (int e = threadIdx.x; e < E; e += blockDim.x) {
     float acc = 0.f;
     for (int p = p0; p < p1; ++p) {

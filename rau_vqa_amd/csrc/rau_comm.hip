@@ -99,8 +99,12 @@ int rau_allreduce_grads(rau_ctx* ctx) {
   if (!ctx->bwd_done) return fail(RAU_ERR_STATE, "rau_allreduce_grads: no rau_backward to reduce");
   ncclComm_t comm = static_cast<ncclComm_t>(ctx->comm);
   hipStream_t sc = ctx->st_comm;
-  HIPC(hipStreamWaitEvent(sc, ctx->evD, 0));
-  HIPC(hipStreamWaitEvent(sc, ctx->evM3, 0));
+  if (ctx->graph_last) {   // the step ran as a graph: only its end is a waitable event
+    HIPC(hipStreamWaitEvent(sc, ctx->evEnd, 0));
+  } else {
+    HIPC(hipStreamWaitEvent(sc, ctx->evD, 0));
+    HIPC(hipStreamWaitEvent(sc, ctx->evM3, 0));
+  }
   Group& gm = ctx->grp[RAU_GROUP_MULT];
   NCCLC(g_rccl.AllReduce(gm.g, gm.g, gm.n, ncclFloat, ncclAvg, comm, sc));
   HIPC(hipStreamWaitEvent(sc, ctx->evEnd, 0));

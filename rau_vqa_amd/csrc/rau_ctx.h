@@ -138,6 +138,11 @@ struct rau_ctx {
   hipStream_t st_comm = nullptr;
   hipEvent_t evC = nullptr;
   int comm_ranks = 0;
+  // hipGraph replay of a whole step (rau_graph_step): one executable graph per step "shape"
+  uint64_t* dkey = nullptr;      // device copy of (seed, step): what fill_masks reads
+  bool capturing = false;
+  bool graph_last = false;       // the last backward ran inside a graph (its events are graph-internal)
+  std::vector<std::pair<uint64_t, hipGraphExec_t>> graphs;
   // update
   float *npart = nullptr, *norms_d = nullptr;
   bool fwd_done = false, bwd_done = false;

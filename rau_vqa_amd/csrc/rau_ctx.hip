@@ -340,6 +340,7 @@ int rau_create(const rau_config* cfg, rau_ctx** out) {
     CK(dalloc(ctx, &ctx->edc[L][0], (size_t)B * Rq));
     CK(dalloc(ctx, &ctx->edc[L][1], (size_t)B * Rq));
   }
+  CK(dalloc(ctx, &ctx->dkey, (size_t)2));
   CK(dalloc(ctx, &ctx->npart, (size_t)1024));
   CK(dalloc(ctx, &ctx->norms_d, (size_t)4));
 #undef CK
@@ -362,6 +363,7 @@ void rau_destroy(rau_ctx* ctx) {
   if (ctx->st) hipStreamSynchronize(ctx->st);
   if (ctx->st2) hipStreamSynchronize(ctx->st2);
   if (ctx->st3) hipStreamSynchronize(ctx->st3);
+  for (auto& g : ctx->graphs) hipGraphExecDestroy(g.second);
   for (void* p : ctx->allocs) hipFree(p);
   for (auto& r : ctx->precs) {
     hipEventDestroy(r.a);
@@ -464,6 +466,9 @@ int rau_set_dropout_seed(rau_ctx* ctx, uint64_t seed, uint32_t step) {
   ctx->step = step;
   for (int i = 0; i < 5; ++i) ctx->mexplicit[i] = false;
   ctx->mod_masks_valid = false;
+  // device copy for fill_masks (pageable source: staged at call time, ordered on the ctx stream)
+  const uint64_t key[2] = {seed, (uint64_t)step};
+  HIPC(hipMemcpyAsync(ctx->dkey, key, sizeof(key), hipMemcpyHostToDevice, ctx->st));
   return RAU_OK;
 }
 int rau_set_mask(rau_ctx* ctx, int site, const uint8_t* keep, size_t n) {
@@ -487,7 +492,7 @@ static int gen_masks(rau_ctx* ctx) {
     if (!ctx->mexplicit[i] && ctx->mp[i] > 0.f)
       RUN("fill_masks", 0, ctx->mcount[i] / 8.0,
           fill_masks(ctx->st, ctx->seed, (uint32_t)i, ctx->step, ctx->mp[i], ctx->mcount[i],
-                     ctx->mbits[i]));
+                     ctx->mbits[i], ctx->dkey));
   return 0;
 }
 int rau_get_mask(rau_ctx* ctx, int site, uint8_t* keep, size_t n) {
@@ -542,6 +547,10 @@ int rau_set_batch(rau_ctx* ctx, const float* feats, const int32_t* tokens, const
   }
   ustart.push_back((int32_t)pos.size());
   ctx->nuniq = (int)utok.size();
+  // pad to the maximum token count: a graph-captured embed_bwd launches T*B blocks, the surplus
+  // ones see an empty range
+  utok.resize((size_t)c.T * c.B, 1);
+  ustart.resize((size_t)c.T * c.B + 1, (int32_t)pos.size());
   if (feats)   // rows of S positions into rows of Sp (pad columns stay zero)
     HIPC(hipMemcpy2DAsync(ctx->feats, (size_t)ctx->Sp * sizeof(float), feats,
                           (size_t)c.S * sizeof(float), (size_t)c.S * sizeof(float),
@@ -947,7 +956,8 @@ int rau_backward(rau_ctx* ctx, const float* hop_w) {
   ctx->fwd_done = false;  // dl is scaled in place below: one backward per forward
 
   // dpred:mul(w[h])  SS:569 / MS:568-570 / Full:587-589
-  HIPC(hipMemcpyAsync(ctx->hopw_d, hop_w, H * sizeof(float), hipMemcpyHostToDevice, st));
+  if (!ctx->capturing)   // (rau_graph_step uploads the weights before it launches the graph)
+    HIPC(hipMemcpyAsync(ctx->hopw_d, hop_w, H * sizeof(float), hipMemcpyHostToDevice, st));
   RUN("scale_hops", 0, (double)H * B * K * 8, scale_hops(st, H, (size_t)B * K, ctx->hopw_d, ctx->dl));
 
   // Hops behind the last one with a non-zero loss weight receive no gradient at all (zero
@@ -1155,7 +1165,7 @@ int rau_backward(rau_ctx* ctx, const float* hop_w) {
           gemm_nn(st, rows, E, 4 * Rq, ctx->dG1, 4 * Rq, ctx->i2h[0].W, E, ctx->dwe, E, o));
     }
     RUN("embed_bwd", 0, (double)rows * E * 12,
-        embed_bwd(st, ctx->nuniq, E, ctx->utok, ctx->ustart, ctx->upos, ctx->dwe, ctx->we, m_we,
+        embed_bwd(st, ctx->capturing ? c.T * B : ctx->nuniq, E, ctx->utok, ctx->ustart, ctx->upos, ctx->dwe, ctx->we, m_we,
                   sc(RAU_MASK_WE), ctx->grp[RAU_GROUP_EMBED].g));
     if (int rc = enc_wgrads(0, uc > 0 ? uc : TL, ctx->evE)) return rc;
   }
@@ -1164,6 +1174,58 @@ int rau_backward(rau_ctx* ctx, const float* hop_w) {
   HIPC(hipStreamWaitEvent(st, ctx->evD, 0));  // join: every gradient is ordered on st
   HIPC(hipEventRecord(ctx->evEnd, st));
   ctx->bwd_done = true;
+  ctx->graph_last = false;
+  return RAU_OK;
+}
+
+// One training step's forward + backward (optionally with the gradient zeroing in front) as ONE
+// hipGraph launch.  The three streams, their fork/join events and every kernel argument are
+// captured once per step "shape" -- (mode, longest question, active hops, which mask sites are
+// explicit, zeroing or not) -- and replayed; what changes from step to step lives in device
+// memory: the batch (rau_set_batch), the Philox key (rau_set_dropout_seed) and the hop weights
+// (uploaded here, in front of the launch).
+int rau_graph_step(rau_ctx* ctx, const float* hop_w, int zero_grads_first) {
+  NEED(ctx && hop_w, "null argument");
+  if (!ctx->have_batch || !ctx->have_labels)
+    return fail(RAU_ERR_STATE, "rau_graph_step: needs a batch with labels (rau_set_batch)");
+  if (ctx->prof_on) return fail(RAU_ERR_STATE, "rau_graph_step: profiling must be off");
+  const int H = ctx->cfg.H;
+  int HA = 0;
+  for (int h = 0; h < H; ++h)
+    if (hop_w[h] != 0.f) HA = h + 1;
+  uint64_t key = (uint64_t)ctx->mode | ((uint64_t)ctx->max_len << 2) | ((uint64_t)HA << 12) |
+                 ((uint64_t)(zero_grads_first != 0) << 22);
+  for (int i = 0; i < 5; ++i) key |= (uint64_t)ctx->mexplicit[i] << (24 + i);
+  HIPC(hipMemcpyAsync(ctx->hopw_d, hop_w, H * sizeof(float), hipMemcpyHostToDevice, ctx->st));
+  hipGraphExec_t exec = nullptr;
+  for (auto& g : ctx->graphs)
+    if (g.first == key) exec = g.second;
+  if (!exec) {
+    hipGraph_t graph = nullptr;
+    HIPC(hipStreamBeginCapture(ctx->st, hipStreamCaptureModeRelaxed));
+    ctx->capturing = true;
+    int rc = zero_grads_first ? rau_zero_grads(ctx) : 0;
+    if (!rc) rc = rau_forward(ctx);
+    if (!rc) rc = rau_backward(ctx, hop_w);
+    ctx->capturing = false;
+    hipError_t e = hipStreamEndCapture(ctx->st, &graph);
+    if (rc) {
+      if (graph) hipGraphDestroy(graph);
+      return rc;
+    }
+    if (e != hipSuccess)
+      return fail(RAU_ERR_DEVICE, "hipStreamEndCapture: %s", hipGetErrorString(e));
+    e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    hipGraphDestroy(graph);
+    if (e != hipSuccess)
+      return fail(RAU_ERR_DEVICE, "hipGraphInstantiate: %s", hipGetErrorString(e));
+    ctx->graphs.push_back({key, exec});
+  }
+  HIPC(hipGraphLaunch(exec, ctx->st));
+  HIPC(hipEventRecord(ctx->evEnd, ctx->st));   // a real (non-captured) end-of-step event
+  ctx->fwd_done = false;
+  ctx->bwd_done = true;
+  ctx->graph_last = true;
   return RAU_OK;
 }
 
@@ -1171,7 +1233,7 @@ int rau_wait_grads(rau_ctx* ctx, int group, void* hip_stream) {
   if (int rc = check_group(ctx, group)) return rc;
   if (!ctx->bwd_done) return fail(RAU_ERR_STATE, "rau_wait_grads: no rau_backward to wait for");
   hipStream_t s = (hipStream_t)hip_stream;
-  if (group == RAU_GROUP_MULT) {
+  if (group == RAU_GROUP_MULT && !ctx->graph_last) {
     // final once the bulk stream's conv gradients (evD) and the weight-gradient stream's
     // mult block (evM3) are done -- i.e. before the encoder BPTT, which they overlap
     HIPC(hipStreamWaitEvent(s, ctx->evD, 0));

@@ -82,7 +82,7 @@ static int ensure_masks(rau_ctx* ctx) {
     if (!ctx->mexplicit[i] && ctx->mp[i] > 0.f)
       RUN("fill_masks", 0, ctx->mcount[i] / 8.0,
           fill_masks(ctx->st, ctx->seed, (uint32_t)i, ctx->step, ctx->mp[i], ctx->mcount[i],
-                     ctx->mbits[i]));
+                     ctx->mbits[i], ctx->dkey));
   ctx->mod_masks_seed = ctx->seed;
   ctx->mod_masks_step = ctx->step;
   ctx->mod_masks_valid = true;

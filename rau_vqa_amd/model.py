@@ -209,6 +209,13 @@ class RAU:
             raise ValueError("hop_w must have H entries")
         L.check(self._lib.rau_backward(self._h, w.ctypes.data))
 
+    def graph_step(self, hop_w, zero_grads=True):
+        """zero_grads + forward + backward as one hipGraph launch (captured on first use)."""
+        w = np.ascontiguousarray(hop_w, np.float32)
+        if w.shape != (self.cfg.H,):
+            raise ValueError("hop_w must have H entries")
+        L.check(self._lib.rau_graph_step(self._h, w.ctypes.data, int(zero_grads)))
+
     def sync(self):
         L.check(self._lib.rau_sync(self._h))
 
