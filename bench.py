@@ -11,14 +11,20 @@ in the three flat buffers) [+ RCCL average of those buffers when N > 1].  Inputs
 are resident in HBM before the timed region.  Noise/clip/Adam is NOT in the
 metric; it is timed separately as step_incl_update.
 
-For N > 1 launch with torch.distributed.run, one rank per GPU (weak scaling:
-the per-GPU batch stays 256).
+N > 1: one rank per GPU over RCCL.  `python bench.py --gpus N` launches its own ranks
+(`python -m torch.distributed.run` as a CHILD process, started before this process has
+imported torch or touched the GPU) and relays rank 0's JSON line; started under
+torch.distributed.run (WORLD_SIZE set) it is a rank.  Default = weak scaling (256 per GPU);
+`--global-batch G` = strong scaling (G/N per GPU: BASELINE.json configs[3] = 512 with
+--variant MS, configs[4] = 1024 with --variant Full --D 2048).
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -28,8 +34,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md, f32-input MFMA
+MFMA_BF16_PEAK_TFLOPS = 2500.0 # dense bf16 MFMA
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md, HBM3E (about 6300 achievable)
-DOMINANT = "conv_embed_fwd"    # gemm_kernel<128,128,KC,RC_FLAT_MASK,CONV_TANH>
+# kernel classes that can be "the dominant kernel" (bulk MFMA GEMMs with FLOP and byte counts)
+BULK_CLASSES = ("conv_embed_fwd", "conv_embed_wgrad", "conv_att_pre", "conv_att_dgrad",
+                "conv_att_wgrad")
 
 
 def usable_cores():
@@ -77,12 +86,59 @@ def cpu_baseline(cfgd, budget_s=15.0):
                       f"(PyTorch-CPU fp32 restatement of the reference graph, {dt:.1f}s)"}
 
 
+def cpu_baseline_cxx(cfgd, budget_s=12.0):
+    """CPU-B: the C++ oracle (oracle/rau_cpu.cc, OpenMP, f32) on the same bounded
+    sample -- a sanity floor next to the PyTorch-CPU restatement, not a tuned baseline."""
+    import oracle
+    from rau_vqa_amd import synth
+    d = dict(cfgd)
+    d["B"] = 16
+    sh = oracle.Shapes(**d)
+    ne, nr, nm = oracle.group_sizes(sh)
+    batch = synth.make_batch(sh.B, sh.T, sh.V, sh.D, sh.S, sh.K, lens="full")
+    params = synth.make_params({"embed": ne, "rnn": nr, "mult": nm})
+    masks = synth.make_masks(oracle.mask_shapes(sh), {k: 0.5 for k in oracle.MASK_SITES})
+    cores = usable_cores()
+    os.environ["OMP_NUM_THREADS"] = str(cores)
+    t0 = time.time()
+    n = 0
+    while True:
+        oracle.step(sh, params, batch["feats"], batch["tokens"], batch["lens"], batch["labels"],
+                    masks, dtype=np.float32)
+        n += 1
+        if time.time() - t0 > budget_s or n >= 50:
+            break
+    dt = time.time() - t0
+    return {"value": sh.B * n / dt, "unit": "QA-pairs/s", "cores": cores, "kind": "port",
+            "sample": f"{n} fwd+bwd steps at batch {sh.B} (C++ oracle, OpenMP f32, {dt:.1f}s)"}
+
+
+def self_launch(args):
+    """--gpus N > 1 without a rendezvous in the environment: start the ranks as a child
+    torch.distributed.run (never an exec, and before anything here has touched the GPU),
+    relay its output, exit with its code."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+           f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run(cmd, env=env)
+    sys.exit(r.returncode)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=256, help="per-GPU batch")
+    ap.add_argument("--batch", type=int, default=256, help="per-GPU batch (weak scaling)")
+    ap.add_argument("--global-batch", type=int, default=0,
+                    help="strong scaling: total batch split evenly over the ranks "
+                         "(configs[3]: 512 --variant MS; configs[4]: 1024 --variant Full --D 2048)")
     ap.add_argument("--D", type=int, default=512)
     ap.add_argument("--dtype", choices=("f32", "bf16"), default="f32",
                     help="bf16 = BASELINE.json configs[2] mode (use with --D 2048): bf16-operand "
@@ -99,11 +155,14 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        self_launch(args)
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nnodes=1 "
-                             f"--nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...")
         raise SystemExit(f"--gpus {args.gpus} != WORLD_SIZE {world}")
+    if args.global_batch:
+        if args.global_batch % world:
+            raise SystemExit(f"--global-batch {args.global_batch} not divisible by {world} ranks")
+        args.batch = args.global_batch // world
 
     import torch  # before librau.so, so both share one HIP runtime
     import torch.distributed as dist
@@ -142,7 +201,9 @@ def main():
         reducer = (NativeGradAllReduce if os.environ.get("RAU_DP") == "native" else GradAllReduce)(m)
 
     def step(i):
-        m.set_dropout_seed(123, i)
+        # every rank draws its OWN dropout masks for its shard (the noise key of the update
+        # stays identical on all ranks: same update everywhere)
+        m.set_dropout_seed(123 + 7919 * rank, i)
         if args.graph and not m_prof[0]:
             m.graph_step(hop_w)
         else:
@@ -187,31 +248,45 @@ def main():
         prof = m.prof()
         m.prof_enable(False)
         m_prof[0] = False
-        dom = prof[DOMINANT]
+        # dominant kernel = the bulk-GEMM class with the most measured device time in THIS run
+        bulk = {k: prof[k] for k in BULK_CLASSES if k in prof and prof[k]["launches"]}
+        dom_name = max(bulk, key=lambda k: bulk[k]["ms"])
+        dom = bulk[dom_name]
         avg_ms = dom["ms"] / dom["launches"]
         flops_per_launch = dom["flops"] / dom["launches"]
-        achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12
-        # HBM bytes per launch of the dominant kernel from the committed PMC passes
-        # (profiles/r01_pmc_conv_embed_fwd.json: separate FETCH_SIZE / WRITE_SIZE runs,
-        # FETCH_SIZE doubled per the gfx950 correction); only valid for the default shape
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r01_pmc_conv_embed_fwd.json")
-        if os.path.exists(pmc) and args.batch == 256 and args.D == 512:
-            traffic = json.load(open(pmc))["hbm_bytes_per_launch"]
-        extra["roofline"] = {"bound": "mfma", "achieved": achieved, "peak": MFMA_F32_PEAK_TFLOPS,
-                             "unit": "TFLOP/s", "frac": achieved / MFMA_F32_PEAK_TFLOPS,
-                             "traffic": traffic, "kernel": DOMINANT,
-                             "avg_launch_ms": avg_ms,
-                             "flops_per_launch": flops_per_launch}
-        if args.dtype == "bf16":
-            # bf16 operands: the same kernel is HBM-bound; algorithmic bytes =
-            # read X' once + write I once per launch, both f32 in memory
-            gbs = dom["bytes"] / dom["launches"] / (avg_ms * 1e-3) / 1e9
+        bytes_per_launch = dom["bytes"] / dom["launches"]
+        tfl = flops_per_launch / (avg_ms * 1e-3) / 1e12
+        gbs = bytes_per_launch / (avg_ms * 1e-3) / 1e9
+        # HBM bytes per launch of that kernel: NOT measured by this run -- taken from the committed
+        # PMC passes of the same command (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs,
+        # FETCH_SIZE doubled per the gfx950 correction) when one exists for this kernel and shape
+        traffic, traffic_src = None, None
+        for rnd in ("r02", "r01"):
+            pmc = os.path.join(ROOT, "profiles", f"{rnd}_pmc_{dom_name}.json")
+            if os.path.exists(pmc) and (args.batch, args.D, args.dtype) == (256, 512, "f32"):
+                traffic = json.load(open(pmc))["hbm_bytes_per_launch"]
+                traffic_src = f"profiles/{rnd}_pmc_{dom_name}.json (separate rocprofv3 --pmc passes)"
+                break
+        mfma_peak = MFMA_F32_PEAK_TFLOPS if args.dtype == "f32" else MFMA_BF16_PEAK_TFLOPS
+        both = {"mfma_frac": tfl / mfma_peak, "hbm_frac": gbs / HBM_PEAK_GBS,
+                "mfma_tflops": tfl, "hbm_gbs_algorithmic": gbs}
+        if args.dtype == "f32":   # f32 MFMA-bound
+            extra["roofline"] = {"bound": "mfma", "achieved": tfl, "peak": mfma_peak,
+                                 "unit": "TFLOP/s", "frac": tfl / mfma_peak}
+        else:                     # bf16 operands: HBM-bound; algorithmic bytes = operands read
             extra["roofline"] = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS,
-                                 "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None,
-                                 "kernel": DOMINANT, "avg_launch_ms": avg_ms,
-                                 "bytes_per_launch": dom["bytes"] / dom["launches"],
-                                 "mfma_tflops": achieved}
+                                 "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS}
+        extra["roofline"].update({"traffic": traffic, "traffic_source": traffic_src,
+                                  "kernel": dom_name, "avg_launch_ms": avg_ms,
+                                  "launches_per_step": dom["launches"] / nprof,
+                                  "flops_per_launch": flops_per_launch,
+                                  "bytes_per_launch": bytes_per_launch, **both})
+        # the same two fractions for every bulk class (which one is "dominant" can flip by run)
+        extra["bulk_kernels"] = {
+            k: {"ms_per_step": round(v["ms"] / nprof, 4),
+                "mfma_frac": round(v["flops"] / (v["ms"] * 1e-3) / 1e12 / mfma_peak, 4),
+                "hbm_frac": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+            for k, v in bulk.items()}
         tot = sum(v["ms"] for v in prof.values())
         extra["kernel_classes_ms_per_step"] = {
             k: round(v["ms"] / nprof, 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}
@@ -242,6 +317,7 @@ def main():
         m.training()
         if world == 1 and not args.no_cpu_baseline:
             extra["cpu_baseline"] = cpu_baseline(cfgd)
+            extra["cpu_baseline_cxx"] = cpu_baseline_cxx(cfgd)
     elif world > 1:
         # keep ranks in lock-step with rank 0's extra (collective-carrying) steps
         for i in range(3):
@@ -260,26 +336,46 @@ def main():
         fence()
         m.training()
 
+    # global per-hop loss and train accuracy (SS:491-492, 518): per-rank sums reduced over the
+    # ranks (SURVEY 8e "also reduce"); host-side logging, outside the timed region
+    from rau_vqa_amd.dist import reduce_hop_stats
+    hop_loss, hop_acc = reduce_hop_stats(m.losses(), m.argmax(), batch["labels"])
+
     if rank == 0:
         qa = cfg.B * world * args.steps / dt
-        line = {"metric": "QA-pairs/sec fwd+bwd, Ours_SS 8-step RAU, batch 256, 14x14x512",
+        headline = (args.dtype, args.D, args.variant, cfg.B) == ("f32", 512, "SS", 256)
+        fmap = f"14x14x{cfg.D}"
+        metric = (f"QA-pairs/sec fwd+bwd, Ours_{args.variant} 8-step RAU, batch {cfg.B}"
+                  f"{' per GPU' if world > 1 else ''}, {fmap}")
+        if headline and world == 1:
+            metric = "QA-pairs/sec fwd+bwd, Ours_SS 8-step RAU, batch 256, 14x14x512"
+        cfgs = {("SS", 512, "f32"): "configs[1]", ("ResNet", 2048, "bf16"): "configs[2]",
+                ("MS", 512, "f32"): "configs[3]", ("Full", 2048, "f32"): "configs[4]",
+                ("Full", 2048, "bf16"): "configs[4] (bf16 operands)"}
+        line = {"metric": metric,
                 "value": qa, "unit": "QA-pairs/s", "n_gpus": world, "steps": args.steps,
                 "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-                "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-                "dtype": "f32" if args.dtype == "f32" else "bf16 conv-GEMM operands, f32 accumulate",
+                "higher_is_better": True, "scaling": "strong" if args.global_batch else "weak",
+                "vs_baseline": None,
+                "dtype": args.dtype,
                 "data": "synthetic",
-                "config": {"workload": "Ours_SS 8-step RAU fwd+bwd (configs[1])"
-                           if (args.dtype, args.D, args.variant) == ("f32", 512, "SS") else
-                           f"Ours_{args.variant} 8-step RAU fwd+bwd, D={args.D}, {args.dtype} (not the headline config)",
+                "config": {"workload": f"Ours_{args.variant} 8-step RAU fwd+bwd, {fmap}, "
+                                       f"{cfgs.get((args.variant, args.D, args.dtype), 'not a BASELINE config')}",
                            "batch_per_gpu": cfg.B, "global_batch": cfg.B * world, "T": cfg.T,
-                           "feature_map": f"14x14x{cfg.D}", "hops": cfg.H,
+                           "feature_map": fmap, "hops": cfg.H,
                            "parallelism": f"dp{world}",
+                           "collective": (f"{backend} all-reduce(avg) of 3 flat grad buckets, "
+                                          f"{world} ranks" if world > 1 else "none"),
                            "hop_weights": {"SS": "SS (x nHop)", "MS": "MS (x 1)"}.get(
                                args.variant, f"{args.variant} gating, epoch {args.epoch}"),
-                           "dropout": "train mode, Philox masks per step",
-                           "launch": "hipGraph replay" if args.graph else "eager, 3 streams"}}
+                           "arithmetic": "f32 operands, f32 MFMA accumulate" if args.dtype == "f32"
+                                         else "bf16-rounded conv-GEMM operands, f32 accumulate; rest f32",
+                           "dropout": "train mode, Philox masks per step and rank",
+                           "launch": "hipGraph replay" if args.graph else "eager, 3 streams"},
+                "hop_loss_global": [round(float(x), 5) for x in hop_loss],
+                "hop_train_acc_global": [round(float(x), 5) for x in hop_acc]}
         line.update(extra)
-        print(json.dumps(line))
+        print(json.dumps(line), flush=True)
     m.close()
     if world > 1:
         dist.destroy_process_group()

@@ -116,3 +116,24 @@ class NativeGradAllReduce:
 
     def __call__(self):
         self.rau.allreduce_grads()
+
+
+def reduce_hop_stats(losses, argmax, labels, group=None):
+    """Global per-hop loss and train accuracy from per-rank values (reference SS:491-492, 518:
+    the per-hop correct counts and criterion outputs feval logs).  `losses` [H] are means over
+    the LOCAL batch, `argmax` [H,B_local] 1-based answers, `labels` [B_local].  Sums of
+    (loss * B_local, correct, B_local) are all-reduced; returns (loss [H], accuracy [H]) over
+    the global batch.  Works without a process group (single rank)."""
+    import numpy as np
+    H, B = argmax.shape
+    v = np.concatenate([np.asarray(losses, np.float64) * B,
+                        (argmax == np.asarray(labels)[None, :]).sum(1).astype(np.float64),
+                        [float(B)]])
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        t = torch.from_numpy(v)
+        if dist.get_backend(group) == "nccl":
+            t = t.cuda()
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        v = t.cpu().numpy()
+    n = v[-1]
+    return v[:H] / n, v[H:2 * H] / n

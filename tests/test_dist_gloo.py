@@ -45,9 +45,11 @@ def _worker(rank, world, port, q):
     allreduce_average(ts)
     loss = torch.from_numpy(out["losses"].copy())
     allreduce_average([loss])
+    from rau_vqa_amd.dist import reduce_hop_stats
+    gl, ga = reduce_hop_stats(out["losses"], out["argmax"], local["labels"])
     if rank == 0:
         q.put({"g_mult": ts[0].numpy(), "g_rnn": ts[1].numpy(), "g_embed": ts[2].numpy(),
-               "losses": loss.numpy()})
+               "losses": loss.numpy(), "hop_loss": gl, "hop_acc": ga})
     dist.destroy_process_group()
 
 
@@ -71,3 +73,7 @@ def test_two_rank_average_equals_full_batch():
                       batch["labels"], None, dtype=np.float64)
     for k in ("g_mult", "g_rnn", "g_embed", "losses"):
         assert np.allclose(got[k], ref[k], rtol=1e-10, atol=1e-13), k
+    # per-hop loss sums and correct-counts reduced over the ranks (SS:491-492)
+    assert np.allclose(got["hop_loss"], ref["losses"], rtol=1e-10)
+    acc = (ref["argmax"] == batch["labels"][None, :]).mean(1)
+    assert np.allclose(got["hop_acc"], acc)

@@ -151,3 +151,29 @@ def test_bench_flow_with_two_ranks_over_gloo():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 64 and d["value"] > 0
     assert d["scaling"] == "weak" and "roofline" in d
+
+
+def test_bench_self_launch_strong_scaling_two_ranks():
+    """`python bench.py --gpus 2` with no rendezvous in the environment -- the form the driver
+    uses -- starts its own ranks as a child torch.distributed.run and relays rank 0's line.
+    Strong-scaling flavour: BASELINE.json configs[3] (Ours_MS weights, a GLOBAL batch split over
+    the ranks), plus the cross-rank per-hop loss / accuracy reduction."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env.update(RAU_DIST_BACKEND="gloo")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2",
+           "--warmup", "1", "--global-batch", "64", "--variant", "MS", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong"
+    assert d["config"]["global_batch"] == 64 and d["config"]["batch_per_gpu"] == 32
+    assert "2 ranks" in d["config"]["collective"]
+    assert len(d["hop_loss_global"]) == 8 and all(np.isfinite(d["hop_loss_global"]))
+    assert all(0.0 <= a <= 1.0 for a in d["hop_train_acc_global"])
+    for k in ("mfma_frac", "hbm_frac", "kernel", "traffic"):
+        assert k in d["roofline"]
