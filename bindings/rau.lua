@@ -63,6 +63,21 @@ int rau_criterion_forward(rau_ctx* ctx, int h, const float* logits, const int32_
                           float* loss);
 int rau_criterion_backward(rau_ctx* ctx, int h, const float* logits,
                            const int32_t* labels_dev, float scale, float** d_logits);
+int rau_dev_alloc(rau_ctx* ctx, size_t n_floats, float** out);
+int rau_dev_free(rau_ctx* ctx, float* p);
+int rau_dev_fill(rau_ctx* ctx, float* dst, size_t n, float value);
+int rau_dev_copy(rau_ctx* ctx, float* dst, const float* src, size_t n);
+int rau_dev_axpy(rau_ctx* ctx, float* y, const float* x, size_t n, float alpha);
+int rau_dev_scale(rau_ctx* ctx, float* x, size_t n, float alpha);
+int rau_dev_select_rows(rau_ctx* ctx, float* dst, const float* src, int32_t rows, int32_t cols,
+                        const int32_t* key_dev, int32_t value);
+int rau_dev_rowmax(rau_ctx* ctx, const float* x, int32_t rows, int32_t cols, float* max_dev,
+                   int32_t* argmax_dev);
+int rau_dev_sum(rau_ctx* ctx, const float* x, size_t n, double* out_host);
+int rau_dev_count_eq(rau_ctx* ctx, const int32_t* a_dev, const int32_t* b_dev, int32_t n,
+                     int32_t* count_host);
+int rau_dev_upload(rau_ctx* ctx, void* dst_dev, const void* host, size_t bytes);
+int rau_dev_download(rau_ctx* ctx, void* host, const void* src_dev, size_t bytes);
 int rau_graph_step(rau_ctx* ctx, const float* hop_w, int zero_grads_first);
 int rau_sync(rau_ctx* ctx);
 int rau_get_losses(rau_ctx* ctx, float* losses);
@@ -83,6 +98,11 @@ int rau_allreduce_grads(rau_ctx* ctx);
 int rau_comm_destroy(rau_ctx* ctx);
 int rau_timer_begin(rau_ctx* ctx);
 int rau_timer_end(rau_ctx* ctx, float* ms);
+int rau_prof_enable(rau_ctx* ctx, int on);
+int rau_prof_reset(rau_ctx* ctx);
+int rau_prof_count(rau_ctx* ctx);
+int rau_prof_entry(rau_ctx* ctx, int index, const char** name, int64_t* launches,
+                   double* total_ms, double* flops, double* bytes);
 ]]
 
 local C = ffi.load(os.getenv('RAU_LIB') or 'librau.so')
@@ -172,63 +192,194 @@ end
 function RAU:commInit(nranks, rank, id) check(C.rau_comm_init(self.h, nranks, rank, id, #id)) end
 function RAU:allreduceGrads() check(C.rau_allreduce_grads(self.h)) end
 
+-- Device tensors ---------------------------------------------------------------
+-- What feval's loops do BETWEEN module calls (`rnn_out[k] = lst[k]`, `uni_pred:add(pred[1])`,
+-- `torch.max(pred[1], 2)`, `ans:eq(y):sum()`, SS:455-461, 482-492, 522-526, 584-591) needs
+-- tensor-shaped values.  cutorch does not exist on an MI355X host, so the clones below return
+-- RAU.Tensor objects: {ptr = device float*, size = {rows, cols}, rau = owner}, dense row-major,
+-- with the handful of methods those loops use, each one small C-ABI call (rau_dev_*).
+-- Views of ctx-owned slots keep nn.Module's self.output lifetime; RAU.Tensor.new allocates.
+local Tensor = {}
+local IntTensor = {}
+local function numel(sz) local n = 1; for _, v in ipairs(sz) do n = n * v end; return n end
+local function ptr_of(x) if type(x) == 'table' then return x.ptr end; return x end
+
+Tensor.__index = function(t, k)
+  if type(k) == 'number' then return Tensor.row(t, k) end     -- t[k]: 1-based row view
+  return Tensor[k]
+end
+Tensor.__newindex = function(t, k, v)
+  if type(k) == 'number' then Tensor.row(t, k):copy(v) else rawset(t, k, v) end   -- t[k] = row
+end
+function Tensor.wrap(rau, ptr, ...)
+  return setmetatable({ rau = rau, ptr = ptr, size = { ... } }, Tensor)
+end
+function Tensor.new(rau, ...)                                  -- zero-filled, like torch.zeros
+  local sz = { ... }
+  local p = ffi.new('float*[1]')
+  check(C.rau_dev_alloc(rau.h, numel(sz), p))
+  return setmetatable({ rau = rau, ptr = p[0], size = sz, owned = true }, Tensor)
+end
+function Tensor:nElement() return numel(self.size) end
+function Tensor:dim() return #self.size end
+function Tensor:row(k)                                         -- 1-based, view
+  local cols = numel(self.size) / self.size[1]
+  assert(k >= 1 and k <= self.size[1], 'row index out of range')
+  return Tensor.wrap(self.rau, self.ptr + (k - 1) * cols, cols)
+end
+function Tensor:zero() check(C.rau_dev_fill(self.rau.h, self.ptr, self:nElement(), 0)); return self end
+function Tensor:fill(v) check(C.rau_dev_fill(self.rau.h, self.ptr, self:nElement(), v)); return self end
+function Tensor:copy(src)                                      -- device tensor or host FloatTensor
+  if getmetatable(src) == Tensor then
+    assert(src:nElement() == self:nElement(), 'size mismatch')
+    check(C.rau_dev_copy(self.rau.h, self.ptr, src.ptr, self:nElement()))
+  else
+    check(C.rau_dev_upload(self.rau.h, self.ptr, src:data(), self:nElement() * 4))
+  end
+  return self
+end
+function Tensor:clone() return Tensor.new(self.rau, unpack(self.size)):copy(self) end
+function Tensor:add(a, x)                                      -- :add(x) or :add(alpha, x)
+  if x == nil then a, x = 1, a end
+  assert(x:nElement() == self:nElement(), 'size mismatch')
+  check(C.rau_dev_axpy(self.rau.h, self.ptr, x.ptr, self:nElement(), a)); return self
+end
+function Tensor:mul(a) check(C.rau_dev_scale(self.rau.h, self.ptr, self:nElement(), a)); return self end
+function Tensor:div(a) return self:mul(1 / a) end
+function Tensor:sum()
+  local o = ffi.new('double[1]')
+  check(C.rau_dev_sum(self.rau.h, self.ptr, self:nElement(), o)); return o[0]
+end
+function Tensor:mean() return self:sum() / self:nElement() end
+-- torch.max(t, 2): values [rows,1] and 1-based first-max indices [rows,1] (SS:488)
+function Tensor:max(dim)
+  assert(dim == 2 and #self.size == 2, 'only max over dimension 2 of a matrix')
+  local r, c = self.size[1], self.size[2]
+  local v = Tensor.new(self.rau, r, 1)
+  local i = IntTensor.new(self.rau, r, 1)
+  check(C.rau_dev_rowmax(self.rau.h, self.ptr, r, c, v.ptr, i.ptr))
+  return v, i
+end
+-- dst rows k with key[k] == value take src's rows: the whole `for k=1,B do if x_len[k]==t ...`
+-- loop of SS:455-461 / SS:584-591 as one call (key: device IntTensor)
+function Tensor:selectRows(src, key, value)
+  local r = self.size[1]
+  check(C.rau_dev_select_rows(self.rau.h, self.ptr, src.ptr, r, self:nElement() / r, key.ptr, value))
+  return self
+end
+function Tensor:float()                                        -- host copy (torch.FloatTensor)
+  local t = torch.FloatTensor(unpack(self.size))
+  check(C.rau_dev_download(self.rau.h, t:data(), self.ptr, self:nElement() * 4)); return t
+end
+function Tensor:free() if self.owned then check(C.rau_dev_free(self.rau.h, self.ptr)); self.owned = false end end
+
+IntTensor.__index = IntTensor
+function IntTensor.new(rau, ...)
+  local sz = { ... }
+  local p = ffi.new('float*[1]')
+  check(C.rau_dev_alloc(rau.h, numel(sz), p))                  -- 4-byte elements either way
+  return setmetatable({ rau = rau, ptr = ffi.cast('int32_t*', p[0]), size = sz }, IntTensor)
+end
+function IntTensor:copy(src)                                   -- host IntTensor -> device
+  check(C.rau_dev_upload(self.rau.h, self.ptr, src:data(), numel(self.size) * 4)); return self
+end
+function IntTensor:int()
+  local t = torch.IntTensor(unpack(self.size))
+  check(C.rau_dev_download(self.rau.h, t:data(), self.ptr, numel(self.size) * 4)); return t
+end
+-- ans:eq(y):sum() in one call (SS:489-492)
+function IntTensor:eqSum(other)
+  local o = ffi.new('int32_t[1]')
+  check(C.rau_dev_count_eq(self.rau.h, self.ptr, other.ptr, numel(self.size), o)); return o[0]
+end
+RAU.Tensor, RAU.IntTensor = Tensor, IntTensor
+function RAU:zeros(...) return Tensor.new(self, ...) end       -- torch.zeros(...):cuda()
+function RAU:ints(host) return IntTensor.new(self, host:nElement()):copy(host) end
+
+-- nn.Module surface completeness: parameters live on the device from the start and the clones
+-- share them by construction, so these are identities (SS:319, 340-346); updateParameters is
+-- never called by the reference (updates go through adam on the flat vectors, SS:770-772) and
+-- maps to plain SGD on the fused update for hosts that do call it.
+function RAU:cuda() return self end
+function RAU:clone() return self end
+function RAU:float() return self end
+function RAU:updateParameters(lr) self:update(0, lr, lr, 0, 0.55, 1e30, 0) end
+-- flat parameter / gradient vectors as device tensors: params, grads = rau:flat('mult')
+function RAU:flat(group)
+  local p = self:getParameters(group)
+  return Tensor.wrap(self, p.ptr, p.n), Tensor.wrap(self, p.grad, p.n)
+end
+
 -- Module-level clones ---------------------------------------------------------
--- For scripts that keep feval's own loops (SS:443-596).  Arguments and results are
--- device float* / int32_t* (cdata); a result points into a ctx-owned slot that stays
+-- For scripts that keep feval's own loops (SS:443-596).  Arguments are RAU.Tensor / RAU.IntTensor
+-- objects (or raw device cdata pointers); results are RAU.Tensor VIEWS of ctx-owned slots that stay
 -- valid until the same clone runs again (the lifetime of nn.Module's self.output).
 -- Indices are 1-based like embed_clones[t] / lstm_clones[t] / multimodal_clones[h].
 local function clone(self, kind, i)
   local m = { rau = self, i = i - 1 }
+  local cfg, Q = self.cfg, 4 * self.cfg.Rq
   if kind == 'embed' then
     function m:forward(x_t)
       local o = ffi.new('float*[1]')
-      check(C.rau_embed_forward(self.rau.h, self.i, x_t, o)); self.output = o[0]
+      check(C.rau_embed_forward(self.rau.h, self.i, ptr_of(x_t), o))
+      self.output = Tensor.wrap(self.rau, o[0], cfg.B, cfg.E)
       return self.output
     end
-    function m:backward(x_t, d_we) check(C.rau_embed_backward(self.rau.h, self.i, x_t, d_we)) end
+    function m:backward(x_t, d_we) check(C.rau_embed_backward(self.rau.h, self.i, ptr_of(x_t), ptr_of(d_we))) end
   elseif kind == 'rnn' then
     function m:forward(inp)   -- {x, state}
       local o = ffi.new('float*[1]')
-      check(C.rau_deeplstm_forward(self.rau.h, self.i, inp[1], inp[2], o)); self.output = o[0]
+      check(C.rau_deeplstm_forward(self.rau.h, self.i, ptr_of(inp[1]), ptr_of(inp[2]), o))
+      self.output = Tensor.wrap(self.rau, o[0], cfg.B, Q)
       return self.output
     end
     function m:backward(inp, d_state_out)
       local dx, ds = ffi.new('float*[1]'), ffi.new('float*[1]')
-      check(C.rau_deeplstm_backward(self.rau.h, self.i, inp[1], inp[2], d_state_out, dx, ds))
-      self.gradInput = { dx[0], ds[0] }
+      check(C.rau_deeplstm_backward(self.rau.h, self.i, ptr_of(inp[1]), ptr_of(inp[2]),
+                                    ptr_of(d_state_out), dx, ds))
+      self.gradInput = { Tensor.wrap(self.rau, dx[0], cfg.B, cfg.E), Tensor.wrap(self.rau, ds[0], cfg.B, Q) }
       return self.gradInput
     end
   elseif kind == 'multimodal' then
     function m:forward(inp)   -- {q, X, c, h}
       local o = {}
       for k = 1, 5 do o[k] = ffi.new('float*[1]') end
-      check(C.rau_multimodal_forward(self.rau.h, self.i, inp[1], inp[2], inp[3], inp[4],
-                                     o[1], o[2], o[3], o[4], o[5]))
-      self.output = { o[1][0], o[2][0], o[3][0], o[4][0], o[5][0] }  -- {logits, dp, a, c, h}
+      check(C.rau_multimodal_forward(self.rau.h, self.i, ptr_of(inp[1]), ptr_of(inp[2]),
+                                     ptr_of(inp[3]), ptr_of(inp[4]), o[1], o[2], o[3], o[4], o[5]))
+      local r = self.rau                                             -- {logits, dp, a, c, h}
+      self.output = { Tensor.wrap(r, o[1][0], cfg.B, cfg.K), Tensor.wrap(r, o[2][0], cfg.B),
+                      Tensor.wrap(r, o[3][0], cfg.B, cfg.S), Tensor.wrap(r, o[4][0], cfg.B, cfg.R),
+                      Tensor.wrap(r, o[5][0], cfg.B, cfg.R) }
       return self.output
     end
     function m:backward(inp, g)   -- g = {d_logits, d_do_pred|nil, d_attprob|nil, d_c, d_h}
       local o = {}
       for k = 1, 4 do o[k] = ffi.new('float*[1]') end
-      check(C.rau_multimodal_backward(self.rau.h, self.i, inp[1], inp[2], inp[3], inp[4],
-                                      g[1], g[2], g[3], g[4], g[5], o[1], nil, o[3], o[4]))
-      self.gradInput = { o[1][0], nil, o[3][0], o[4][0] }   -- {d_q, (d_X dead, SS:579), d_c, d_h}
+      check(C.rau_multimodal_backward(self.rau.h, self.i, ptr_of(inp[1]), ptr_of(inp[2]),
+                                      ptr_of(inp[3]), ptr_of(inp[4]), ptr_of(g[1]), ptr_of(g[2]),
+                                      ptr_of(g[3]), ptr_of(g[4]), ptr_of(g[5]), o[1], nil, o[3], o[4]))
+      local r = self.rau                                    -- {d_q, (d_X dead, SS:579), d_c, d_h}
+      self.gradInput = { Tensor.wrap(r, o[1][0], cfg.B, Q), nil, Tensor.wrap(r, o[3][0], cfg.B, cfg.R),
+                         Tensor.wrap(r, o[4][0], cfg.B, cfg.R) }
       return self.gradInput
     end
   elseif kind == 'criterion' then
     function m:forward(logits, y)
       local l = ffi.new('float[1]')
-      check(C.rau_criterion_forward(self.rau.h, self.i, logits, y, l))
+      check(C.rau_criterion_forward(self.rau.h, self.i, ptr_of(logits), ptr_of(y), l))
       return l[0]
     end
     function m:backward(logits, y, scale)
       local o = ffi.new('float*[1]')
-      check(C.rau_criterion_backward(self.rau.h, self.i, logits, y, scale or 1, o))
-      return o[0]
+      check(C.rau_criterion_backward(self.rau.h, self.i, ptr_of(logits), ptr_of(y), scale or 1, o))
+      return Tensor.wrap(self.rau, o[0], cfg.B, cfg.K)
     end
   end
   function m:training() self.rau:training() end
   function m:evaluate() self.rau:evaluate() end
+  function m:cuda() return self end
+  function m:clone() return self end                 -- clones share parameters by construction
+  function m:getParameters() return self.rau:flat(kind == 'embed' and 'embed' or kind == 'rnn' and 'rnn' or 'mult') end
   return m
 end
 function RAU:embedClone(t) return clone(self, 'embed', t) end

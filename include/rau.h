@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define RAU_ABI_VERSION 2
+#define RAU_ABI_VERSION 3
 
 typedef enum rau_status {
   RAU_OK = 0,
@@ -84,13 +84,14 @@ typedef struct rau_config {
   int32_t Rq;   /* rnn_size = 512, SS:209 (nrnn_layer fixed at 2, SS:210) */
   int32_t D;    /* cnnout_dim 512 | 2048, SS:216 */
   int32_t S;    /* cnnout_w*cnnout_h = 196 (14x14) or 49 (7x7, the scripts' default), SS:219;
-                 * not a multiple of 4: padded internally, module-level calls unavailable */
+                 * not a multiple of 4: padded internally (callers always see dense [.., S]) */
   int32_t M;    /* multfeat_dim = 512, SS:220 */
   int32_t A;    /* attfeat_dim = 256, SS:221 */
   int32_t R;    /* att_rnn_size = 512, SS:225 (1 layer, dropout 0) */
   int32_t K;    /* answer_size = 1000, SS:222 */
   int32_t H;    /* nHop */
-  float p_we, p_rnn, p_q, p_x, p_mf;  /* dropout probabilities, 0.5 each */
+  float p_we, p_rnn, p_q, p_x, p_mf;  /* dropout probabilities, 0.5 each (device masks resolve p to
+                                       * 1/256; the 1/(1-p) scale uses the same quantised p) */
   int32_t dtype;      /* rau_dtype */
   int32_t device_id;  /* HIP device ordinal (opt.gpuid) */
 } rau_config;
@@ -213,6 +214,33 @@ int rau_criterion_forward(rau_ctx* ctx, int h, const float* logits, const int32_
                           float* loss);
 int rau_criterion_backward(rau_ctx* ctx, int h, const float* logits,
                            const int32_t* labels_dev, float scale, float** d_logits);
+
+/* ---- device tensors: the tensor algebra feval does BETWEEN module calls ----------------------
+ * The reference's loops copy state rows where x_len[k] == t (`rnn_out[k] = lst[k]`, SS:455-461;
+ * the dq row replacement, SS:584-591), accumulate (`uni_pred:add(pred[1])`, SS:522-526), take
+ * `torch.max(pred[1], 2)` and `ans:eq(y):sum()` (SS:488-492) and zero-fill state tensors
+ * (SS:357-413) -- on the reference's CUDA box through cutorch.  An MI355X host has no cutorch, so
+ * those few operations are exported on plain device pointers (dense row-major float / int32),
+ * enqueued on the ctx stream.  rau_dev_alloc'ed memory is zero-filled and owned by the ctx (freed
+ * by rau_destroy, or earlier by rau_dev_free).  rau_dev_sum / _count_eq / _upload / _download
+ * synchronise; the others do not. */
+int rau_dev_alloc(rau_ctx* ctx, size_t n_floats, float** out);
+int rau_dev_free(rau_ctx* ctx, float* p);
+int rau_dev_fill(rau_ctx* ctx, float* dst, size_t n, float value);
+int rau_dev_copy(rau_ctx* ctx, float* dst, const float* src, size_t n);
+int rau_dev_axpy(rau_ctx* ctx, float* y, const float* x, size_t n, float alpha);   /* y += alpha x */
+int rau_dev_scale(rau_ctx* ctx, float* x, size_t n, float alpha);
+/* dst[k,:] = src[k,:] for the rows k with key_dev[k] == value (SS:455-461, 584-591) */
+int rau_dev_select_rows(rau_ctx* ctx, float* dst, const float* src, int32_t rows, int32_t cols,
+                        const int32_t* key_dev, int32_t value);
+/* torch.max(x, 2): per-row maximum and FIRST maximal index, 1-based (either output may be NULL) */
+int rau_dev_rowmax(rau_ctx* ctx, const float* x, int32_t rows, int32_t cols, float* max_dev,
+                   int32_t* argmax_dev);
+int rau_dev_sum(rau_ctx* ctx, const float* x, size_t n, double* out_host);
+int rau_dev_count_eq(rau_ctx* ctx, const int32_t* a_dev, const int32_t* b_dev, int32_t n,
+                     int32_t* count_host);
+int rau_dev_upload(rau_ctx* ctx, void* dst_dev, const void* host, size_t bytes);
+int rau_dev_download(rau_ctx* ctx, void* host, const void* src_dev, size_t bytes);
 
 /* rau_zero_grads (optional) + rau_forward + rau_backward as ONE hipGraph launch: the three
  * streams, their fork/join events and all kernel arguments are captured once per step shape

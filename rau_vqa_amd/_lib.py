@@ -85,6 +85,22 @@ _SIGS = {
                                         C.POINTER(C.c_float)]),
     "rau_criterion_backward": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_float,
                                          C.POINTER(C.c_void_p)]),
+    # device tensors (the tensor algebra feval does between module calls)
+    "rau_dev_alloc": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
+    "rau_dev_free": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "rau_dev_fill": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_float]),
+    "rau_dev_copy": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "rau_dev_axpy": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_float]),
+    "rau_dev_scale": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_float]),
+    "rau_dev_select_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
+                                      C.c_void_p, C.c_int32]),
+    "rau_dev_rowmax": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p,
+                                 C.c_void_p]),
+    "rau_dev_sum": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_double)]),
+    "rau_dev_count_eq": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
+                                   C.POINTER(C.c_int32)]),
+    "rau_dev_upload": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "rau_dev_download": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "rau_graph_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     "rau_sync": (C.c_int, [C.c_void_p]),
     "rau_get_losses": (C.c_int, [C.c_void_p, C.c_void_p]),

@@ -314,8 +314,11 @@ enum Epi : int {
   EPI_OUTER = 3      // C = acc + dj[b,m] a[n]   (dI' of the attention backward)
 };
 
+// One workgroup's tile; (bx, by, bz) = (tile id, batch problem, K split) -- blockIdx in the plain
+// launch, a table lookup in the grouped launch (gemm_group_kernel).
 template <int BM, int BN, int BKT, int ASRC, int BSRC, int EPI, int DT = 0 /* 1: bf16 operands */>
-__global__ __launch_bounds__(256, DT ? 3 : 2) void gemm_kernel(const GemmParams P) {
+__device__ __forceinline__ void gemm_tile(const GemmParams& P, const int bx, const int by,
+                                          const int bz) {
   constexpr int BK = BKT;
   static_assert(DT == 0 || (BM == 128 && BN == 128 && BKT == 32), "bf16 mode: 128x128x32 tiles");
   // long-reduction kernels (conv weight gradients) only: measured +9% there, 0 on the short-K convs
@@ -347,28 +350,28 @@ __global__ __launch_bounds__(256, DT ? 3 : 2) void gemm_kernel(const GemmParams 
   const int wm = w & 1, wn = w >> 1;
 
   const int nwg = P.tiles_m * P.tiles_n;
-  const int id = xcd_remap(blockIdx.x, nwg);
+  const int id = xcd_remap(bx, nwg);
   const int tm = id % P.tiles_m, tn = id / P.tiles_m;
   const int m0 = tm * BM, n0 = tn * BN;
 
-  const int step0 = blockIdx.z * P.nk_per_split;
+  const int step0 = bz * P.nk_per_split;
   int nsteps = P.nk - step0;
   if (nsteps > P.nk_per_split) nsteps = P.nk_per_split;
 
   int PN = P.N;                 // this problem's output width / row pitch / slab placement
   long Pcrs = P.c_rs, Pslab_stride = P.slab_stride;
-  long Cbatch = P.nbatch ? (long)blockIdx.y * P.slab_batch_stride : 0;
+  long Cbatch = P.nbatch ? (long)by * P.slab_batch_stride : 0;
   if (P.nbatch && P.Nb[0]) {
-    PN = P.Nb[blockIdx.y];
+    PN = P.Nb[by];
     Pcrs = PN;
     Pslab_stride = (long)P.M * PN;
-    Cbatch = P.slab_off[blockIdx.y];
+    Cbatch = P.slab_off[by];
     if (n0 >= PN) return;       // tile column beyond this (narrower) problem: whole workgroup
   }
   typename LoaderOf<BM, BKT, ASRC, DT != 0>::type LA;
   typename LoaderOf<BN, BKT, BSRC, DT != 0>::type LB;
-  const float* Abase = P.nbatch ? P.Ab[blockIdx.y] : P.A;
-  const float* Bbase = P.nbatch ? P.Bb[blockIdx.y] : P.B;
+  const float* Abase = P.nbatch ? P.Ab[by] : P.A;
+  const float* Bbase = P.nbatch ? P.Bb[by] : P.B;
   LA.init(P, Abase, P.a_rs, P.a_bs, m0, P.M, tid);
   LB.init(P, Bbase, P.b_rs, P.b_bs, n0, PN, tid);
 
@@ -502,7 +505,7 @@ __global__ __launch_bounds__(256, DT ? 3 : 2) void gemm_kernel(const GemmParams 
         v += __shfl_xor(v, 2, 64);
         v += __shfl_xor(v, 4, 64);
         const int m = m0 + tid / 8 + i * 32;
-        if ((tid & 7) == 0 && m < P.M) P.rs_out[(long)blockIdx.z * P.M + m] = v;
+        if ((tid & 7) == 0 && m < P.M) P.rs_out[(long)bz * P.M + m] = v;
       }
     }
   }
@@ -523,7 +526,7 @@ __global__ __launch_bounds__(256, DT ? 3 : 2) void gemm_kernel(const GemmParams 
           v.x += w4.x; v.y += w4.y; v.z += w4.z; v.w += w4.w;
         }
         const int m = m0 + tid * 4;
-        float* o = P.rs_out + (long)blockIdx.z * P.M + m;
+        float* o = P.rs_out + (long)bz * P.M + m;
         if (m + 3 < P.M) {
           o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
         } else {
@@ -541,7 +544,7 @@ __global__ __launch_bounds__(256, DT ? 3 : 2) void gemm_kernel(const GemmParams 
   const int cloc = wn * WN + (l & 31);       // column of j=0 inside the tile
 
   if (EPI == EPI_LIN || EPI == EPI_SLAB) {
-    float* C = P.C + (EPI == EPI_SLAB ? (long)blockIdx.z * Pslab_stride + Cbatch : 0);
+    float* C = P.C + (EPI == EPI_SLAB ? (long)bz * Pslab_stride + Cbatch : 0);
 #pragma unroll
     for (int j = 0; j < JN; ++j) {
       const int n = n0 + cloc + j * 32;
@@ -624,6 +627,45 @@ __global__ __launch_bounds__(256, DT ? 3 : 2) void gemm_kernel(const GemmParams 
         }
     }
   }
+}
+
+template <int BM, int BN, int BKT, int ASRC, int BSRC, int EPI, int DT = 0>
+__global__ __launch_bounds__(256, DT ? 3 : 2) void gemm_kernel(const GemmParams P) {
+  gemm_tile<BM, BN, BKT, ASRC, BSRC, EPI, DT>(P, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// Grouped launch: up to kGroupMax independent split-K problems C_p = A_p^T B_p (the Linear weight
+// gradients of one parameter group) in ONE grid.  Workgroup g belongs to problem p with
+// wg0[p] <= g < wg0[p+1]; inside it, tile = (g - wg0[p]) % tiles, split = (g - wg0[p]) / tiles.
+constexpr int kGroupMax = 13;
+struct GroupProb {
+  const float* A; const float* B; float* slab; float* rs_out;
+  long lda, ldb;
+  int M, N, tiles_m, tiles_n;
+};
+struct GroupParams {
+  int np, K, nk, nk_per_split;
+  int wg0[kGroupMax + 1];
+  GroupProb p[kGroupMax];
+};
+template <int BM, int BN, int BKT, int ASRC, int BSRC>
+__global__ __launch_bounds__(256, 2) void gemm_group_kernel(const GroupParams G) {
+  int pi = 0;
+#pragma unroll 1
+  while (pi + 1 < G.np && (int)blockIdx.x >= G.wg0[pi + 1]) ++pi;
+  const GroupProb& q = G.p[pi];
+  const int local = (int)blockIdx.x - G.wg0[pi];
+  const int tiles = q.tiles_m * q.tiles_n;
+  GemmParams P{};
+  P.M = q.M; P.N = q.N; P.K = G.K;
+  P.nk = G.nk; P.nk_per_split = G.nk_per_split;
+  P.tiles_m = q.tiles_m; P.tiles_n = q.tiles_n;
+  P.A = q.A; P.a_rs = q.lda;
+  P.B = q.B; P.b_rs = q.ldb;
+  P.C = q.slab; P.c_rs = q.N; P.slab_stride = (long)q.M * q.N;
+  P.rs_out = q.rs_out;
+  P.alpha = 1.f;
+  gemm_tile<BM, BN, BKT, ASRC, BSRC, EPI_SLAB, 0>(P, local % tiles, 0, local / tiles);
 }
 
 // ------------------------------------------------------------ host launch

@@ -1,6 +1,7 @@
 // gemm_lin.hip -- Linear-layer GEMMs on the f32-MFMA engine (gemm_core.h):
 // forward y = x W^T (gemm_nt), input gradient dx = dy W (gemm_nn) and the
 // deterministic split-K weight gradient dW += dy^T x (gemm_tn_acc).
+#include <algorithm>
 #include <cstdlib>
 
 #include "gemm_core.h"
@@ -207,6 +208,105 @@ hipError_t gemm_tn_acc(hipStream_t st, int M, int N, int K, const float* A, long
   }
   if (e != hipSuccess || !dbias) return e;
   return splitk_reduce_acc(st, (size_t)M, s, rs, (size_t)M, dbias);
+}
+
+// ---- grouped Linear weight gradients: dW_p += dY_p^T X_p (and db_p += column sums of dY_p) for
+// all the Linears of a parameter group in ONE GEMM launch + ONE reduction launch.  Every problem
+// shares the reduction length K (rows = hops x batch, or tokens x batch).  The K split is chosen
+// for long K loops (>= 16 steps per workgroup) rather than for workgroup count: these launches
+// run underneath the bulk conv GEMMs and the recurrence, so what counts is how little of the
+// machine they take, not their own latency.
+static int group_splits(const TnProblem* pr, int np, int K) {
+  int tiles = 0;
+  for (int i = 0; i < np; ++i) tiles += ((pr[i].M + 127) / 128) * ((pr[i].N + 127) / 128);
+  const int nk = (K + BK - 1) / BK;
+  static const int target = [] {
+    const char* e = std::getenv("RAU_GROUP_WGS");
+    const int v = e ? std::atoi(e) : 0;
+    return v > 0 ? v : 640;
+  }();
+  int s = (target + tiles / 2) / (tiles > 0 ? tiles : 1);
+  if (s > nk / 16) s = nk / 16;
+  if (s < 1) s = 1;
+  const int per = (nk + s - 1) / s;
+  return (nk + per - 1) / per;
+}
+size_t gemm_tn_group_slab_floats(const TnProblem* pr, int np, int K) {
+  const int s = group_splits(pr, np, K);
+  size_t n = 0;
+  for (int i = 0; i < np; ++i) n += (size_t)s * ((size_t)pr[i].M * pr[i].N + pr[i].M);
+  return n;
+}
+
+struct GroupReduce {
+  int np, splits;
+  long e0[kGroupMax + 1];        // prefix sums of M*N
+  long b0[kGroupMax + 1];        // prefix sums of M (bias gradients)
+  const float* slab[kGroupMax]; const float* rs[kGroupMax];
+  float* dst[kGroupMax]; float* db[kGroupMax];
+  long mn[kGroupMax]; int m[kGroupMax];
+};
+__global__ void k_group_reduce_acc(const GroupReduce R) {
+  const long nW = R.e0[R.np], nB = R.b0[R.np];
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < nW + nB;
+       i += (long)gridDim.x * blockDim.x) {
+    const bool bias = i >= nW;
+    const long j = bias ? i - nW : i;
+    const long* pre = bias ? R.b0 : R.e0;
+    int p = 0;
+    while (p + 1 < R.np && j >= pre[p + 1]) ++p;
+    const long k = j - pre[p];
+    if (bias) {
+      if (!R.db[p]) continue;
+      float v = R.db[p][k];
+      for (int s = 0; s < R.splits; ++s) v += R.rs[p][(long)s * R.m[p] + k];
+      R.db[p][k] = v;
+    } else {
+      float v = R.dst[p][k];
+      for (int s = 0; s < R.splits; ++s) v += R.slab[p][(long)s * R.mn[p] + k];
+      R.dst[p][k] = v;
+    }
+  }
+}
+
+hipError_t gemm_tn_group_acc(hipStream_t st, const TnProblem* pr, int np, int K, float* slab,
+                             size_t slab_floats) {
+  if (np < 1 || np > kGroupMax) return hipErrorInvalidValue;
+  if (gemm_tn_group_slab_floats(pr, np, K) > slab_floats) return hipErrorInvalidValue;
+  const int s = group_splits(pr, np, K);
+  GroupParams G{};
+  GroupReduce R{};
+  G.np = np; G.K = K;
+  G.nk = (K + BK - 1) / BK;
+  G.nk_per_split = (G.nk + s - 1) / s;
+  R.np = np; R.splits = s;
+  float* w = slab;
+  int wg = 0;
+  for (int i = 0; i < np; ++i) {
+    GroupProb& q = G.p[i];
+    q.A = pr[i].A; q.lda = pr[i].lda; q.B = pr[i].B; q.ldb = pr[i].ldb;
+    q.M = pr[i].M; q.N = pr[i].N;
+    q.tiles_m = (q.M + 127) / 128; q.tiles_n = (q.N + 127) / 128;
+    q.slab = w;
+    w += (size_t)s * q.M * q.N;
+    q.rs_out = w;
+    w += (size_t)s * q.M;
+    G.wg0[i] = wg;
+    wg += q.tiles_m * q.tiles_n * s;
+    R.slab[i] = q.slab; R.rs[i] = q.rs_out; R.dst[i] = pr[i].C; R.db[i] = pr[i].dbias;
+    R.mn[i] = (long)q.M * q.N; R.m[i] = q.M;
+    R.e0[i + 1] = R.e0[i] + R.mn[i];
+    R.b0[i + 1] = R.b0[i] + q.M;
+  }
+  G.wg0[np] = wg;
+  hipLaunchKernelGGL((gemm_group_kernel<128, 128, BK, SRC_RC_SUM, SRC_RC>), dim3(wg), dim3(256), 0,
+                     st, G);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  const long n = R.e0[np] + R.b0[np];
+  const int blocks = (int)std::min<long>((n + 255) / 256, 2048);
+  hipLaunchKernelGGL(k_group_reduce_acc, dim3(blocks), dim3(256), 0, st, R);
+  return hipGetLastError();
 }
 
 }  // namespace rau

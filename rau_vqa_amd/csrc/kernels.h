@@ -57,6 +57,15 @@ hipError_t gemm_tn_acc(hipStream_t st, int M, int N, int K, const float* A, long
                        const float* B, long ldb, float* C, long ldc, float* slab,
                        float* dbias = nullptr);
 
+// All the Linear weight gradients of a parameter group as ONE grouped launch (+ one reduction):
+// C_p[M_p,N_p] += A_p[K,M_p]^T B_p[K,N_p], dbias_p[m] += sum_k A_p[k,m]; C_p dense (ldc = N_p).
+struct TnProblem {
+  int M, N; const float* A; long lda; const float* B; long ldb; float* C; float* dbias;
+};
+size_t gemm_tn_group_slab_floats(const TnProblem* pr, int np, int K);
+hipError_t gemm_tn_group_acc(hipStream_t st, const TnProblem* pr, int np, int K, float* slab,
+                             size_t slab_floats);
+
 // ----------------------------------------------------------- conv GEMMs (gemm_conv.hip)
 // I[b,m,s] = tanh(sum_d Wi[m,d] * X'[b,d,s] + bi[m])   (reference SS:238-242; X' is the
 // feature map with dropout already applied, see dropout_features; nB may be H*B)
@@ -124,6 +133,20 @@ struct LstmFwdCell {
 };
 struct LstmFwdCells { int n; LstmFwdCell c[2]; };
 hipError_t lstm_fwd_multi(hipStream_t st, int order, int nB, int R, const LstmFwdCells& cells);
+// One LSTM cell step as ONE launch (lstm_fused.hip): recurrent gate GEMM on f32 MFMA with the
+// cell's pointwise half as its epilogue.  Up to two independent cells per launch (the encoder's
+// layer wavefront).  Per cell: pre-activation = `pre` rows [B,4R] (or b1 + b2 when pre is null)
+// + sum over nsrc (0..2) sources of A_k [B,K_k] W_k[4R,K_k]^T; gates is written in place of pre
+// when they are the same buffer.
+struct LstmStepSide {
+  int nsrc; int K[2];
+  const float* A[2]; const float* W[2];
+  const float* pre; const float* b1; const float* b2;
+  float* gates; const float* c_prev; float* c; float* h; float* tanhc;
+  float* drop_out; const uint32_t* mask; size_t mask_e0; float mscale;
+};
+struct LstmStepParams { int n, B, R; LstmStepSide s[2]; };
+hipError_t lstm_step_fused(hipStream_t st, int order, const LstmStepParams& P);
 struct LstmBwdCell {
   const float* gates; const float* c_prev; long cp_rs; const float* tanhc;
   const float* slabA; int nA;     // recurrent dh partials [nB,R]
@@ -154,7 +177,24 @@ hipError_t att_bwd_fused(hipStream_t st, int nB, int M, int A, int S, const floa
                          const float* dj, const float* a, const float* da_lin,
                          const float* ws, float* T_to_dS, float* dz, float* du, float* dwsp,
                          const float* Psrc = nullptr /* T not kept: recompute tanh(Psrc + u) */,
-                         const float* u = nullptr);
+                         const float* u = nullptr,
+                         // da_ns > 0: da_lin holds K-split partials [split][nB][SL] of dj Wf (summed
+                         // by the kernel, plus the optional pitched addend da_add [nB][S])
+                         int da_ns = 0, int SL = 0, const float* da_add = nullptr);
+// The same two passes cut into 4-wave workgroups (NC row chunks per sample, two launches per
+// pass): they always fit next to resident bulk-GEMM workgroups.  `part` is scratch of
+// att_split_part_floats(nB, S) floats.  T is never kept (the backward recomputes tanh(Psrc + u)
+// when Psrc is given, else reads T).
+size_t att_split_part_floats(int nB, int S);
+hipError_t att_fwd_split(hipStream_t st, int nB, int M, int A, int S, const float* P,
+                         const float* u, const float* ws, const float* bs, const float* zm,
+                         const float* I, const float* qf, float* a, float* jv, float* part,
+                         const AttPartials& ap = AttPartials());
+hipError_t att_bwd_split(hipStream_t st, int nB, int M, int A, int S, const float* I,
+                         const float* dj, const float* a, const float* da_lin, const float* ws,
+                         float* T_to_dS, float* dz, float* du, float* dwsp, const float* Psrc,
+                         const float* u, float* part, int da_ns = 0, int SL = 0,
+                         const float* da_add = nullptr);
 // xd[h][i] = X[i] * keep(h, i) * scale for h < H, i < per_hop (feature-map dropout, SS:239)
 // SL != Sp: rows of SL logical positions at pitch Sp (mask indexed logically, pad columns zeroed)
 hipError_t dropout_features(hipStream_t st, int H, size_t per_hop, const float* X,
@@ -171,7 +211,8 @@ hipError_t ce_fwd(hipStream_t st, int nB, int K, int M, const float* logits,
                   const int32_t* labels, const float* mf, const float* wd, const float* bd,
                   float* dl, float* lossrow, int32_t* argmax, float* dopred,
                   const float* part = nullptr, int nsplit = 0, const float* bias = nullptr,
-                  float* logits_out = nullptr);
+                  float* logits_out = nullptr,
+                  int Bper = 0 /* rows are [hop][sample]: samples per hop (label period, 1/B) */);
 hipError_t loss_reduce(hipStream_t st, int H, int nB, const float* lossrow, float* losses);
 hipError_t scale_hops(hipStream_t st, int H, size_t per_hop, const float* w_dev, float* x);
 hipError_t gather_q(hipStream_t st, int nB, int Rq, int T, const int32_t* lens, const float* c1,

@@ -373,11 +373,15 @@ hipError_t lstm_bwd_multi(hipStream_t st, int order, int nB, int R, const LstmBw
 static int att_waves(bool bwd) {
   static const int v[2] = {
       [] { const char* e = std::getenv("RAU_ATT_WAVES_FWD"); const int n = e ? std::atoi(e) : 0;
-           return (n == 4 || n == 8 || n == 16) ? n : 16; }(),
+           return (n == 4 || n == 8 || n == 16) ? n : 8; }(),
       [] { const char* e = std::getenv("RAU_ATT_WAVES_BWD"); const int n = e ? std::atoi(e) : 0;
-           return (n == 4 || n == 8 || n == 16) ? n : 16; }()};
+           return (n == 4 || n == 8 || n == 16) ? n : 8; }()};
   return v[bwd ? 1 : 0];
 }
+
+constexpr int kAttLoads = 8;   // independent row loads a wave issues before it consumes the first
+constexpr int kAttLoadsT = 4;  // same, in the tanh-heavy loops (register budget: the kernels must fit
+                               // beside two resident bulk-GEMM workgroups of 144-176 VGPRs)
 
 template <int NW>
 __device__ __forceinline__ float block_sum_ordered(const float* red, int S, int s) {
@@ -426,19 +430,33 @@ __global__ __launch_bounds__(NW * 64) void k_att_fwd_fused(
   if (ap.u_out)   // the finished u row, for the backward's tanh(P + u)
     for (int k = tid; k < A; k += NW * 64) ap.u_out[(size_t)b * A + k] = ap.u_ns ? us[k] : ub[k];
   // ---- phase 1: T = tanh(P + u), e[s] = sum_k ws[k] T[k,s]
+  // kAttLoadsT rows are loaded before the first one is used: next to the bulk GEMMs a dependent
+  // global load takes microseconds, so the bytes in flight per wave set this kernel's speed
   for (int q0 = 0; q0 < S4; q0 += 64) {
     const int q = q0 + l;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     if (q < S4) {
-      for (int k = w; k < A; k += NW) {
-        const float4 p = reinterpret_cast<const float4*>(Pb + (size_t)k * S)[q];
-        const float uk = ap.u_ns ? us[k] : ub[k];
-        const float wk = ws[k];
-        float4 t;
-        t.x = tanh_fast(p.x + uk); t.y = tanh_fast(p.y + uk);
-        t.z = tanh_fast(p.z + uk); t.w = tanh_fast(p.w + uk);
-        if (T) reinterpret_cast<float4*>(Tb + (size_t)k * S)[q] = t;
-        acc.x += wk * t.x; acc.y += wk * t.y; acc.z += wk * t.z; acc.w += wk * t.w;
+      for (int k0 = w; k0 < A; k0 += NW * kAttLoadsT) {
+        float4 p[kAttLoadsT];
+#pragma unroll
+        for (int i = 0; i < kAttLoadsT; ++i) {
+          const int k = k0 + i * NW;
+          p[i] = k < A ? reinterpret_cast<const float4*>(Pb + (size_t)k * S)[q]
+                       : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int i = 0; i < kAttLoadsT; ++i) {
+          const int k = k0 + i * NW;
+          if (k < A) {
+            const float uk = ap.u_ns ? us[k] : ub[k];
+            const float wk = ws[k];
+            float4 t;
+            t.x = tanh_fast(p[i].x + uk); t.y = tanh_fast(p[i].y + uk);
+            t.z = tanh_fast(p[i].z + uk); t.w = tanh_fast(p[i].w + uk);
+            if (T) reinterpret_cast<float4*>(Tb + (size_t)k * S)[q] = t;
+            acc.x += wk * t.x; acc.y += wk * t.y; acc.z += wk * t.z; acc.w += wk * t.w;
+          }
+        }
       }
       reinterpret_cast<float4*>(red + (size_t)w * S)[q] = acc;
     }
@@ -480,21 +498,25 @@ __global__ __launch_bounds__(NW * 64) void k_att_fwd_fused(
     a[(size_t)b * S + s] = v;
   }
   __syncthreads();
-  // ---- phase 3: jv[m] = qf[m] + sum_s I[m,s] a[s]; one wave per row, 4 rows in flight
+  // ---- phase 3: jv[m] = qf[m] + sum_s I[m,s] a[s]; one wave per row, kAttLoads rows in flight
   const float* Ib = I + (size_t)b * M * S;
-  for (int m0 = w * 4; m0 < M; m0 += NW * 4) {
-    float part[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int m0 = w * kAttLoads; m0 < M; m0 += NW * kAttLoads) {
+    float part[kAttLoads];
+#pragma unroll
+    for (int r = 0; r < kAttLoads; ++r) part[r] = 0.f;
     for (int q = l; q < S4; q += 64) {
       const float4 av = reinterpret_cast<const float4*>(as)[q];
+      float4 x[kAttLoads];
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
-        if (m0 + r < M) {
-          const float4 x = reinterpret_cast<const float4*>(Ib + (size_t)(m0 + r) * S)[q];
-          part[r] += x.x * av.x + x.y * av.y + x.z * av.z + x.w * av.w;
-        }
+      for (int r = 0; r < kAttLoads; ++r)
+        x[r] = m0 + r < M ? reinterpret_cast<const float4*>(Ib + (size_t)(m0 + r) * S)[q]
+                          : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int r = 0; r < kAttLoads; ++r)
+        part[r] += x[r].x * av.x + x[r].y * av.y + x[r].z * av.z + x[r].w * av.w;
     }
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
+    for (int r = 0; r < kAttLoads; ++r) {
       const float v = wave_sum(part[r]);
       if (l == 0 && m0 + r < M) jv[(size_t)b * M + m0 + r] = v + qf[(size_t)b * M + m0 + r];
     }
@@ -518,7 +540,8 @@ __global__ __launch_bounds__(NW * 64) void k_att_bwd_fused(
     int M, int A, int S, const float* __restrict__ I, const float* __restrict__ dj,
     const float* __restrict__ a, const float* __restrict__ da_lin, const float* __restrict__ ws,
     float* __restrict__ T, float* __restrict__ dz, float* __restrict__ du,
-    float* __restrict__ dwsp, const float* __restrict__ Psrc, const float* __restrict__ u) {
+    float* __restrict__ dwsp, const float* __restrict__ Psrc, const float* __restrict__ u,
+    int da_ns, int SL, int nB, const float* __restrict__ da_add) {
   RAU_CHAIN_PRIO();
   extern __shared__ __attribute__((aligned(16))) float sm[];
   float* red = sm;                     // [NW][S]
@@ -528,15 +551,25 @@ __global__ __launch_bounds__(NW * 64) void k_att_bwd_fused(
   const int S4 = S >> 2;
   const float* Ib = I + (size_t)b * M * S;
   const float* djb = dj + (size_t)b * M;
-  // ---- phase 1: da[s] = da_lin[s] + sum_m dj[m] I[m,s]
+  // ---- phase 1: da[s] = da_lin[s] + sum_m dj[m] I[m,s]   (kAttLoads rows of I in flight)
   for (int q0 = 0; q0 < S4; q0 += 64) {
     const int q = q0 + l;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     if (q < S4) {
-      for (int m = w; m < M; m += NW) {
-        const float d = djb[m];
-        const float4 x = reinterpret_cast<const float4*>(Ib + (size_t)m * S)[q];
-        acc.x += d * x.x; acc.y += d * x.y; acc.z += d * x.z; acc.w += d * x.w;
+      for (int m0 = w; m0 < M; m0 += NW * kAttLoads) {
+        float4 x[kAttLoads];
+#pragma unroll
+        for (int i = 0; i < kAttLoads; ++i) {
+          const int m = m0 + i * NW;
+          x[i] = m < M ? reinterpret_cast<const float4*>(Ib + (size_t)m * S)[q]
+                       : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int i = 0; i < kAttLoads; ++i) {
+          const int m = m0 + i * NW;
+          const float d = m < M ? djb[m] : 0.f;
+          acc.x += d * x[i].x; acc.y += d * x[i].y; acc.z += d * x[i].z; acc.w += d * x[i].w;
+        }
       }
       reinterpret_cast<float4*>(red + (size_t)w * S)[q] = acc;
     }
@@ -545,7 +578,17 @@ __global__ __launch_bounds__(NW * 64) void k_att_bwd_fused(
   // ---- phase 2: dz = a * (da - sum_s a da)
   float dot = 0.f;
   for (int s = tid; s < S; s += (NW * 64)) {
-    const float d = da_lin[(size_t)b * S + s] + block_sum_ordered<NW>(red, S, s);
+    float d;
+    if (da_ns > 0) {   // da_lin = K-split partials [split][nB][SL] of dj Wf, summed here in order
+      d = 0.f;
+      if (s < SL) {
+        for (int sp = 0; sp < da_ns; ++sp) d += da_lin[((size_t)sp * nB + b) * SL + s];
+        if (da_add) d += da_add[(size_t)b * S + s];
+      }
+    } else {
+      d = da_lin[(size_t)b * S + s];
+    }
+    d += block_sum_ordered<NW>(red, S, s);
     dzs[s] = d;
     dot += a[(size_t)b * S + s] * d;
   }
@@ -566,47 +609,371 @@ __global__ __launch_bounds__(NW * 64) void k_att_bwd_fused(
   // very buffer dS is written to: same thread, same address, read first).
   float* Tb = T + (size_t)b * A * S;
   const float* Pb = Psrc ? Psrc + (size_t)b * A * S : nullptr;
-  for (int k = w; k < A; k += NW) {
-    const float wk = ws[k];
-    const float uk = Psrc ? u[(size_t)b * A + k] : 0.f;
-    float s1 = 0.f, s2 = 0.f;
+  constexpr int UB = 4;   // rows of P/T in flight per wave
+  for (int k0 = w; k0 < A; k0 += NW * UB) {
+    float s1[UB], s2[UB];
+#pragma unroll
+    for (int i = 0; i < UB; ++i) s1[i] = s2[i] = 0.f;
     for (int q = l; q < S4; q += 64) {
-      float4 t;
-      if (Psrc) {
-        const float4 p = reinterpret_cast<const float4*>(Pb + (size_t)k * S)[q];
-        t.x = tanh_fast(p.x + uk); t.y = tanh_fast(p.y + uk);
-        t.z = tanh_fast(p.z + uk); t.w = tanh_fast(p.w + uk);
-      } else {
-        t = reinterpret_cast<const float4*>(Tb + (size_t)k * S)[q];
-      }
       const float4 d = reinterpret_cast<const float4*>(dzs)[q];
-      float4 o;
-      o.x = d.x * wk * (1.f - t.x * t.x);
-      o.y = d.y * wk * (1.f - t.y * t.y);
-      o.z = d.z * wk * (1.f - t.z * t.z);
-      o.w = d.w * wk * (1.f - t.w * t.w);
-      reinterpret_cast<float4*>(Tb + (size_t)k * S)[q] = o;
-      s1 += (o.x + o.y) + (o.z + o.w);
-      s2 += d.x * t.x + d.y * t.y + d.z * t.z + d.w * t.w;
+      float4 t[UB];
+#pragma unroll
+      for (int i = 0; i < UB; ++i) {
+        const int k = k0 + i * NW;
+        t[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (k < A)
+          t[i] = Psrc ? reinterpret_cast<const float4*>(Pb + (size_t)k * S)[q]
+                      : reinterpret_cast<const float4*>(Tb + (size_t)k * S)[q];
+      }
+#pragma unroll
+      for (int i = 0; i < UB; ++i) {
+        const int k = k0 + i * NW;
+        if (k < A) {
+          const float wk = ws[k];
+          if (Psrc) {
+            const float uk = u[(size_t)b * A + k];
+            t[i].x = tanh_fast(t[i].x + uk); t[i].y = tanh_fast(t[i].y + uk);
+            t[i].z = tanh_fast(t[i].z + uk); t[i].w = tanh_fast(t[i].w + uk);
+          }
+          float4 o;
+          o.x = d.x * wk * (1.f - t[i].x * t[i].x);
+          o.y = d.y * wk * (1.f - t[i].y * t[i].y);
+          o.z = d.z * wk * (1.f - t[i].z * t[i].z);
+          o.w = d.w * wk * (1.f - t[i].w * t[i].w);
+          reinterpret_cast<float4*>(Tb + (size_t)k * S)[q] = o;
+          s1[i] += (o.x + o.y) + (o.z + o.w);
+          s2[i] += d.x * t[i].x + d.y * t[i].y + d.z * t[i].z + d.w * t[i].w;
+        }
+      }
     }
-    s1 = wave_sum(s1);
-    s2 = wave_sum(s2);
-    if (l == 0) {
-      du[(size_t)b * A + k] = s1;
-      dwsp[(size_t)b * A + k] = s2;
+#pragma unroll
+    for (int i = 0; i < UB; ++i) {
+      const int k = k0 + i * NW;
+      const float v1 = wave_sum(s1[i]);
+      const float v2 = wave_sum(s2[i]);
+      if (l == 0 && k < A) {
+        du[(size_t)b * A + k] = v1;
+        dwsp[(size_t)b * A + k] = v2;
+      }
     }
   }
 }
 hipError_t att_bwd_fused(hipStream_t st, int nB, int M, int A, int S, const float* I,
                          const float* dj, const float* a, const float* da_lin,
                          const float* ws, float* T_to_dS, float* dz, float* du, float* dwsp,
-                         const float* Psrc, const float* u) {
+                         const float* Psrc, const float* u, int da_ns, int SL,
+                         const float* da_add) {
   const int nw = att_waves(true);
   const size_t lds = ((size_t)(nw + 1) * S + nw) * sizeof(float);
 #define ATT_BWD(NW_) hipLaunchKernelGGL(k_att_bwd_fused<NW_>, dim3(nB), dim3(NW_ * 64), lds, st, M, A, \
-                                        S, I, dj, a, da_lin, ws, T_to_dS, dz, du, dwsp, Psrc, u)
+                                        S, I, dj, a, da_lin, ws, T_to_dS, dz, du, dwsp, Psrc, u, \
+                                        da_ns, SL, nB, da_add)
   if (nw == 4) ATT_BWD(4); else if (nw == 8) ATT_BWD(8); else ATT_BWD(16);
 #undef ATT_BWD
+  return hipGetLastError();
+}
+
+// ------------------------------------------- split per-sample attention kernels
+// Same arithmetic as the fused kernels above, cut into small workgroups: NC row chunks per
+// sample, one 4-wave workgroup each (<= 64 VGPRs, ~3 KB LDS).  A 8- or 16-wave workgroup has to
+// wait until a compute unit can take all of its waves at once, which next to two resident
+// bulk-GEMM workgroups (144-176 VGPRs per wave) means waiting for a GEMM tile to retire (measured
+// in the overlapped step: 60 us -> 120-470 us per launch); four-wave workgroups always fit, and
+// NC x more of them spread over the chip.  Each pass is two launches: per-chunk partial column
+// sums over the sample's [rows][S] tile, then a launch whose workgroups all finish the (cheap)
+// softmax step redundantly and stream their own chunk of the second tile.
+constexpr int kSplitLoads = 4;   // row loads in flight per wave
+
+// part[b][c][s] = sum_{k in chunk c} ws[k] tanh(P[b,k,s] + u[b,k])
+__global__ __launch_bounds__(256) void k_att_score_part(
+    int nB, int A, int S, const float* __restrict__ P, const float* __restrict__ u,
+    const float* __restrict__ ws, float* __restrict__ part, AttPartials ap) {
+  RAU_CHAIN_PRIO();
+  extern __shared__ __attribute__((aligned(16))) float sm[];   // [4][S]
+  const int c = blockIdx.x, NC = gridDim.x, b = blockIdx.y;
+  const int tid = threadIdx.x, l = tid & 63, w = tid >> 6;
+  const int S4 = S >> 2;
+  const int rows = (A + NC - 1) / NC, k_lo = c * rows, k_hi = min(A, k_lo + rows);
+  const float* Pb = P + (size_t)b * A * S;
+  for (int q0 = 0; q0 < S4; q0 += 64) {
+    const int q = q0 + l;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k0 = k_lo + w; k0 < k_hi; k0 += 4 * kSplitLoads) {
+      float4 p[kSplitLoads];
+      float uk[kSplitLoads];
+#pragma unroll
+      for (int i = 0; i < kSplitLoads; ++i) {
+        const int k = k0 + 4 * i;
+        p[i] = (k < k_hi && q < S4) ? reinterpret_cast<const float4*>(Pb + (size_t)k * S)[q]
+                                    : make_float4(0.f, 0.f, 0.f, 0.f);
+        float v = 0.f;
+        if (k < k_hi) {
+          if (ap.u_ns) {   // K-split partials of qf Wa^T (+ bias), summed in order
+            v = ap.u_bias[k];
+            for (int sp = 0; sp < ap.u_ns; ++sp) v += u[((size_t)sp * nB + b) * A + k];
+          } else {
+            v = u[(size_t)b * A + k];
+          }
+        }
+        uk[i] = v;
+      }
+#pragma unroll
+      for (int i = 0; i < kSplitLoads; ++i) {
+        const int k = k0 + 4 * i;
+        if (k < k_hi) {
+          const float wk = ws[k];
+          acc.x += wk * tanh_fast(p[i].x + uk[i]); acc.y += wk * tanh_fast(p[i].y + uk[i]);
+          acc.z += wk * tanh_fast(p[i].z + uk[i]); acc.w += wk * tanh_fast(p[i].w + uk[i]);
+          if (ap.u_out && q0 == 0 && l == 0) ap.u_out[(size_t)b * A + k] = uk[i];
+        }
+      }
+    }
+    if (q < S4) reinterpret_cast<float4*>(sm + (size_t)w * S)[q] = acc;
+  }
+  __syncthreads();
+  for (int s = tid; s < S; s += 256)
+    part[((size_t)b * NC + c) * S + s] = (sm[s] + sm[S + s]) + (sm[2 * S + s] + sm[3 * S + s]);
+}
+
+// a = softmax(sum_c part + bs + zm) (every chunk's workgroup, redundantly; chunk 0 stores it);
+// jv[m] = qf[m] + sum_s I[m,s] a[s] for the rows m of chunk c
+__global__ __launch_bounds__(256) void k_att_ctx(
+    int nB, int M, int S, const float* __restrict__ part, const float* __restrict__ bs,
+    const float* __restrict__ zm, const float* __restrict__ I, const float* __restrict__ qf,
+    float* __restrict__ a, float* __restrict__ jv, AttPartials ap) {
+  RAU_CHAIN_PRIO();
+  extern __shared__ __attribute__((aligned(16))) float sm[];   // as[S] + 8 scalars
+  float* as = sm;
+  float* sc = sm + S;
+  const int c = blockIdx.x, NC = gridDim.x, b = blockIdx.y;
+  const int tid = threadIdx.x, l = tid & 63, w = tid >> 6;
+  const int S4 = S >> 2;
+  const int SL = ap.SL > 0 ? ap.SL : S;
+  float mx = -INFINITY;
+  for (int s = tid; s < S; s += 256) {
+    float z = -INFINITY;   // pad positions take no attention (and so no gradient)
+    if (s < SL) {
+      float zmv;
+      if (ap.z_ns) {
+        zmv = ap.z_bias[s];
+        for (int sp = 0; sp < ap.z_ns; ++sp) zmv += zm[((size_t)sp * nB + b) * SL + s];
+      } else {
+        zmv = zm[(size_t)b * S + s];
+      }
+      float e = part[(size_t)b * NC * S + s];
+      for (int cc = 1; cc < NC; ++cc) e += part[((size_t)b * NC + cc) * S + s];
+      z = e + bs[0] + zmv;
+    }
+    as[s] = z;
+    mx = fmaxf(mx, z);
+  }
+  mx = wave_max(mx);
+  if (l == 0) sc[w] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3]));
+  float den = 0.f;
+  for (int s = tid; s < S; s += 256) {
+    const float ex = expf(as[s] - mx);
+    as[s] = ex;
+    den += ex;
+  }
+  den = wave_sum(den);
+  if (l == 0) sc[4 + w] = den;
+  __syncthreads();
+  den = ((sc[4] + sc[5]) + sc[6]) + sc[7];
+  const float inv = 1.f / den;
+  for (int s = tid; s < S; s += 256) {
+    const float v = as[s] * inv;
+    as[s] = v;
+    if (c == 0) a[(size_t)b * S + s] = v;
+  }
+  __syncthreads();
+  const int rows = (M + NC - 1) / NC, m_lo = c * rows, m_hi = min(M, m_lo + rows);
+  const float* Ib = I + (size_t)b * M * S;
+  for (int m0 = m_lo + w * kSplitLoads; m0 < m_hi; m0 += 4 * kSplitLoads) {
+    float pr[kSplitLoads];
+#pragma unroll
+    for (int r = 0; r < kSplitLoads; ++r) pr[r] = 0.f;
+    for (int q = l; q < S4; q += 64) {
+      const float4 av = reinterpret_cast<const float4*>(as)[q];
+      float4 x[kSplitLoads];
+#pragma unroll
+      for (int r = 0; r < kSplitLoads; ++r)
+        x[r] = m0 + r < m_hi ? reinterpret_cast<const float4*>(Ib + (size_t)(m0 + r) * S)[q]
+                             : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int r = 0; r < kSplitLoads; ++r)
+        pr[r] += x[r].x * av.x + x[r].y * av.y + x[r].z * av.z + x[r].w * av.w;
+    }
+#pragma unroll
+    for (int r = 0; r < kSplitLoads; ++r) {
+      const float v = wave_sum(pr[r]);
+      if (l == 0 && m0 + r < m_hi) jv[(size_t)b * M + m0 + r] = v + qf[(size_t)b * M + m0 + r];
+    }
+  }
+}
+
+static int att_chunks() {
+  static const int v = [] { const char* e = std::getenv("RAU_ATT_CHUNKS"); const int n = e ? std::atoi(e) : 0;
+                            return (n >= 1 && n <= 8) ? n : 4; }();
+  return v;
+}
+size_t att_split_part_floats(int nB, int S) { return (size_t)nB * 8 * S; }
+
+hipError_t att_fwd_split(hipStream_t st, int nB, int M, int A, int S, const float* P,
+                         const float* u, const float* ws, const float* bs, const float* zm,
+                         const float* I, const float* qf, float* a, float* jv, float* part,
+                         const AttPartials& ap) {
+  const int nc = att_chunks();
+  hipLaunchKernelGGL(k_att_score_part, dim3(nc, nB), dim3(256), (size_t)4 * S * sizeof(float), st, nB,
+                     A, S, P, u, ws, part, ap);
+  hipLaunchKernelGGL(k_att_ctx, dim3(nc, nB), dim3(256), (size_t)(S + 8) * sizeof(float), st, nB, M, S,
+                     part, bs, zm, I, qf, a, jv, ap);
+  return hipGetLastError();
+}
+
+// part[b][c][s] = sum_{m in chunk c} dj[b,m] I[b,m,s]
+__global__ __launch_bounds__(256) void k_att_da_part(int M, int S, const float* __restrict__ I,
+                                                     const float* __restrict__ dj,
+                                                     float* __restrict__ part) {
+  RAU_CHAIN_PRIO();
+  extern __shared__ __attribute__((aligned(16))) float sm[];   // [4][S]
+  const int c = blockIdx.x, NC = gridDim.x, b = blockIdx.y;
+  const int tid = threadIdx.x, l = tid & 63, w = tid >> 6;
+  const int S4 = S >> 2;
+  const int rows = (M + NC - 1) / NC, m_lo = c * rows, m_hi = min(M, m_lo + rows);
+  const float* Ib = I + (size_t)b * M * S;
+  const float* djb = dj + (size_t)b * M;
+  for (int q0 = 0; q0 < S4; q0 += 64) {
+    const int q = q0 + l;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int m0 = m_lo + w; m0 < m_hi; m0 += 4 * kSplitLoads) {
+      float4 x[kSplitLoads];
+#pragma unroll
+      for (int i = 0; i < kSplitLoads; ++i) {
+        const int m = m0 + 4 * i;
+        x[i] = (m < m_hi && q < S4) ? reinterpret_cast<const float4*>(Ib + (size_t)m * S)[q]
+                                    : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int i = 0; i < kSplitLoads; ++i) {
+        const int m = m0 + 4 * i;
+        const float d = m < m_hi ? djb[m] : 0.f;
+        acc.x += d * x[i].x; acc.y += d * x[i].y; acc.z += d * x[i].z; acc.w += d * x[i].w;
+      }
+    }
+    if (q < S4) reinterpret_cast<float4*>(sm + (size_t)w * S)[q] = acc;
+  }
+  __syncthreads();
+  for (int s = tid; s < S; s += 256)
+    part[((size_t)b * NC + c) * S + s] = (sm[s] + sm[S + s]) + (sm[2 * S + s] + sm[3 * S + s]);
+}
+
+// da = da_lin + sum_c part; dz = a (da - sum_s a da) (every chunk's workgroup; chunk 0 stores it);
+// rows k of chunk c: T -> dS = dz ws[k] (1 - T^2) in place, du[k] = sum_s dS, dwsp[k] = sum_s dz T
+__global__ __launch_bounds__(256) void k_att_ds(
+    int nB, int A, int S, const float* __restrict__ part, const float* __restrict__ a,
+    const float* __restrict__ da_lin, const float* __restrict__ ws, float* __restrict__ T,
+    float* __restrict__ dz, float* __restrict__ du, float* __restrict__ dwsp,
+    const float* __restrict__ Psrc, const float* __restrict__ u, int da_ns, int SL,
+    const float* __restrict__ da_add) {
+  RAU_CHAIN_PRIO();
+  extern __shared__ __attribute__((aligned(16))) float sm[];   // dzs[S] + 4 scalars
+  float* dzs = sm;
+  float* sc = sm + S;
+  const int c = blockIdx.x, NC = gridDim.x, b = blockIdx.y;
+  const int tid = threadIdx.x, l = tid & 63, w = tid >> 6;
+  const int S4 = S >> 2;
+  float dot = 0.f;
+  for (int s = tid; s < S; s += 256) {
+    float d;
+    if (da_ns > 0) {   // K-split partials [split][nB][SL] of dj Wf, summed in order
+      d = 0.f;
+      if (s < SL) {
+        for (int sp = 0; sp < da_ns; ++sp) d += da_lin[((size_t)sp * nB + b) * SL + s];
+        if (da_add) d += da_add[(size_t)b * S + s];
+      }
+    } else {
+      d = da_lin[(size_t)b * S + s];
+    }
+    float e = part[(size_t)b * NC * S + s];
+    for (int cc = 1; cc < NC; ++cc) e += part[((size_t)b * NC + cc) * S + s];
+    d += e;
+    dzs[s] = d;
+    dot += a[(size_t)b * S + s] * d;
+  }
+  dot = wave_sum(dot);
+  if (l == 0) sc[w] = dot;
+  __syncthreads();
+  dot = ((sc[0] + sc[1]) + sc[2]) + sc[3];
+  for (int s = tid; s < S; s += 256) {
+    const float v = a[(size_t)b * S + s] * (dzs[s] - dot);
+    dzs[s] = v;
+    if (c == 0) dz[(size_t)b * S + s] = v;
+  }
+  __syncthreads();
+  const int rows = (A + NC - 1) / NC, k_lo = c * rows, k_hi = min(A, k_lo + rows);
+  float* Tb = T + (size_t)b * A * S;
+  const float* Pb = Psrc ? Psrc + (size_t)b * A * S : nullptr;
+  constexpr int UB = 2;
+  for (int k0 = k_lo + w; k0 < k_hi; k0 += 4 * UB) {
+    float s1[UB], s2[UB];
+#pragma unroll
+    for (int i = 0; i < UB; ++i) s1[i] = s2[i] = 0.f;
+    for (int q = l; q < S4; q += 64) {
+      const float4 d = reinterpret_cast<const float4*>(dzs)[q];
+      float4 t[UB];
+#pragma unroll
+      for (int i = 0; i < UB; ++i) {
+        const int k = k0 + 4 * i;
+        t[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (k < k_hi)
+          t[i] = Psrc ? reinterpret_cast<const float4*>(Pb + (size_t)k * S)[q]
+                      : reinterpret_cast<const float4*>(Tb + (size_t)k * S)[q];
+      }
+#pragma unroll
+      for (int i = 0; i < UB; ++i) {
+        const int k = k0 + 4 * i;
+        if (k < k_hi) {
+          const float wk = ws[k];
+          if (Psrc) {
+            const float uk = u[(size_t)b * A + k];
+            t[i].x = tanh_fast(t[i].x + uk); t[i].y = tanh_fast(t[i].y + uk);
+            t[i].z = tanh_fast(t[i].z + uk); t[i].w = tanh_fast(t[i].w + uk);
+          }
+          float4 o;
+          o.x = d.x * wk * (1.f - t[i].x * t[i].x);
+          o.y = d.y * wk * (1.f - t[i].y * t[i].y);
+          o.z = d.z * wk * (1.f - t[i].z * t[i].z);
+          o.w = d.w * wk * (1.f - t[i].w * t[i].w);
+          reinterpret_cast<float4*>(Tb + (size_t)k * S)[q] = o;
+          s1[i] += (o.x + o.y) + (o.z + o.w);
+          s2[i] += d.x * t[i].x + d.y * t[i].y + d.z * t[i].z + d.w * t[i].w;
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < UB; ++i) {
+      const int k = k0 + 4 * i;
+      const float v1 = wave_sum(s1[i]);
+      const float v2 = wave_sum(s2[i]);
+      if (l == 0 && k < k_hi) {
+        du[(size_t)b * A + k] = v1;
+        dwsp[(size_t)b * A + k] = v2;
+      }
+    }
+  }
+}
+
+hipError_t att_bwd_split(hipStream_t st, int nB, int M, int A, int S, const float* I,
+                         const float* dj, const float* a, const float* da_lin, const float* ws,
+                         float* T_to_dS, float* dz, float* du, float* dwsp, const float* Psrc,
+                         const float* u, float* part, int da_ns, int SL, const float* da_add) {
+  const int nc = att_chunks();
+  hipLaunchKernelGGL(k_att_da_part, dim3(nc, nB), dim3(256), (size_t)4 * S * sizeof(float), st, M, S, I,
+                     dj, part);
+  hipLaunchKernelGGL(k_att_ds, dim3(nc, nB), dim3(256), (size_t)(S + 4) * sizeof(float), st, nB, A, S,
+                     part, a, da_lin, ws, T_to_dS, dz, du, dwsp, Psrc, u, da_ns, SL, da_add);
   return hipGetLastError();
 }
 
@@ -776,7 +1143,8 @@ __global__ void k_ce_fwd(int nB, int K, int M, const float* __restrict__ logits,
                          float* __restrict__ dl, float* __restrict__ lossrow,
                          int32_t* __restrict__ argmax, float* __restrict__ dopred,
                          const float* __restrict__ part, int nsplit,
-                         const float* __restrict__ bias, float* __restrict__ logits_out) {
+                         const float* __restrict__ bias, float* __restrict__ logits_out,
+                         int Bper) {
   RAU_CHAIN_PRIO();
   __shared__ float s_val[4];
   __shared__ int s_idx[4];
@@ -821,8 +1189,8 @@ __global__ void k_ce_fwd(int nB, int K, int M, const float* __restrict__ logits,
   const float lse = mx + logf(den);
   if (tid == 0) argmax[b] = ai + 1;
   if (labels) {
-    const int y = labels[b] - 1;
-    const float invB = 1.f / (float)nB;
+    const int y = labels[b % Bper] - 1;   // rows = [hop][sample]: labels repeat every Bper rows
+    const float invB = 1.f / (float)Bper;
     for (int k = tid; k < K; k += 256) {
       float p = expf(lg[k] - lse) * invB;
       if (k == y) p -= invB;
@@ -843,9 +1211,10 @@ __global__ void k_ce_fwd(int nB, int K, int M, const float* __restrict__ logits,
 hipError_t ce_fwd(hipStream_t st, int nB, int K, int M, const float* logits,
                   const int32_t* labels, const float* mf, const float* wd, const float* bd,
                   float* dl, float* lossrow, int32_t* argmax, float* dopred, const float* part,
-                  int nsplit, const float* bias, float* logits_out) {
+                  int nsplit, const float* bias, float* logits_out, int Bper) {
   hipLaunchKernelGGL(k_ce_fwd, dim3(nB), dim3(256), 0, st, nB, K, M, logits, labels, mf, wd, bd,
-                     dl, lossrow, argmax, dopred, part, nsplit, bias, logits_out);
+                     dl, lossrow, argmax, dopred, part, nsplit, bias, logits_out,
+                     Bper > 0 ? Bper : nB);
   return hipGetLastError();
 }
 

@@ -76,7 +76,9 @@ struct rau_ctx {
   hipStream_t st2 = nullptr;   // bulk stream: hop-batched 1x1-conv GEMMs, overlapped with the chain
   hipStream_t st3 = nullptr;   // weight-gradient stream: throughput GEMMs nobody waits for until the end
   hipEvent_t evA = nullptr, evD = nullptr, evW = nullptr, evE = nullptr, evW3 = nullptr,
-             evM3 = nullptr, evEnd = nullptr, evE1 = nullptr;
+             evM3 = nullptr, evEnd = nullptr, evE1 = nullptr, evHd = nullptr;
+  std::vector<hipEvent_t> evEc;      // encoder weight-gradient chunks
+  std::vector<hipEvent_t> evH;       // per hop: forward chain done (the head stream waits on it)
   std::vector<hipEvent_t> evF, evK;  // per hop group: forward bulk done / backward chain done
   // hops per bulk launch (pipelines the bulk GEMMs with the hop loops): gsize[h] = n if hops
   // [h, h+n) form one launch group, else 0.  `groups` is the configured partition, `cur` the one
@@ -115,6 +117,11 @@ struct rau_ctx {
   float *qd, *Yq, *qf, *I, *T, *u, *zm, *a, *jv, *j, *g4, *cc, *hh, *tc, *mf, *logits,
       *dl, *lossrow, *dopred, *losses_d, *hopw_d;
   int32_t* argmax_d;
+  float* att_part = nullptr;  // [B][chunks][S] partial column sums of the split attention kernels
+  bool att_fused = false;
+  bool enc_fused = true;      // encoder forward: one fused GEMM + cell launch per wavefront step
+  float* hopw_h = nullptr;    // pinned staging of the hop weights, 2 slots of H
+  int hopw_slot = 0;
   // backward temporaries
   // dZ holds dI (gradient at i_embed's OUTPUT); the tanh derivative is applied by its consumers
   float *dpre, *dhn, *dg4, *dcn[2], *dhp[2], *dj, *da_lin, *dz, *du, *dwsp, *dZ,
@@ -127,6 +134,7 @@ struct rau_ctx {
   float *m_state = nullptr, *m_dstate = nullptr;   // [T][B][Q] packed DeepLSTM state slots
   float *m_tmp[4] = {nullptr, nullptr, nullptr, nullptr};  // [B][max(Rq,R,M)] scratch
   float *m_dq = nullptr, *m_dc = nullptr, *m_dh = nullptr;  // [H][B][Q], [H][B][R], [H][B][R]
+  float *m_Xp = nullptr, *m_a = nullptr, *m_da = nullptr, *m_dXd = nullptr;  // re-pitching (S % 4 != 0)
   float *m_dX = nullptr, *m_dZ = nullptr;          // [B][D][S], [B][M][S]: feature-map gradient, on request
   float *m_add = nullptr, *m_s = nullptr, *m_zero = nullptr;  // [B][M], [B], zeros [B][max(Q,R)]
   float *m_loss = nullptr;                         // [H] criterion outputs
@@ -246,10 +254,22 @@ struct HopGrad {
   const float* dmf_add;   // [B,M] or null: extra gradient at merge_feat before its dropout
   const float* da_out;    // [B,S] or null: gradient at the attprob output
   float* dc_out;          // [B,R] out: gradient at prev_c
-  float* dh_out;          // [B,R] out: gradient at prev_h
+  float* dh_out;          // [B,R] out: gradient at prev_h (written only when dh_part_out is null)
+  // step-level fast path (rau_backward): what does not depend on the recurrence is formed for
+  // all hops up front, and dh_prev travels from hop to hop as K-split partials
+  int dpre_ready;         // ctx->dpre rows of this hop already hold (dl Wc) (.) mask
+  const float* dhn_all;   // [H*B,R] dpre Wo for all hops (with dpre_ready)
+  const float* dh_part;   // [dh_part_ns][B,R] partials of the gradient at next_h (or null)
+  int dh_part_ns;
+  float** dh_part_out;    // non-null: leave dh_prev as partials and report them here
+  int* dh_part_ns_out;
 };
 __attribute__((visibility("hidden"))) int hop_forward(rau_ctx* ctx, int h, const float* cp,
     const float* hp, float* c_out, float* h_out, const float* Ih, const float* Pin,
     const int32_t* labels);
+__attribute__((visibility("hidden"))) int hop_forward_chain(rau_ctx* ctx, int h, const float* cp,
+    const float* hp, float* c_out, float* h_out, const float* Ih, const float* Pin);
+__attribute__((visibility("hidden"))) int hop_forward_head(rau_ctx* ctx, hipStream_t s, float* ws,
+    size_t reg, int h0, int nh, const int32_t* labels);
 __attribute__((visibility("hidden"))) int hop_backward(rau_ctx* ctx, int h, const float* cp,
     const float* Ih, const HopGrad& g);

@@ -50,6 +50,41 @@ static int prof_collect(rau_ctx* ctx) {
   if (tl) { std::fprintf(tl, "#\n"); std::fclose(tl); }
   return 0;
 }
+// The Linear weight-gradient problems of the mult group (over hop-major rows) and of the encoder
+// (over token-major rows): dW += dY^T X, db += column sums of dY.  dz and a are pitched (leading
+// dimension = position pitch, Linear size = logical S).
+static int mult_wgrad_problems(rau_ctx* ctx, TnProblem* pr) {
+  const rau_config& c = ctx->cfg;
+  const int S = ctx->Sp, SL = c.S, M = c.M, A = c.A, R = c.R, K = c.K, Q = ctx->Q;
+  const size_t BR_ = (size_t)c.B * R;
+  const float* hprev = ctx->hh;            // h_{0..H-1}
+  const float* hnew = ctx->hh + BR_;       // h_{1..H}
+  struct WG { Lin* l; const float* dY; long ldy; const float* X; long ldx; };
+  const WG wgs[] = {
+      {&ctx->cls, ctx->dl, K, ctx->mf, M},             {&ctx->lstm_out, ctx->dpre, M, hnew, R},
+      {&ctx->lstm_i2h, ctx->dg4, 4 * R, ctx->j, M},    {&ctx->lstm_h2h, ctx->dg4, 4 * R, hprev, R},
+      {&ctx->feat_attprob, ctx->dj, M, ctx->a, S},     {&ctx->att_mem, ctx->dz, S, hprev, R},
+      {&ctx->att_q, ctx->du, A, ctx->qf, M},           {&ctx->q_proj, ctx->dqt, M, ctx->qd, Q},
+      {&ctx->h_proj, ctx->dqt, M, hprev, R}};
+  int n = 0;
+  for (const WG& w : wgs) {
+    const int out = w.l == &ctx->att_mem ? SL : w.l->out;
+    const int in = w.l == &ctx->feat_attprob ? SL : w.l->in;
+    pr[n++] = TnProblem{out, in, w.dY, w.ldy, w.X, w.ldx, w.l->dW, w.l->db};
+  }
+  return n;
+}
+static int enc_wgrad_problems(rau_ctx* ctx, size_t row0, TnProblem* pr) {
+  struct WG { Lin* l; const float* dY; const float* X; };
+  const WG wgs[] = {{&ctx->i2h[0], ctx->dG1, ctx->we}, {&ctx->h2h[0], ctx->dG1, ctx->h1},
+                    {&ctx->i2h[1], ctx->dG2, ctx->x2}, {&ctx->h2h[1], ctx->dG2, ctx->h2}};
+  int n = 0;
+  for (const WG& w : wgs)
+    pr[n++] = TnProblem{w.l->out, w.l->in, w.dY + row0 * w.l->out, w.l->out,
+                        w.X + row0 * w.l->in, w.l->in, w.l->dW, w.l->db};
+  return n;
+}
+
 // ================================================================== C ABI
 extern "C" {
 
@@ -107,7 +142,17 @@ int rau_create(const rau_config* cfg, rau_ctx** out) {
   ctx->Q = 4 * c.Rq;
   ctx->Sp = (c.S + 3) & ~3;
   ctx->bf16 = c.dtype == RAU_BF16;
-  for (int i = 0; i < 5; ++i) ctx->mp[i] = ps[i];
+  // The device Philox masks keep an element when an 8-bit draw >= round(p * 256) (fill_masks): the
+  // effective drop probability is p quantised to 1/256, and the inverted-dropout scale 1/(1-p)
+  // uses THAT value so that E[mask * scale] = 1 exactly (the reference's 0.5 is representable).
+  for (int i = 0; i < 5; ++i) {
+    const float pq = std::lround(ps[i] * 256.0f) / 256.0f;
+    if (pq >= 1.f) {
+      delete ctx;
+      return fail(RAU_ERR_INVALID, "rau_create: dropout p=%f rounds to 1 at 1/256 resolution", ps[i]);
+    }
+    ctx->mp[i] = pq;
+  }
   *out = nullptr;
 #define CK(x)                \
   do {                       \
@@ -184,10 +229,15 @@ int rau_create(const rau_config* cfg, rau_ctx** out) {
   }
   ctx->evF.resize(c.H);
   ctx->evK.resize(c.H);
+  ctx->evH.resize(c.H);
   for (int i = 0; i < c.H; ++i) {
     hipEventCreateWithFlags(&ctx->evF[i], evflags);
     hipEventCreateWithFlags(&ctx->evK[i], evflags);
+    hipEventCreateWithFlags(&ctx->evH[i], evflags);
   }
+  hipEventCreateWithFlags(&ctx->evHd, evflags);
+  ctx->evEc.resize(8);
+  for (auto& e : ctx->evEc) hipEventCreateWithFlags(&e, evflags);
 
   // S below is the position PITCH of the device tensors; SL the logical number of positions
   // (they differ only for maps like 7x7 = 49 -> 52: pad columns carry zero features, zero
@@ -279,6 +329,9 @@ int rau_create(const rau_config* cfg, rau_ctx** out) {
   CK(dalloc(ctx, &ctx->WiT, (size_t)M * D));
   CK(dalloc(ctx, &ctx->WpT, (size_t)A * M));
   CK(dalloc(ctx, &ctx->zm, (size_t)B * S));
+  CK(dalloc(ctx, &ctx->att_part, att_split_part_floats(B, S)));
+  ctx->att_fused = std::getenv("RAU_ATT_FUSED") != nullptr;
+  ctx->enc_fused = std::getenv("RAU_ENC_UNFUSED") == nullptr;    // A/B knob: split-K GEMM + cell launches   // A/B knob: the one-workgroup-per-sample kernels
   CK(dalloc(ctx, &ctx->a, HB * S));
   CK(dalloc(ctx, &ctx->jv, (size_t)B * M));
   CK(dalloc(ctx, &ctx->j, HB * M));
@@ -293,10 +346,17 @@ int rau_create(const rau_config* cfg, rau_ctx** out) {
   CK(dalloc(ctx, &ctx->dopred, HB));
   CK(dalloc(ctx, &ctx->losses_d, (size_t)H));
   CK(dalloc(ctx, &ctx->hopw_d, (size_t)H));
+  {  // ctx-owned pinned staging for the hop weights: the async upload never reads caller memory
+    hipError_t eh = hipHostMalloc((void**)&ctx->hopw_h, (size_t)2 * H * sizeof(float), hipHostMallocDefault);
+    if (eh != hipSuccess) {
+      rau_destroy(ctx);
+      return fail(RAU_ERR_NOMEM, "hipHostMalloc(hop weights): %s", hipGetErrorString(eh));
+    }
+  }
   CK(dalloc(ctx, &ctx->argmax_d, HB));
   // ---- backward
   CK(dalloc(ctx, &ctx->dpre, HB * M));
-  CK(dalloc(ctx, &ctx->dhn, (size_t)B * R));
+  CK(dalloc(ctx, &ctx->dhn, HB * R));   // dpre Wo for all hops
   CK(dalloc(ctx, &ctx->dg4, HB * 4 * R));
   for (int i = 0; i < 2; ++i) {
     CK(dalloc(ctx, &ctx->dcn[i], (size_t)B * R));
@@ -325,8 +385,18 @@ int rau_create(const rau_config* cfg, rau_ctx** out) {
     for (auto& s : shapes) sl = std::max(sl, gemm_tn_slab_floats(s[0], s[1], s[2]));
     ctx->slab_floats = sl;
     CK(dalloc(ctx, &ctx->slab, sl));
-    ctx->slab3_floats = sl;
-    CK(dalloc(ctx, &ctx->slab3, sl));
+    {  // the weight-gradient stream's workspace also holds the grouped launches' partial slabs
+      TnProblem pr[13];
+      size_t sl3 = sl;
+      int n = mult_wgrad_problems(ctx, pr);
+      for (int hh = 1; hh <= H; ++hh)
+        sl3 = std::max(sl3, gemm_tn_group_slab_floats(pr, n, hh * B));
+      n = enc_wgrad_problems(ctx, 0, pr);
+      for (int tt = 1; tt <= T; ++tt)
+        sl3 = std::max(sl3, gemm_tn_group_slab_floats(pr, n, tt * B));
+      ctx->slab3_floats = sl3;
+      CK(dalloc(ctx, &ctx->slab3, sl3));
+    }
   }
   {
     const int widest = std::max({4 * R, 4 * Rq, K, M, S, A, Q});
@@ -365,6 +435,7 @@ void rau_destroy(rau_ctx* ctx) {
   if (ctx->st3) hipStreamSynchronize(ctx->st3);
   for (auto& g : ctx->graphs) hipGraphExecDestroy(g.second);
   for (void* p : ctx->allocs) hipFree(p);
+  if (ctx->hopw_h) hipHostFree(ctx->hopw_h);
   for (auto& r : ctx->precs) {
     hipEventDestroy(r.a);
     hipEventDestroy(r.b);
@@ -377,6 +448,9 @@ void rau_destroy(rau_ctx* ctx) {
   if (ctx->st3) hipStreamDestroy(ctx->st3);
   for (hipEvent_t e : ctx->evF) hipEventDestroy(e);
   for (hipEvent_t e : ctx->evK) hipEventDestroy(e);
+  for (hipEvent_t e : ctx->evH) hipEventDestroy(e);
+  if (ctx->evHd) hipEventDestroy(ctx->evHd);
+  for (hipEvent_t e : ctx->evEc) hipEventDestroy(e);
   if (ctx->st2) hipStreamDestroy(ctx->st2);
   if (ctx->st) hipStreamDestroy(ctx->st);
   delete ctx;
@@ -583,30 +657,31 @@ int rau_batch_feats(rau_ctx* ctx, float** feats_dev) {
 
 // ================================================================ one hop
 // The recurrence-dependent half of one answering hop (SS:292-307 given this hop's I and
-// P = Wp I + bp): q_embed's recurrent half, attention, attention LSTM, classifier and the
-// criterion head.  Activations land in the ctx's hop-h slots; the new state in c_out/h_out.
-int hop_forward(rau_ctx* ctx, int h, const float* cp, const float* hp, float* c_out, float* h_out,
-                const float* Ih, const float* Pin, const int32_t* labels) {
+// P = Wp I + bp), in two parts:
+//   hop_forward_chain -- what the NEXT hop has to wait for: q_embed's recurrent half, attention,
+//     the attention LSTM (8 dependent launches; next_c / next_h land in c_out / h_out);
+//   hop_forward_head  -- what nothing on the recurrence waits for: merge_feat, out_score,
+//     out_do_pred and the criterion head (SS:277-283, 488, 518), batched over `nh` consecutive
+//     hops ([nh*B] rows) on any stream with its own split-K workspace.
+// rau_forward runs the heads on the weight-gradient stream (idle during the forward pass), so the
+// hop-to-hop critical path is the chain alone; the module-level entry points run both on st.
+int hop_forward_chain(rau_ctx* ctx, int h, const float* cp, const float* hp, float* c_out,
+                      float* h_out, const float* Ih, const float* Pin) {
   const rau_config& c = ctx->cfg;
-  const int B = c.B, S = ctx->Sp, SL = c.S, M = c.M, A = c.A, R = c.R, K = c.K;
+  const int B = c.B, S = ctx->Sp, SL = c.S, M = c.M, A = c.A, R = c.R;
   hipStream_t st = ctx->st;
-  const bool tr = ctx->mode == RAU_MODE_TRAIN;
-  const uint32_t* m_mf = (tr && ctx->mp[RAU_MASK_MF] > 0.f) ? ctx->mbits[RAU_MASK_MF] : nullptr;
-  auto sc = [&](int site) { return 1.f / (1.f - ctx->mp[site]); };
   auto gflop = [](double m, double n, double k) { return 2.0 * m * n * k; };
   const size_t BM_ = (size_t)B * M, BS_ = (size_t)B * S, BR_ = (size_t)B * R;
   float* qf = ctx->qf + (size_t)h * BM_;
   float* ah = ctx->a + (size_t)h * BS_;
   float* jh = ctx->j + (size_t)h * BM_;
   float* g4 = ctx->g4 + (size_t)h * B * 4 * R;
-  float* mfh = ctx->mf + (size_t)h * BM_;
-  float* lg = ctx->logits + (size_t)h * B * K;
   // Split-K partials of several of these GEMMs are summed by their CONSUMER kernel instead of a
   // reduce launch (each launch on this dependent chain costs 8-20 us next to the bulk GEMMs):
   // the slab is carved into four regions so that partials can stay alive side by side.
   const size_t reg = ctx->slab_floats / 4;
   float *slab_u = ctx->slab + reg, *slab_t = ctx->slab + 2 * reg;
-  int ns_u = 0, ns_t = 0, ns_i = 0, ns_c = 0;
+  int ns_u = 0, ns_t = 0, ns_i = 0;
   size_t off[3];
   {  // the three Linears fed by h_prev alone -- q_embed's recurrent half (SS:234), attbymemory
      // (SS:287) and the attention LSTM's h2h (ATTLSTM.lua:7) -- in ONE launch
@@ -636,9 +711,14 @@ int hop_forward(rau_ctx* ctx, int h, const float* cp, const float* hp, float* c_
     ap.z_ns = ns_z; ap.z_bias = ctx->att_mem.b;
     ap.SL = SL;
     ap.u_out = ctx->u + (size_t)h * B * A;   // tanh(P + u) itself is not kept: 25 % less traffic here
-    RUN("att_fwd_fused", 2.0 * B * S * (A + M), ((double)B * A * S + BM_ * S) * 4,
-        att_fwd_fused(st, B, M, A, S, Pin, slab_u, ctx->att_score.W, ctx->att_score.b, slab_z, Ih, qf,
-                      nullptr, ah, ctx->jv, ap));
+    if (ctx->att_fused)
+      RUN("att_fwd_fused", 2.0 * B * S * (A + M), ((double)B * A * S + BM_ * S) * 4,
+          att_fwd_fused(st, B, M, A, S, Pin, slab_u, ctx->att_score.W, ctx->att_score.b, slab_z, Ih, qf,
+                        nullptr, ah, ctx->jv, ap));
+    else
+      RUN("att_fwd_split", 2.0 * B * S * (A + M), ((double)B * A * S + BM_ * S) * 4,
+          att_fwd_split(st, B, M, A, S, Pin, slab_u, ctx->att_score.W, ctx->att_score.b, slab_z, Ih, qf,
+                        ah, ctx->jv, ctx->att_part, ap));
   }
   {  // classifier SS:265-283
     LINOPTS(o);
@@ -663,35 +743,73 @@ int hop_forward(rau_ctx* ctx, int h, const float* cp, const float* hp, float* c_
     C.drop_out = nullptr; C.mask = nullptr; C.mask_e0 = 0; C.mscale = 1.f;
     RUN("lstm_fwd", 0, BR_ * 4.0 * 10, lstm_fwd_multi(st, GATES_ATT, B, R, cells));
   }
+  return RAU_OK;
+}
+
+// merge_feat = dropout(j + h' Wo^T + bo), logits = merge_feat Wc^T + bc, do_pred, cross-entropy +
+// first-max argmax for hops [h0, h0 + nh): rows = nh * B.  h' rows are ctx->hh slots h0+1 .. (the
+// chain's h_out), `ws` a split-K workspace of >= 2 regions of `reg` floats owned by stream `s`.
+int hop_forward_head(rau_ctx* ctx, hipStream_t s, float* ws, size_t reg, int h0, int nh,
+                     const int32_t* labels) {
+  const rau_config& c = ctx->cfg;
+  const int B = c.B, M = c.M, R = c.R, K = c.K;
+  const bool tr = ctx->mode == RAU_MODE_TRAIN;
+  const uint32_t* m_mf = (tr && ctx->mp[RAU_MASK_MF] > 0.f) ? ctx->mbits[RAU_MASK_MF] : nullptr;
+  auto gflop = [](double m, double n, double k) { return 2.0 * m * n * k; };
+  const size_t BM_ = (size_t)B * M, BR_ = (size_t)B * R;
+  const int rows = nh * B;
+  const float* hnew = ctx->hh + (size_t)(h0 + 1) * BR_;
+  const float* jh = ctx->j + (size_t)h0 * BM_;
+  float* mfh = ctx->mf + (size_t)h0 * BM_;
+  float* lg = ctx->logits + (size_t)h0 * B * K;
+  int ns_c = 0;
   {
-    LINOPTS(o);
-    o.slab_floats = reg;
+    LinOpts o;
+    o.slab = ws; o.slab_floats = reg;
     o.bias = ctx->lstm_out.b;
     o.addend = jh;
     o.add_rs = M;
     o.emask = m_mf;
-    o.emask_e0 = (size_t)h * BM_;
-    o.emscale = sc(RAU_MASK_MF);
-    RUN("small_gemm", gflop(B, M, R), 0,
-        gemm_nt(st, B, M, R, h_out, R, ctx->lstm_out.W, R, mfh, M, o));
+    o.emask_e0 = (size_t)h0 * BM_;
+    o.emscale = 1.f / (1.f - ctx->mp[RAU_MASK_MF]);
+    RUNS(s, "head_gemm", gflop(rows, M, R), 0,
+         gemm_nt(s, rows, M, R, hnew, R, ctx->lstm_out.W, R, mfh, M, o));
   }
   {  // out_score SS:280: partials finished (+ bias) by the criterion-head kernel
     LinOpts o;
-    o.slab = slab_u; o.slab_floats = reg; o.defer_splits = &ns_c;
-    RUN("small_gemm", gflop(B, K, M), 0, gemm_nt(st, B, K, M, mfh, M, ctx->cls.W, M, lg, K, o));
+    o.slab = ws + reg; o.slab_floats = reg; o.defer_splits = &ns_c;
+    RUNS(s, "head_gemm", gflop(rows, K, M), 0,
+         gemm_nt(s, rows, K, M, mfh, M, ctx->cls.W, M, lg, K, o));
   }
-  RUN("ce_fwd", 0, (double)B * K * 12,
-      ce_fwd(st, B, K, M, lg, labels, mfh, ctx->do_pred.W,
-             ctx->do_pred.b, ctx->dl + (size_t)h * B * K, ctx->lossrow + (size_t)h * B,
-             ctx->argmax_d + (size_t)h * B, ctx->dopred + (size_t)h * B, slab_u, ns_c, ctx->cls.b,
-             lg));
+  RUNS(s, "ce_fwd", 0, (double)rows * K * 12,
+       ce_fwd(s, rows, K, M, lg, labels, mfh, ctx->do_pred.W, ctx->do_pred.b,
+              ctx->dl + (size_t)h0 * B * K, ctx->lossrow + (size_t)h0 * B,
+              ctx->argmax_d + (size_t)h0 * B, ctx->dopred + (size_t)h0 * B, ws + reg, ns_c,
+              ctx->cls.b, lg, B));
   return RAU_OK;
+}
+
+int hop_forward(rau_ctx* ctx, int h, const float* cp, const float* hp, float* c_out, float* h_out,
+                const float* Ih, const float* Pin, const int32_t* labels) {
+  if (int rc = hop_forward_chain(ctx, h, cp, hp, c_out, h_out, Ih, Pin)) return rc;
+  if (h_out != ctx->hh + (size_t)(h + 1) * ctx->cfg.B * ctx->cfg.R)
+    return fail(RAU_ERR_INVALID, "hop_forward: h_out must be the ctx's hop slot");
+  const size_t reg = ctx->slab_floats / 4;
+  return hop_forward_head(ctx, ctx->st, ctx->slab, reg, h, 1, labels);
 }
 
 // Backward of hop_forward (hand-derived, SURVEY 8a "exact backward of one hop"): from the
 // gradients at {logits, next_c, next_h} to dpre, dg4, dj, dz, dS (in T), du, dq~ in the
-// hop-h slots and {dc_prev, dh_prev} in g.dc_out / g.dh_out.  Weight gradients and the
-// 1x1-conv gradients are formed by the callers from those slots.
+// hop-h slots and {dc_prev, dh_prev}.  Weight gradients and the 1x1-conv gradients are formed
+// by the callers from those slots.
+//
+// What is on the recurrence's critical path is kept to 10 dependent launches:
+//   * dpre = (dl Wc) (.) mask and dhn = dpre Wo do not depend on the recurrence; the step-level
+//     caller forms them for all hops at once up front (g.dpre_ready / g.dhn_all);
+//   * the three contributions to dh_prev (dg Wr, dz Wm, dq~ Wh) stay K-split partials, laid out
+//     back to back, and are summed by the NEXT hop's lstm_bwd (g.dh_part_*), so none of them
+//     costs a reduce launch; dj Wf's partials are summed inside att_bwd_fused;
+//   * dg Wx and dg Wr share their A operand: one batched launch when M == R.
 int hop_backward(rau_ctx* ctx, int h, const float* cp, const float* Ih, const HopGrad& g) {
   const rau_config& c = ctx->cfg;
   const int B = c.B, S = ctx->Sp, SL = c.S, M = c.M, A = c.A, R = c.R, K = c.K;
@@ -712,62 +830,119 @@ int hop_backward(rau_ctx* ctx, int h, const float* cp, const float* Ih, const Ho
   float* duh = ctx->du + (size_t)h * B * A;
   float* dqt = ctx->dqt + (size_t)h * BM_;
   float* dc_out = g.dc_out;
-  float* dh_out = g.dh_out;
-  {  // dmf = dlogits Wc ; dpre = dmf (.) mask   (do_pred grad is zero, SS:566)
-    LINOPTS(o);
-    o.addend = g.dmf_add;   // module-level callers: gradient through do_pred (zero in feval)
-    o.add_rs = M;
-    o.emask = m_mf;
-    o.emask_e0 = (size_t)h * BM_;
-    o.emscale = sc(RAU_MASK_MF);
-    RUN("small_gemm", gflop(B, M, K), 0,
-        gemm_nn(st, B, M, K, g.dl, K, ctx->cls.W, M, dpre, M, o));
-  }
-  {  // dhn = dpre Wo + dh_next, the K-split partials of dpre Wo summed inside lstm_bwd
+  // split-K workspace: region 0 = partials that are reduced right away (LINOPTS default) or
+  // consumed by the next kernel; regions 1..3 = this hop's dj partials followed by the dh_prev
+  // partials, which live until the next hop's lstm_bwd has read them
+  const size_t reg = ctx->slab_floats / 4;
+  float* X = ctx->slab + reg;
+  const size_t Xcap = 3 * reg;
+  if (!g.dpre_ready) {
+    {  // dmf = dlogits Wc ; dpre = dmf (.) mask   (do_pred grad is zero, SS:566)
+      LINOPTS(o);
+      o.slab_floats = reg;
+      o.addend = g.dmf_add;   // module-level callers: gradient through do_pred (zero in feval)
+      o.add_rs = M;
+      o.emask = m_mf;
+      o.emask_e0 = (size_t)h * BM_;
+      o.emscale = sc(RAU_MASK_MF);
+      RUN("small_gemm", gflop(B, M, K), 0,
+          gemm_nn(st, B, M, K, g.dl, K, ctx->cls.W, M, dpre, M, o));
+    }
+    // dhn = dpre Wo + dh_next, the K-split partials of dpre Wo summed inside lstm_bwd
     int nsp = 0;
     LINOPTS(o);
+    o.slab_floats = reg;
     o.defer_splits = &nsp;
     RUN("small_gemm", gflop(B, R, M), 0, gemm_nn(st, B, R, M, dpre, M, ctx->lstm_out.W, R, ctx->dhn, R, o));
     RUN("lstm_bwd", 0, BR_ * 4.0 * 12,
         lstm_bwd(st, GATES_ATT, B, R, g4, cp, R, ctx->tc + (size_t)h * BR_, nullptr, R, g.dh_next,
                  g.dc_next, dg4, dc_out, nullptr, 0, nullptr, nullptr, 0, ctx->slab, nsp));
+  } else {
+    // dhn rows of this hop + the previous hop_backward's dh_prev partials (+ dh_next if given)
+    RUN("lstm_bwd", 0, BR_ * 4.0 * 12,
+        lstm_bwd(st, GATES_ATT, B, R, g4, cp, R, ctx->tc + (size_t)h * BR_,
+                 g.dhn_all + (size_t)h * BR_, R, g.dh_next, g.dc_next, dg4, dc_out, nullptr, 0,
+                 nullptr, nullptr, 0, g.dh_part, g.dh_part_ns));
   }
-  {  // dj = dpre + dg Wx ; dh_prev = dg Wr
-    LINOPTS(o);
+  // dj partials = dg Wx ; dh_prev partials #1 = dg Wr
+  int ns_j = 0, ns_h = 0;
+  float* dhp = nullptr;      // start of this hop's dh_prev partials [ns_h][B][R]
+  if (M == R) {
+    const float* Ap[2] = {dg4, dg4};
+    const float* Wp[2] = {ctx->lstm_i2h.W, ctx->lstm_h2h.W};
+    RUN("small_gemm", 2 * gflop(B, M, 4 * R), 0,
+        gemm_nn_batched_deferred(st, 2, B, M, 4 * R, Ap, 4 * R, Wp, M, X, Xcap / 2, &ns_j));
+    dhp = X + (size_t)ns_j * BM_;
+    ns_h = ns_j;
+  } else {
+    LinOpts o1;
+    o1.slab = X; o1.slab_floats = Xcap / 4; o1.defer_splits = &ns_j;
+    RUN("small_gemm", gflop(B, M, 4 * R), 0,
+        gemm_nn(st, B, M, 4 * R, dg4, 4 * R, ctx->lstm_i2h.W, M, djh, M, o1));
+    dhp = X + (size_t)ns_j * BM_;
+    LinOpts o2;
+    o2.slab = dhp; o2.slab_floats = Xcap / 4; o2.defer_splits = &ns_h;
+    RUN("small_gemm", gflop(B, R, 4 * R), 0,
+        gemm_nn(st, B, R, 4 * R, dg4, 4 * R, ctx->lstm_h2h.W, R, nullptr, R, o2));
+  }
+  {  // dj = dpre + sum of partials
+    LinOpts o;
     o.addend = dpre;
     o.add_rs = M;
-    RUN("small_gemm", gflop(B, M, 4 * R), 0,
-        gemm_nn(st, B, M, 4 * R, dg4, 4 * R, ctx->lstm_i2h.W, M, djh, M, o));
-    LINOPTS(o2);
-    RUN("small_gemm", gflop(B, R, 4 * R), 0,
-        gemm_nn(st, B, R, 4 * R, dg4, 4 * R, ctx->lstm_h2h.W, R, dh_out, R, o2));
+    RUN("lin_reduce", 0, 0, lin_reduce_epilogue(st, B, M, ns_j, X, djh, M, o));
   }
-  {  // da = dj Wf  (+ attselect term below) (+ gradient at the attprob OUTPUT, zero in feval)
+  int ns_a = 0;
+  {  // da = dj Wf  (+ attselect term and the gradient at the attprob OUTPUT inside att_bwd_fused)
     LINOPTS(o);
-    o.addend = g.da_out;
-    o.add_rs = S;
+    o.slab_floats = reg;
+    o.defer_splits = &ns_a;
     RUN("small_gemm", gflop(B, SL, M), 0,
         gemm_nn(st, B, SL, M, djh, M, ctx->feat_attprob.W, SL, ctx->da_lin, S, o));
   }
-  RUN("att_bwd_fused", 2.0 * B * S * (A + M), ((double)B * A * S * 2 + BM_ * S) * 4,
-      att_bwd_fused(st, B, M, A, S, Ih, djh, ah, ctx->da_lin, ctx->att_score.W, Th, dzh, duh,
-                    ctx->dwsp + (size_t)h * B * A, ctx->I_shared ? ctx->P0 : Th,
-                    ctx->u + (size_t)h * B * A));
-  {  // dh_prev += dz Wm
-    LINOPTS(o);
-    o.accumulate = 1;
-    RUN("small_gemm", gflop(B, R, SL), 0, gemm_nn(st, B, R, SL, dzh, S, ctx->att_mem.W, R, dh_out, R, o));
+  if (ctx->att_fused)
+    RUN("att_bwd_fused", 2.0 * B * S * (A + M), ((double)B * A * S * 2 + BM_ * S) * 4,
+        att_bwd_fused(st, B, M, A, S, Ih, djh, ah, ctx->slab, ctx->att_score.W, Th, dzh, duh,
+                      ctx->dwsp + (size_t)h * B * A, ctx->I_shared ? ctx->P0 : Th,
+                      ctx->u + (size_t)h * B * A, ns_a, SL, g.da_out));
+  else
+    RUN("att_bwd_split", 2.0 * B * S * (A + M), ((double)B * A * S * 2 + BM_ * S) * 4,
+        att_bwd_split(st, B, M, A, S, Ih, djh, ah, ctx->slab, ctx->att_score.W, Th, dzh, duh,
+                      ctx->dwsp + (size_t)h * B * A, ctx->I_shared ? ctx->P0 : Th,
+                      ctx->u + (size_t)h * B * A, ctx->att_part, ns_a, SL, g.da_out));
+  const size_t used = (size_t)(dhp - X);
+  {  // dh_prev partials #2 = dz Wm
+    int ns = 0;
+    LinOpts o;
+    o.slab = dhp + (size_t)ns_h * BR_;
+    o.slab_floats = (Xcap - used) / 3;
+    o.defer_splits = &ns;
+    RUN("small_gemm", gflop(B, R, SL), 0, gemm_nn(st, B, R, SL, dzh, S, ctx->att_mem.W, R, nullptr, R, o));
+    ns_h += ns;
   }
   {  // dq~ = (dj + du Wa) (1 - qf^2)
     LINOPTS(o);
+    o.slab_floats = reg;
     o.addend = djh;
     o.add_rs = M;
     o.ymul = qf;
     o.y_rs = M;
     RUN("small_gemm", gflop(B, M, A), 0, gemm_nn(st, B, M, A, duh, A, ctx->att_q.W, M, dqt, M, o));
-    LINOPTS(o2);
-    o2.accumulate = 1;
-    RUN("small_gemm", gflop(B, R, M), 0, gemm_nn(st, B, R, M, dqt, M, ctx->h_proj.W, R, dh_out, R, o2));
+  }
+  {  // dh_prev partials #3 = dq~ Wh
+    int ns = 0;
+    LinOpts o;
+    o.slab = dhp + (size_t)ns_h * BR_;
+    o.slab_floats = (Xcap - used) / 3;
+    o.defer_splits = &ns;
+    RUN("small_gemm", gflop(B, R, M), 0, gemm_nn(st, B, R, M, dqt, M, ctx->h_proj.W, R, nullptr, R, o));
+    ns_h += ns;
+  }
+  if (g.dh_part_out) {   // the next hop_backward's lstm_bwd sums them
+    *g.dh_part_out = dhp;
+    *g.dh_part_ns_out = ns_h;
+  } else {               // module-level callers want dh_prev itself
+    LinOpts o;
+    RUN("lin_reduce", 0, 0, lin_reduce_epilogue(st, B, R, ns_h, dhp, g.dh_out, R, o));
   }
   return RAU_OK;
 }
@@ -803,45 +978,13 @@ int rau_forward(rau_ctx* ctx) {
   // the per-hop half (+u, tanh, score, softmax, context) is att_fwd_fused.
   // Hops are launched in groups of `hop_group` so hop h's chain can start as soon
   // as its group is done while the bulk stream works on the later groups.
-  ctx->I_shared = (m_x == nullptr);
-  if (ctx->I_shared) {   // evaluate mode: one launch group
-    ctx->cur.assign(H, 0);
-    ctx->cur[0] = H;
-  } else {
-    ctx->cur = ctx->groups;
-  }
-  const std::vector<int>& gsz = ctx->cur;
-  {
-    hipStream_t sb = ctx->st2;
-    HIPC(hipEventRecord(ctx->evA, st));
-    HIPC(hipStreamWaitEvent(sb, ctx->evA, 0));
-    RUNS(sb, "transpose", 0, (double)M * D * 8, transpose2d(sb, M, D, ctx->i_embed.W, ctx->WiT));
-    RUNS(sb, "transpose", 0, (double)A * M * 8, transpose2d(sb, A, M, ctx->att_i.W, ctx->WpT));
-    if (m_x)
-      RUNS(sb, "dropout_features", 0, (double)(H + 1) * B * D * S * 4,
-           dropout_features(sb, H, (size_t)B * D * S, ctx->feats, m_x, sc(RAU_MASK_X), ctx->xd, 0, SL,
-                            S));
-    for (int h0 = 0; h0 < H; h0 += gsz[h0]) {
-      const int nBI = ctx->I_shared ? B : gsz[h0] * B;
-      const size_t hb = ctx->I_shared ? 0 : (size_t)h0 * B;  // first (hop, sample) row
-      const float* xin = m_x ? ctx->xd + hb * D * S : ctx->feats;
-      float* Ig = ctx->I + hb * M * S;
-      float* Pg = ctx->I_shared ? ctx->P0 : ctx->T + hb * A * S;
-      RUNS(sb, "conv_embed_fwd", gflop(M, (double)nBI * S, D),
-           ((double)nBI * D * S + (double)nBI * M * S) * 4,
-           conv_embed_fwd(sb, nBI, D, S, M, xin, ctx->WiT, ctx->i_embed.b, Ig, ctx->bf16));
-      RUNS(sb, "conv_att_pre", gflop(A, (double)nBI * S, M),
-           ((double)nBI * M * S + (double)nBI * A * S) * 4,
-           conv_att_pre(sb, nBI, M, S, A, Ig, ctx->WpT, ctx->att_i.b, Pg, ctx->bf16));
-      HIPC(hipEventRecord(ctx->evF[h0], sb));
-    }
-  }
-
+  bool enc_done = false;
   // ---------------- encoder, SS:443-462
   // Layer-1 cell t+1 and layer-2 cell t do not depend on each other, so the two layers
   // advance as a wavefront: per step ONE batched split-K GEMM (h1 W_h2h1^T for layer 1;
   // x2 W_i2h2^T and h2 W_h2h2^T for layer 2; same shapes) and ONE two-cell LSTM kernel
   // that sums the partials -- TL+1 steps of 2 launches instead of 2*TL steps of 2.
+  auto encoder_forward = [&]() -> int {
   if (TL > 0) {
     const int rows = TL * B;
     const size_t G4 = (size_t)B * 4 * Rq;
@@ -855,6 +998,42 @@ int rau_forward(rau_ctx* ctx) {
       RUN("enc_i2h_gemm", gflop(rows, 4 * Rq, E), 0,
           gemm_nt(st, rows, 4 * Rq, E, ctx->we, E, ctx->i2h[0].W, E, ctx->G1, 4 * Rq, o));
     }
+    if (ctx->enc_fused) {
+      // one launch per wavefront step: gate GEMM + cell fused (lstm_fused.hip)
+      for (int s = 1; s <= TL + 1; ++s) {
+        LstmStepParams sp{};
+        sp.B = B; sp.R = Rq;
+        double fl = 0;
+        if (s <= TL) {  // layer-1 cell t = s: G1[t] + h1[t-1] W_h2h1^T
+          LstmStepSide& C1 = sp.s[sp.n++];
+          C1.nsrc = s >= 2 ? 1 : 0;           // h1[0] = 0
+          C1.A[0] = ctx->h1 + (size_t)(s - 1) * BRq; C1.W[0] = ctx->h2h[0].W; C1.K[0] = Rq;
+          C1.pre = ctx->G1 + (size_t)(s - 1) * G4;
+          C1.gates = ctx->G1 + (size_t)(s - 1) * G4;
+          C1.c_prev = ctx->c1 + (size_t)(s - 1) * BRq;
+          C1.c = ctx->c1 + (size_t)s * BRq; C1.h = ctx->h1 + (size_t)s * BRq;
+          C1.tanhc = ctx->tc1 + (size_t)(s - 1) * BRq;
+          C1.drop_out = ctx->x2 + (size_t)(s - 1) * BRq;   // layer-2 input, DeepLSTM.lua:39
+          C1.mask = m_rnn; C1.mask_e0 = (size_t)(s - 1) * BRq; C1.mscale = sc(RAU_MASK_RNN);
+          fl += C1.nsrc * gflop(B, 4 * Rq, Rq);
+        }
+        if (s >= 2) {  // layer-2 cell t = s - 1: b + x2[t] W_i2h2^T + h2[t-1] W_h2h2^T
+          const int t = s - 1;
+          LstmStepSide& C2 = sp.s[sp.n++];
+          C2.nsrc = s >= 3 ? 2 : 1;           // h2[0] = 0
+          C2.A[0] = ctx->x2 + (size_t)(t - 1) * BRq; C2.W[0] = ctx->i2h[1].W; C2.K[0] = Rq;
+          C2.A[1] = ctx->h2 + (size_t)(t - 1) * BRq; C2.W[1] = ctx->h2h[1].W; C2.K[1] = Rq;
+          C2.pre = nullptr; C2.b1 = ctx->i2h[1].b; C2.b2 = ctx->h2h[1].b;
+          C2.gates = ctx->G2 + (size_t)(t - 1) * G4;
+          C2.c_prev = ctx->c2 + (size_t)(t - 1) * BRq;
+          C2.c = ctx->c2 + (size_t)t * BRq; C2.h = ctx->h2 + (size_t)t * BRq;
+          C2.tanhc = ctx->tc2 + (size_t)(t - 1) * BRq;
+          C2.drop_out = nullptr; C2.mask = nullptr; C2.mask_e0 = 0; C2.mscale = 1.f;
+          fl += C2.nsrc * gflop(B, 4 * Rq, Rq);
+        }
+        RUN("enc_step_fused", fl, 0, lstm_step_fused(st, GATES_DEEP, sp));
+      }
+    } else
     for (int s = 1; s <= TL + 1; ++s) {
       const float* Ap[3];
       const float* Wp[3];
@@ -898,6 +1077,51 @@ int rau_forward(rau_ctx* ctx) {
       RUN("lstm_fwd", 0, BRq * 4.0 * 10 * cells.n, lstm_fwd_multi(st, GATES_DEEP, B, Rq, cells));
     }
   }
+  return 0;
+  };
+  ctx->I_shared = (m_x == nullptr);
+  if (ctx->I_shared) {   // evaluate mode: one launch group
+    ctx->cur.assign(H, 0);
+    ctx->cur[0] = H;
+  } else {
+    ctx->cur = ctx->groups;
+  }
+  const std::vector<int>& gsz = ctx->cur;
+  {
+    hipStream_t sb = ctx->st2;
+    HIPC(hipEventRecord(ctx->evA, st));
+    HIPC(hipStreamWaitEvent(sb, ctx->evA, 0));
+    static const bool enc_first = std::getenv("RAU_ENC_FIRST") != nullptr;
+    if (enc_first && TL > 0) {   // A/B knob: the encoder gets the machine to itself first
+      if (int rc = encoder_forward()) return rc;
+      HIPC(hipEventRecord(ctx->evA, st));
+      HIPC(hipStreamWaitEvent(sb, ctx->evA, 0));
+      enc_done = true;
+    }
+    RUNS(sb, "transpose", 0, (double)M * D * 8, transpose2d(sb, M, D, ctx->i_embed.W, ctx->WiT));
+    RUNS(sb, "transpose", 0, (double)A * M * 8, transpose2d(sb, A, M, ctx->att_i.W, ctx->WpT));
+    if (m_x)
+      RUNS(sb, "dropout_features", 0, (double)(H + 1) * B * D * S * 4,
+           dropout_features(sb, H, (size_t)B * D * S, ctx->feats, m_x, sc(RAU_MASK_X), ctx->xd, 0, SL,
+                            S));
+    for (int h0 = 0; h0 < H; h0 += gsz[h0]) {
+      const int nBI = ctx->I_shared ? B : gsz[h0] * B;
+      const size_t hb = ctx->I_shared ? 0 : (size_t)h0 * B;  // first (hop, sample) row
+      const float* xin = m_x ? ctx->xd + hb * D * S : ctx->feats;
+      float* Ig = ctx->I + hb * M * S;
+      float* Pg = ctx->I_shared ? ctx->P0 : ctx->T + hb * A * S;
+      RUNS(sb, "conv_embed_fwd", gflop(M, (double)nBI * S, D),
+           ((double)nBI * D * S + (double)nBI * M * S) * 4,
+           conv_embed_fwd(sb, nBI, D, S, M, xin, ctx->WiT, ctx->i_embed.b, Ig, ctx->bf16));
+      RUNS(sb, "conv_att_pre", gflop(A, (double)nBI * S, M),
+           ((double)nBI * M * S + (double)nBI * A * S) * 4,
+           conv_att_pre(sb, nBI, M, S, A, Ig, ctx->WpT, ctx->att_i.b, Pg, ctx->bf16));
+      HIPC(hipEventRecord(ctx->evF[h0], sb));
+    }
+  }
+
+  if (!enc_done)
+    if (int rc = encoder_forward()) return rc;
   RUN("gather_q", 0, (double)B * Q * 8,
       gather_q(st, B, Rq, TL, ctx->lens_d, ctx->c1, ctx->h1, ctx->c2, ctx->h2, ctx->q));
 
@@ -918,19 +1142,51 @@ int rau_forward(rau_ctx* ctx) {
   // Evaluate mode: dropout is the identity, so I is hop-invariant and computed once.
   HIPC(hipMemsetAsync(ctx->cc, 0, BR_ * sizeof(float), st));  // att_c, att_h zeros SS:362-365
   HIPC(hipMemsetAsync(ctx->hh, 0, BR_ * sizeof(float), st));
+  const int32_t* labels = ctx->have_labels ? ctx->labels_d : nullptr;
+  const size_t reg3 = ctx->slab3_floats / 4;
+  const int head_max = (int)std::max<size_t>(1, reg3 / ((size_t)B * c.K));  // rows the logits slab holds
+  int gstart = 0;
   for (int h = 0; h < H; ++h) {
-    if (gsz[h]) HIPC(hipStreamWaitEvent(st, ctx->evF[h], 0));  // this group's I and P are ready
-    if (int rc = hop_forward(ctx, h, ctx->cc + (size_t)h * BR_, ctx->hh + (size_t)h * BR_,
-                             ctx->cc + (size_t)(h + 1) * BR_, ctx->hh + (size_t)(h + 1) * BR_,
-                             ctx->I + (ctx->I_shared ? 0 : (size_t)h * BM_ * S),
-                             ctx->I_shared ? ctx->P0 : ctx->T + (size_t)h * B * A * S,
-                             ctx->have_labels ? ctx->labels_d : nullptr))
+    if (gsz[h]) {
+      HIPC(hipStreamWaitEvent(st, ctx->evF[h], 0));  // this group's I and P are ready
+      gstart = h;
+    }
+    if (int rc = hop_forward_chain(ctx, h, ctx->cc + (size_t)h * BR_, ctx->hh + (size_t)h * BR_,
+                                   ctx->cc + (size_t)(h + 1) * BR_, ctx->hh + (size_t)(h + 1) * BR_,
+                                   ctx->I + (ctx->I_shared ? 0 : (size_t)h * BM_ * S),
+                                   ctx->I_shared ? ctx->P0 : ctx->T + (size_t)h * B * A * S))
       return rc;
+    // classifier + criterion heads of the finished hops: nothing on the recurrence waits for
+    // them, so they run on the weight-gradient stream (idle in the forward pass), batched over
+    // the hops of a launch group
+    const bool group_end = h + 1 == H || gsz[h + 1] != 0;
+    if (group_end || h + 1 - gstart >= head_max) {
+      HIPC(hipEventRecord(ctx->evH[h], st));
+      HIPC(hipStreamWaitEvent(ctx->st3, ctx->evH[h], 0));
+      for (int h0 = gstart; h0 <= h; h0 += head_max)
+        if (int rc = hop_forward_head(ctx, ctx->st3, ctx->slab3, reg3, h0,
+                                      std::min(head_max, h + 1 - h0), labels))
+          return rc;
+      gstart = h + 1;
+    }
   }
+  HIPC(hipEventRecord(ctx->evHd, ctx->st3));
+  HIPC(hipStreamWaitEvent(st, ctx->evHd, 0));   // callers order against st only
   if (ctx->have_labels)
     RUN("loss_reduce", 0, 0, loss_reduce(st, H, B, ctx->lossrow, ctx->losses_d));
   ctx->fwd_done = true;
   return RAU_OK;
+}
+
+// The caller's hop_w may be a temporary (and may be pinned memory, for which an async copy really
+// is asynchronous): stage it in the ctx's own pinned buffer first.  Two slots, alternated, so the
+// copy of step n is never overwritten by the host while step n+1's call prepares its own.
+static int upload_hop_weights(rau_ctx* ctx, const float* hop_w) {
+  const int H = ctx->cfg.H;
+  float* stage = ctx->hopw_h + (size_t)(ctx->hopw_slot ^= 1) * H;
+  std::memcpy(stage, hop_w, (size_t)H * sizeof(float));
+  HIPC(hipMemcpyAsync(ctx->hopw_d, stage, (size_t)H * sizeof(float), hipMemcpyHostToDevice, ctx->st));
+  return 0;
 }
 
 // =============================================================== backward
@@ -956,8 +1212,9 @@ int rau_backward(rau_ctx* ctx, const float* hop_w) {
   ctx->fwd_done = false;  // dl is scaled in place below: one backward per forward
 
   // dpred:mul(w[h])  SS:569 / MS:568-570 / Full:587-589
-  if (!ctx->capturing)   // (rau_graph_step uploads the weights before it launches the graph)
-    HIPC(hipMemcpyAsync(ctx->hopw_d, hop_w, H * sizeof(float), hipMemcpyHostToDevice, st));
+  if (!ctx->capturing) {  // (rau_graph_step uploads the weights before it launches the graph)
+    if (int rc = upload_hop_weights(ctx, hop_w)) return rc;
+  }
   RUN("scale_hops", 0, (double)H * B * K * 8, scale_hops(st, H, (size_t)B * K, ctx->hopw_d, ctx->dl));
 
   // Hops behind the last one with a non-zero loss weight receive no gradient at all (zero
@@ -968,24 +1225,42 @@ int rau_backward(rau_ctx* ctx, const float* hop_w) {
     if (hop_w[h] != 0.f) HA = h + 1;
 
   // ---------------- RAU BPTT, SS:561-578
+  // Off the recurrence: dpre = (dl Wc) (.) mask and dhn = dpre Wo for all active hops at once
+  const uint32_t* m_mf = mk(RAU_MASK_MF);
+  if (HA > 0) {
+    LINOPTS(o);
+    o.emask = m_mf;
+    o.emask_e0 = 0;
+    o.emscale = sc(RAU_MASK_MF);
+    RUN("head_dgrad", gflop(HA * B, M, K), 0,
+        gemm_nn(st, HA * B, M, K, ctx->dl, K, ctx->cls.W, M, ctx->dpre, M, o));
+    LINOPTS(o2);
+    RUN("head_dgrad", gflop(HA * B, R, M), 0,
+        gemm_nn(st, HA * B, R, M, ctx->dpre, M, ctx->lstm_out.W, R, ctx->dhn, R, o2));
+  }
   const float* dc_next = nullptr;  // grad_att_c / grad_att_h zeros, SS:561-562
-  const float* dh_next = nullptr;
+  float* dh_part = nullptr;        // gradient at next_h: K-split partials left by the previous hop
+  int dh_part_ns = 0;
   for (int h = HA - 1; h >= 0; --h) {
     float* dc_out = ctx->dcn[h & 1];
-    float* dh_out = ctx->dhp[h & 1];
     {
       HopGrad g{};
       g.dl = ctx->dl + (size_t)h * B * K;
       g.dc_next = dc_next;
-      g.dh_next = dh_next;
+      g.dh_next = nullptr;
       g.dc_out = dc_out;
-      g.dh_out = dh_out;
+      g.dh_out = nullptr;
+      g.dpre_ready = 1;
+      g.dhn_all = ctx->dhn;
+      g.dh_part = dh_part;
+      g.dh_part_ns = dh_part_ns;
+      g.dh_part_out = &dh_part;
+      g.dh_part_ns_out = &dh_part_ns;
       if (int rc = hop_backward(ctx, h, ctx->cc + (size_t)h * BR_,
                                 ctx->I + (ctx->I_shared ? 0 : (size_t)h * BM_ * S), g))
         return rc;
     }
     dc_next = dc_out;
-    dh_next = dh_out;
     // ---------------- bulk stream: the 1x1-conv gradients are off the recurrence's
     // critical path (dZ only feeds weight gradients; the feature-map gradient is dead,
     // SS:579, never formed).  As soon as a hop group's chain is done its conv gradients
@@ -1053,21 +1328,13 @@ int rau_backward(rau_ctx* ctx, const float* hop_w) {
       HIPC(hipEventRecord(ctx->evM3, sw));
       return 0;
     }
-    const float* hprev = ctx->hh;            // h_{0..H-1}
-    const float* hnew = ctx->hh + BR_;       // h_{1..H}
-    struct WG { Lin* l; const float* dY; long ldy; const float* X; long ldx; };
-    const WG wgs[] = {
-        {&ctx->cls, ctx->dl, K, ctx->mf, M},             {&ctx->lstm_out, ctx->dpre, M, hnew, R},
-        {&ctx->lstm_i2h, ctx->dg4, 4 * R, ctx->j, M},    {&ctx->lstm_h2h, ctx->dg4, 4 * R, hprev, R},
-        {&ctx->feat_attprob, ctx->dj, M, ctx->a, S},     {&ctx->att_mem, ctx->dz, S, hprev, R},
-        {&ctx->att_q, ctx->du, A, ctx->qf, M},           {&ctx->q_proj, ctx->dqt, M, ctx->qd, Q},
-        {&ctx->h_proj, ctx->dqt, M, hprev, R}};
-    for (const WG& w : wgs) {
-      // dW += dY^T X, and db += column sums of dY from the same pass over dY (dz and a are
-      // pitched: their leading dimension is the position pitch, the Linear's size the logical S)
-      RUNS(sw, "wgrad_gemm", gflop(w.l->out, w.l->in, rows), 0,
-          gemm_tn_acc(sw, w.l->out, w.l->in, rows, w.dY, w.ldy, w.X, w.ldx, w.l->dW, w.l->in,
-                      ctx->slab3, w.l->db));
+    {  // dW += dY^T X and db += column sums of dY for the nine Linears: one grouped launch
+      TnProblem pr[13];
+      const int np = mult_wgrad_problems(ctx, pr);
+      double fl = 0;
+      for (int i = 0; i < np; ++i) fl += gflop(pr[i].M, pr[i].N, rows);
+      RUNS(sw, "wgrad_gemm", fl, 0,
+           gemm_tn_group_acc(sw, pr, np, rows, ctx->slab3, ctx->slab3_floats));
     }
     // att_score: dws = sum dz T ; dbs = sum dz.  att_i bias: sum dS.  i_embed bias: sum dZ.
     RUNS(sw, "colsum", 0, (double)rows * A * 4, colsum_acc(sw, rows, A, ctx->dwsp, A, ctx->att_score.dW, ctx->coltmp3));
@@ -1099,18 +1366,19 @@ int rau_backward(rau_ctx* ctx, const float* hop_w) {
       HIPC(hipStreamWaitEvent(sw, ev, 0));
       const size_t r0 = (size_t)t_lo * B;
       const int nr = (t_hi - t_lo) * B;
-      struct WG { Lin* l; const float* dY; const float* X; };
-      const WG wgs[] = {{&ctx->i2h[0], ctx->dG1, ctx->we}, {&ctx->h2h[0], ctx->dG1, ctx->h1},
-                        {&ctx->i2h[1], ctx->dG2, ctx->x2}, {&ctx->h2h[1], ctx->dG2, ctx->h2}};
-      for (const WG& w : wgs) {
-        // dW += dY^T X, and db += column sums of dY from the same pass over dY
-        RUNS(sw, "wgrad_gemm", gflop(w.l->out, w.l->in, nr), 0,
-            gemm_tn_acc(sw, w.l->out, w.l->in, nr, w.dY + r0 * w.l->out, w.l->out,
-                        w.X + r0 * w.l->in, w.l->in, w.l->dW, w.l->in, ctx->slab3, w.l->db));
-      }
+      TnProblem pr[13];
+      const int np = enc_wgrad_problems(ctx, r0, pr);
+      double fl = 0;
+      for (int i = 0; i < np; ++i) fl += gflop(pr[i].M, pr[i].N, nr);
+      RUNS(sw, "wgrad_gemm", fl, 0, gemm_tn_group_acc(sw, pr, np, nr, ctx->slab3, ctx->slab3_floats));
       return 0;
     };
-    const int uc = std::getenv("RAU_ENC_CHUNK") ? TL / 2 : 0;   // chunking measured slower (11.05 vs 10.6 ms): it crowds the BPTT
+    // RAU_ENC_CHUNKS=n: n time chunks; chunk boundaries at wavefront steps cut[k] (descending)
+    static const int nchunk_env = [] { const char* e = std::getenv("RAU_ENC_CHUNKS"); const int v = e ? std::atoi(e) : 0;
+                                       return v > 0 ? v : 1; }();
+    const int nchunk = std::max(1, std::min(nchunk_env, std::min(TL, (int)ctx->evEc.size())));
+    int next_cut = nchunk - 1;                 // cuts at u = TL * k / nchunk, k = nchunk-1 .. 1
+    int hi = TL;
     for (int u = TL; u >= 0; --u) {
       const float* Ap[3];
       const float* Wp[3];
@@ -1156,8 +1424,13 @@ int rau_backward(rau_ctx* ctx, const float* hop_w) {
         C1.t = t; C1.dq_c = ctx->dq; C1.dq_h = ctx->dq + Rq;
       }
       RUN("lstm_bwd", 0, BRq * 4.0 * 12 * cells.n, lstm_bwd_multi(st, GATES_DEEP, B, Rq, cells));
-      if (u == uc && uc > 0)
-        if (int rc = enc_wgrads(uc, TL, ctx->evE1)) return rc;
+      if (next_cut >= 1 && u == (int)((long)TL * next_cut / nchunk) && u < hi) {
+        if (int rc = enc_wgrads(u, hi, ctx->evEc[next_cut])) return rc;
+        hi = u;
+        --next_cut;
+      } else if (next_cut >= 1 && u < (int)((long)TL * next_cut / nchunk)) {
+        --next_cut;
+      }
     }
     {  // gradient w.r.t. the word embeddings' tanh output, all tokens at once
       LINOPTS(o);
@@ -1167,7 +1440,7 @@ int rau_backward(rau_ctx* ctx, const float* hop_w) {
     RUN("embed_bwd", 0, (double)rows * E * 12,
         embed_bwd(st, ctx->capturing ? c.T * B : ctx->nuniq, E, ctx->utok, ctx->ustart, ctx->upos, ctx->dwe, ctx->we, m_we,
                   sc(RAU_MASK_WE), ctx->grp[RAU_GROUP_EMBED].g));
-    if (int rc = enc_wgrads(0, uc > 0 ? uc : TL, ctx->evE)) return rc;
+    if (int rc = enc_wgrads(0, hi, ctx->evE)) return rc;
   }
   HIPC(hipEventRecord(ctx->evW3, ctx->st3));
   HIPC(hipStreamWaitEvent(st, ctx->evW3, 0));
@@ -1196,7 +1469,7 @@ int rau_graph_step(rau_ctx* ctx, const float* hop_w, int zero_grads_first) {
   uint64_t key = (uint64_t)ctx->mode | ((uint64_t)ctx->max_len << 2) | ((uint64_t)HA << 12) |
                  ((uint64_t)(zero_grads_first != 0) << 22);
   for (int i = 0; i < 5; ++i) key |= (uint64_t)ctx->mexplicit[i] << (24 + i);
-  HIPC(hipMemcpyAsync(ctx->hopw_d, hop_w, H * sizeof(float), hipMemcpyHostToDevice, ctx->st));
+  if (int rc = upload_hop_weights(ctx, hop_w)) return rc;
   hipGraphExec_t exec = nullptr;
   for (auto& g : ctx->graphs)
     if (g.first == key) exec = g.second;

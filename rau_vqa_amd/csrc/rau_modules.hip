@@ -19,8 +19,9 @@ bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) ==
 
 int mod_alloc(rau_ctx* ctx) {
   if (ctx->mod_ready) return 0;
-  // callers hand in / get back DENSE [.., S] tensors; the step-level path pads S internally
-  NEED(ctx->Sp == ctx->cfg.S, "module-level entry points need S %% 4 == 0 (S = %d)", ctx->cfg.S);
+  // Callers hand in / get back DENSE [.., S] tensors.  Internally every [.., S] tensor uses the
+  // position pitch Sp (S rounded up to a multiple of 4: 7x7 maps 49 -> 52), so when Sp != S the
+  // feature map / d_attprob are re-pitched on the way in and attprob / d_X on the way out.
   const rau_config& c = ctx->cfg;
   const size_t B = c.B, Q = ctx->Q;
   const size_t wide = std::max<size_t>({(size_t)c.Rq, (size_t)c.R, (size_t)c.M});
@@ -35,6 +36,11 @@ int mod_alloc(rau_ctx* ctx) {
   CK(dalloc(ctx, &ctx->m_s, B));
   CK(dalloc(ctx, &ctx->m_zero, B * std::max<size_t>(Q, (size_t)c.R)));
   CK(dalloc(ctx, &ctx->m_loss, (size_t)c.H));
+  if (ctx->Sp != c.S) {
+    CK(dalloc(ctx, &ctx->m_Xp, B * c.D * ctx->Sp));
+    CK(dalloc(ctx, &ctx->m_a, (size_t)c.H * B * c.S));
+    CK(dalloc(ctx, &ctx->m_da, B * ctx->Sp));
+  }
 #undef CK
   ctx->mod_ready = true;
   return 0;
@@ -62,11 +68,19 @@ Masks masks_of(rau_ctx* ctx) {
 }
 
 // dW += dY^T X and db += column sums of dY for one Linear, rows = one clone's batch
-int lin_wgrad(rau_ctx* ctx, Lin& l, const float* dY, const float* X, long ldx, bool bias = true) {
+int lin_wgrad(rau_ctx* ctx, Lin& l, const float* dY, const float* X, long ldx, bool bias = true,
+              long ldy = 0) {
   const int B = ctx->cfg.B;
   RUN("wgrad_gemm", 2.0 * l.out * l.in * B, 0,
-      gemm_tn_acc(ctx->st, l.out, l.in, B, dY, l.out, X, ldx, l.dW, l.in, ctx->slab3,
+      gemm_tn_acc(ctx->st, l.out, l.in, B, dY, ldy ? ldy : l.out, X, ldx, l.dW, l.in, ctx->slab3,
                   bias ? l.db : nullptr));
+  return 0;
+}
+// [rows][w_src] -> [rows][w_dst] on the ctx stream (re-pitching of [.., S] tensors)
+int repitch(rau_ctx* ctx, float* dst, size_t w_dst, const float* src, size_t w_src, size_t rows) {
+  const size_t w = std::min(w_dst, w_src);
+  HIPC(hipMemcpy2DAsync(dst, w_dst * 4, src, w_src * 4, w * 4, rows, hipMemcpyDeviceToDevice,
+                        ctx->st));
   return 0;
 }
 
@@ -255,13 +269,17 @@ int rau_multimodal_forward(rau_ctx* ctx, int h, const float* q, const float* X, 
   if (!h_prev) h_prev = ctx->m_zero;
   NEED(aligned16(q) && aligned16(X) && aligned16(c_prev) && aligned16(h_prev),
        "rau_multimodal_forward: pointers must be 16-byte aligned");
-  const int B = c.B, D = c.D, S = c.S, M = c.M, A = c.A, R = c.R, K = c.K, Q = ctx->Q;
+  const int B = c.B, D = c.D, S = ctx->Sp, SL = c.S, M = c.M, A = c.A, R = c.R, K = c.K, Q = ctx->Q;
   hipStream_t st = ctx->st;
   const Masks m = masks_of(ctx);
   auto gflop = [](double mm, double n, double k) { return 2.0 * mm * n * k; };
   const size_t BM_ = (size_t)B * M, BR_ = (size_t)B * R;
   ctx->I_shared = false;
   ctx->fwd_done = false;   // the step-level slots are being overwritten
+  if (S != SL && X != ctx->feats) {   // dense [B,D,SL] from the caller -> pitched (pad columns stay 0)
+    if (int rc = repitch(ctx, ctx->m_Xp, S, X, SL, (size_t)B * D)) return rc;
+    X = ctx->m_Xp;
+  }
   // q_embed's input half: dropout(q) Wq^T + bq + bh   (SS:233-235)
   float* qd = ctx->qd + (size_t)h * B * Q;
   RUN("apply_mask", 0, (double)B * Q * 8,
@@ -278,7 +296,7 @@ int rau_multimodal_forward(rau_ctx* ctx, int h, const float* q, const float* X, 
   if (m.x) {
     float* xd = ctx->xd + (size_t)h * B * D * S;
     RUN("dropout_features", 0, 2.0 * B * D * S * 4,
-        dropout_features(st, 1, (size_t)B * D * S, X, m.x, m.s_x, xd, (size_t)h * B * D * S));
+        dropout_features(st, 1, (size_t)B * D * S, X, m.x, m.s_x, xd, (size_t)h * B * D * SL, SL, S));
     xin = xd;
   }
   RUN("transpose", 0, (double)M * D * 8, transpose2d(st, M, D, ctx->i_embed.W, ctx->WiT));
@@ -294,7 +312,14 @@ int rau_multimodal_forward(rau_ctx* ctx, int h, const float* q, const float* X, 
   if (int rc = hop_forward(ctx, h, c_prev, h_prev, co, ho, Ih, Th, nullptr)) return rc;
   if (logits) *logits = ctx->logits + (size_t)h * B * K;
   if (do_pred) *do_pred = ctx->dopred + (size_t)h * B;
-  if (attprob) *attprob = ctx->a + (size_t)h * B * S;
+  if (attprob) {
+    *attprob = ctx->a + (size_t)h * B * S;
+    if (S != SL) {   // hand back a dense [B,SL] copy
+      float* ad = ctx->m_a + (size_t)h * B * SL;
+      if (int rc = repitch(ctx, ad, SL, ctx->a + (size_t)h * B * S, S, B)) return rc;
+      *attprob = ad;
+    }
+  }
   if (c_out) *c_out = co;
   if (h_out) *h_out = ho;
   return RAU_OK;
@@ -318,11 +343,22 @@ int rau_multimodal_backward(rau_ctx* ctx, int h, const float* q, const float* X,
   NEED(aligned16(q) && aligned16(X) && aligned16(c_prev) && aligned16(h_prev) &&
            aligned16(d_logits) && aligned16(d_attprob) && aligned16(d_c) && aligned16(d_h),
        "rau_multimodal_backward: pointers must be 16-byte aligned");
-  const int B = c.B, D = c.D, S = c.S, M = c.M, A = c.A, R = c.R, Q = ctx->Q;
+  const int B = c.B, D = c.D, S = ctx->Sp, SL = c.S, M = c.M, A = c.A, R = c.R, Q = ctx->Q;
   hipStream_t st = ctx->st;
   const Masks m = masks_of(ctx);
   auto gflop = [](double mm, double n, double k) { return 2.0 * mm * n * k; };
   const size_t BM_ = (size_t)B * M, BS_ = (size_t)B * S, BR_ = (size_t)B * R;
+  if (S != SL) {
+    if (X != ctx->feats) {   // the forward of this clone re-pitched the same X
+      if (int rc = repitch(ctx, ctx->m_Xp, S, X, SL, (size_t)B * D)) return rc;
+      X = ctx->m_Xp;
+    }
+    if (d_attprob) {
+      HIPC(hipMemsetAsync(ctx->m_da, 0, BS_ * sizeof(float), st));
+      if (int rc = repitch(ctx, ctx->m_da, S, d_attprob, SL, B)) return rc;
+      d_attprob = ctx->m_da;
+    }
+  }
   const float* Ih = ctx->I + (size_t)h * BM_ * S;
   const float* mfh = ctx->mf + (size_t)h * BM_;
   float* Th = ctx->T + (size_t)h * B * A * S;
@@ -379,11 +415,18 @@ int rau_multimodal_backward(rau_ctx* ctx, int h, const float* q, const float* X,
     RUN("mul_dtanh", 0, BM_ * S * 12.0, mul_dtanh(st, BM_ * S, dZh, Ih, ctx->m_dZ));
     RUN("conv_embed_dgrad", gflop(D, (double)B * S, M), (BM_ * S + (double)B * D * S) * 4,
         conv_embed_dgrad(st, B, D, S, M, ctx->m_dZ, ctx->i_embed.W, ctx->m_dX));
-    if (m.x)
-      RUN("apply_mask", 0, (double)B * D * S * 8,
-          apply_mask(st, (size_t)B * D * S, (size_t)B * D * S, ctx->m_dX, m.x, m.s_x, ctx->m_dX,
-                     (size_t)h * B * D * S));
-    *d_X = ctx->m_dX;
+    float* dXo = ctx->m_dX;
+    if (S != SL) {   // dense [B,D,SL] for the caller (reuses the re-pitch buffer's sibling)
+      if (!ctx->m_dXd)
+        if (int rc = dalloc(ctx, &ctx->m_dXd, (size_t)B * D * SL)) return rc;
+      if (int rc = repitch(ctx, ctx->m_dXd, SL, ctx->m_dX, S, (size_t)B * D)) return rc;
+      dXo = ctx->m_dXd;
+    }
+    if (m.x)   // the mask is indexed logically: applied on the dense tensor
+      RUN("apply_mask", 0, (double)B * D * SL * 8,
+          apply_mask(st, (size_t)B * D * SL, (size_t)B * D * SL, dXo, m.x, m.s_x, dXo,
+                     (size_t)h * B * D * SL));
+    *d_X = dXo;
   }
   // ---- accGradParameters of the clone's Linears
   const size_t h4 = (size_t)h * B * 4 * R;
@@ -392,7 +435,7 @@ int rau_multimodal_backward(rau_ctx* ctx, int h, const float* q, const float* X,
   if (int rc = lin_wgrad(ctx, ctx->lstm_i2h, ctx->dg4 + h4, ctx->j + (size_t)h * BM_, M)) return rc;
   if (int rc = lin_wgrad(ctx, ctx->lstm_h2h, ctx->dg4 + h4, h_prev, R)) return rc;
   if (int rc = lin_wgrad(ctx, ctx->feat_attprob, ctx->dj + (size_t)h * BM_, ctx->a + (size_t)h * BS_, S)) return rc;
-  if (int rc = lin_wgrad(ctx, ctx->att_mem, ctx->dz + (size_t)h * BS_, h_prev, R)) return rc;
+  if (int rc = lin_wgrad(ctx, ctx->att_mem, ctx->dz + (size_t)h * BS_, h_prev, R, true, S)) return rc;
   if (int rc = lin_wgrad(ctx, ctx->att_q, ctx->du + (size_t)h * B * A, ctx->qf + (size_t)h * BM_, M)) return rc;
   if (int rc = lin_wgrad(ctx, ctx->q_proj, ctx->dqt + (size_t)h * BM_, ctx->qd + (size_t)h * B * Q, Q)) return rc;
   if (int rc = lin_wgrad(ctx, ctx->h_proj, ctx->dqt + (size_t)h * BM_, h_prev, R)) return rc;
@@ -400,8 +443,8 @@ int rau_multimodal_backward(rau_ctx* ctx, int h, const float* q, const float* X,
   RUN("colsum", 0, (double)B * A * 4,
       colsum_acc(st, B, A, ctx->dwsp + (size_t)h * B * A, A, ctx->att_score.dW, ctx->coltmp3));
   HIPC(hipMemsetAsync(ctx->tmpS, 0, S * sizeof(float), st));
-  RUN("colsum", 0, (double)B * S * 4, colsum_acc(st, B, S, ctx->dz + (size_t)h * BS_, S, ctx->tmpS, ctx->coltmp3));
-  RUN("colsum", 0, S * 4.0, colsum_acc(st, S, 1, ctx->tmpS, 1, ctx->att_score.db, ctx->coltmp3));
+  RUN("colsum", 0, (double)B * S * 4, colsum_acc(st, B, SL, ctx->dz + (size_t)h * BS_, S, ctx->tmpS, ctx->coltmp3));
+  RUN("colsum", 0, S * 4.0, colsum_acc(st, SL, 1, ctx->tmpS, 1, ctx->att_score.db, ctx->coltmp3));
   RUN("colsum", 0, (double)B * A * 4,
       colsum_acc(st, B, A, ctx->du + (size_t)h * B * A, A, ctx->att_i.db, ctx->coltmp3));
   if (d_q) *d_q = dqo;

@@ -33,7 +33,7 @@ def test_library_exports_every_declared_symbol():
 def test_abi_version_and_defaults():
     from rau_vqa_amd import _lib
     l = _lib.lib()
-    assert l.rau_abi_version() == 2
+    assert l.rau_abi_version() == 3
     cfg = _lib.RauConfig()
     l.rau_default_config(C.byref(cfg))
     # the reference's hard-coded locals, SS:202-229, and opt.batch_size default SS:48
@@ -75,3 +75,63 @@ def test_product_path_never_imports_the_oracle():
                                  if not l.lstrip().startswith(("//", "#", "*", "/*")))
                 assert "import oracle" not in code and "from oracle" not in code, f
                 assert "rau_oracle" not in code or f == "philox.h", f
+
+
+def _normalise(proto: str) -> str:
+    """Canonical text of a C prototype: comments out, whitespace collapsed, no parameter-name
+    sensitivity to spacing around '*' and ','."""
+    proto = re.sub(r"/\*.*?\*/", " ", proto, flags=re.S)
+    proto = re.sub(r"\s+", " ", proto).strip()
+    proto = re.sub(r"\s*\*\s*", "* ", proto)
+    proto = re.sub(r"\s*,\s*", ", ", proto)
+    proto = re.sub(r"\(\s*", "(", proto)
+    proto = re.sub(r"\s*\)", ")", proto)
+    return proto
+
+
+def _prototypes(text: str):
+    """{name: normalised prototype} of every `... rau_xxx(...);` declaration in `text`."""
+    text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
+    text = re.sub(r"//[^\n]*", " ", text)
+    text = re.sub(r"^\s*#[^\n]*", " ", text, flags=re.M)      # preprocessor lines
+    out = {}
+    for m in re.finditer(r"([A-Za-z_][A-Za-z_0-9\s\*]*?\b(rau_[a-z_0-9]+)\s*\([^;{]*?\))\s*;", text):
+        out[m.group(2)] = _normalise(m.group(1))
+    return out
+
+
+def _struct_fields(text: str, name: str):
+    body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (name, name), text, flags=re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", " ", body, flags=re.S)
+    fields = []
+    for decl in body.split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        ty, names = decl.split(None, 1)
+        fields += [(ty, n.strip()) for n in names.split(",")]
+    return fields
+
+
+def test_lua_ffi_cdef_matches_the_header():
+    """bindings/rau.lua's ffi.cdef block is a second, hand-kept statement of the ABI (LuaJIT cannot
+    run here): every prototype in it must equal include/rau.h's, token for token, the struct must
+    have the same fields in the same order, and no declared entry point may be missing."""
+    header = open(os.path.join(ROOT, "include", "rau.h")).read()
+    lua = open(os.path.join(ROOT, "bindings", "rau.lua")).read()
+    blocks = re.findall(r"ffi\.cdef\[\[(.*?)\]\]", lua, flags=re.S)
+    assert blocks, "no ffi.cdef block"
+    cdef = "\n".join(blocks)
+    want, got = _prototypes(header), _prototypes(cdef)
+    assert sorted(want) == declared_symbols()
+    missing = sorted(set(want) - set(got))
+    assert not missing, f"ffi.cdef lacks: {missing}"
+    extra = sorted(set(got) - set(want))
+    assert not extra, f"ffi.cdef declares symbols the header does not: {extra}"
+    diff = {k: (got[k], want[k]) for k in want if got[k] != want[k]}
+    assert not diff, diff
+    assert _struct_fields(cdef, "rau_config") == _struct_fields(header, "rau_config")
+    # and the ctypes mirror of the struct
+    from rau_vqa_amd import _lib
+    ctypes_fields = [n for n, _ in _lib.RauConfig._fields_]
+    assert ctypes_fields == [n for _, n in _struct_fields(header, "rau_config")]
