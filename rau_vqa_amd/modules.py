@@ -171,3 +171,197 @@ def _feval(rau, feats, x, x_len, y, hop_w):
         d_x, d_state = rnn[t].backward(we[t], state[t], d_out)
         emb[t].backward(x[t], d_x)
     return torch.tensor(losses), torch.stack(answers)
+
+
+# --------------------------------------------------------------------------------------------
+# Device tensors without torch: the Python twin of bindings/rau.lua's RAU.Tensor.  Every method is
+# one rau_dev_* call of the C ABI, so a host with no tensor library on the GPU (LuaJIT + CPU
+# Torch7 on an MI355X box) can keep feval's own loops.  feval_dev below is those loops written
+# with nothing else -- the executable proof of what the Lua shim does.
+class DevTensor:
+    """Dense row-major float32 device tensor: {ptr, size, rau}; views share memory."""
+
+    def __init__(self, rau, ptr: int, size, owned=False):
+        self.rau, self.ptr, self.size, self.owned = rau, int(ptr), tuple(size), owned
+
+    @classmethod
+    def zeros(cls, rau, *size):
+        out = C.c_void_p()
+        n = 1
+        for v in size:
+            n *= v
+        L.check(rau._lib.rau_dev_alloc(rau._h, n, C.byref(out)))
+        return cls(rau, out.value, size, owned=True)
+
+    @classmethod
+    def wrap(cls, rau, ptr, *size):
+        return cls(rau, ptr.value if isinstance(ptr, C.c_void_p) else ptr, size)
+
+    def numel(self):
+        n = 1
+        for v in self.size:
+            n *= v
+        return n
+
+    def row(self, k):                 # 0-based here (Lua: 1-based), view
+        cols = self.numel() // self.size[0]
+        return DevTensor(self.rau, self.ptr + 4 * k * cols, (cols,))
+
+    def __getitem__(self, k):
+        return self.row(k)
+
+    def __setitem__(self, k, v):      # t[k] = row  (rnn_out[k] = lst[k], SS:455-461)
+        self.row(k).copy(v)
+
+    def zero(self):
+        return self.fill(0.0)
+
+    def fill(self, v):
+        L.check(self.rau._lib.rau_dev_fill(self.rau._h, self.ptr, self.numel(), float(v)))
+        return self
+
+    def copy(self, src):
+        if isinstance(src, DevTensor):
+            assert src.numel() == self.numel()
+            L.check(self.rau._lib.rau_dev_copy(self.rau._h, self.ptr, src.ptr, self.numel()))
+        else:                          # host array
+            import numpy as np
+            a = np.ascontiguousarray(src, np.float32)
+            assert a.size == self.numel()
+            L.check(self.rau._lib.rau_dev_upload(self.rau._h, self.ptr, a.ctypes.data, a.nbytes))
+        return self
+
+    def add(self, a, x=None):          # :add(x) or :add(alpha, x)
+        if x is None:
+            a, x = 1.0, a
+        assert x.numel() == self.numel()
+        L.check(self.rau._lib.rau_dev_axpy(self.rau._h, self.ptr, x.ptr, self.numel(), float(a)))
+        return self
+
+    def mul(self, a):
+        L.check(self.rau._lib.rau_dev_scale(self.rau._h, self.ptr, self.numel(), float(a)))
+        return self
+
+    def sum(self):
+        out = C.c_double()
+        L.check(self.rau._lib.rau_dev_sum(self.rau._h, self.ptr, self.numel(), C.byref(out)))
+        return out.value
+
+    def max(self, dim):                # torch.max(t, 2): (values [r,1], 1-based first-max ids [r,1])
+        assert dim == 2 and len(self.size) == 2
+        r, c = self.size
+        v, i = DevTensor.zeros(self.rau, r, 1), DevTensor.zeros(self.rau, r, 1)
+        L.check(self.rau._lib.rau_dev_rowmax(self.rau._h, self.ptr, r, c, v.ptr, i.ptr))
+        i.is_int = True
+        return v, i
+
+    def select_rows(self, src, key, value):
+        r = self.size[0]
+        L.check(self.rau._lib.rau_dev_select_rows(self.rau._h, self.ptr, src.ptr, r,
+                                                  self.numel() // r, key.ptr, int(value)))
+        return self
+
+    def eq_sum(self, other):           # ans:eq(y):sum(), SS:489-492 (int32 tensors)
+        out = C.c_int32()
+        L.check(self.rau._lib.rau_dev_count_eq(self.rau._h, self.ptr, other.ptr, self.numel(),
+                                               C.byref(out)))
+        return out.value
+
+    def numpy(self, dtype=None):
+        import numpy as np
+        a = np.empty(self.size, np.int32 if dtype == "int32" else np.float32)
+        L.check(self.rau._lib.rau_dev_download(self.rau._h, a.ctypes.data, self.ptr, a.nbytes))
+        return a
+
+    @classmethod
+    def ints(cls, rau, host):
+        import numpy as np
+        a = np.ascontiguousarray(host, np.int32)
+        t = cls.zeros(rau, *a.shape)
+        L.check(rau._lib.rau_dev_upload(rau._h, t.ptr, a.ctypes.data, a.nbytes))
+        return t
+
+    def free(self):
+        if self.owned:
+            L.check(self.rau._lib.rau_dev_free(self.rau._h, self.ptr))
+            self.owned = False
+
+
+def _cp(t):
+    return None if t is None else C.c_void_p(t.ptr)
+
+
+def feval_dev(rau, feats, x, x_len_host, y, hop_w, row_loop=False):
+    """feval's tensor half (SS:443-596) over the module-level ABI with DevTensor glue only.
+
+    feats [B,D,S] DevTensor, x: list of T int32 DevTensors [B], x_len_host: numpy [B] (the
+    reference reads x_len on the host, SS:455), y int32 DevTensor [B].  row_loop=True copies the
+    selected state rows one by one exactly like the reference's `for k=1,B` loop; otherwise one
+    rau_dev_select_rows call per step does the same.  Returns (losses, correct counts, uni logits).
+    """
+    c, lib, h = rau.cfg, rau._lib, rau._h
+    x_len_dev = DevTensor.ints(rau, x_len_host)
+    max_len = int(max(x_len_host)) if len(x_len_host) else 0
+
+    def select(dst, src, t):
+        if row_loop:
+            for k in range(c.B):
+                if x_len_host[k] == t:
+                    dst[k] = src[k]
+        else:
+            dst.select_rows(src, x_len_dev, t)
+
+    state = [DevTensor.zeros(rau, c.B, c.Q)]
+    we = []
+    rnn_out = DevTensor.zeros(rau, c.B, c.Q)
+    for t in range(max_len):
+        o = C.c_void_p()
+        L.check(lib.rau_embed_forward(h, t, _cp(x[t]), C.byref(o)))
+        we.append(DevTensor.wrap(rau, o, c.B, c.E))
+        o = C.c_void_p()
+        L.check(lib.rau_deeplstm_forward(h, t, _cp(we[t]), _cp(state[t]), C.byref(o)))
+        state.append(DevTensor.wrap(rau, o, c.B, c.Q))
+        select(rnn_out, state[t + 1], t + 1)
+    att_c, att_h = [DevTensor.zeros(rau, c.B, c.R)], [DevTensor.zeros(rau, c.B, c.R)]
+    uni = DevTensor.zeros(rau, c.B, c.K)
+    logits, losses, correct = [], [], []
+    for hop in range(c.H):
+        outs = [C.c_void_p() for _ in range(5)]
+        L.check(lib.rau_multimodal_forward(h, hop, _cp(rnn_out), _cp(feats), _cp(att_c[hop]),
+                                           _cp(att_h[hop]), *[C.byref(o) for o in outs]))
+        lg = DevTensor.wrap(rau, outs[0], c.B, c.K)
+        logits.append(lg)
+        att_c.append(DevTensor.wrap(rau, outs[3], c.B, c.R))
+        att_h.append(DevTensor.wrap(rau, outs[4], c.B, c.R))
+        _, ans = lg.max(2)                                   # SS:488
+        correct.append(ans.eq_sum(y))                        # SS:489-492
+        uni.add(lg)                                          # SS:522-526
+        loss = C.c_float()
+        L.check(lib.rau_criterion_forward(h, hop, _cp(lg), _cp(y), C.byref(loss)))
+        losses.append(loss.value)
+    d_c = d_h = None
+    d_q = DevTensor.zeros(rau, c.B, c.Q)
+    for hop in reversed(range(c.H)):
+        o = C.c_void_p()
+        L.check(lib.rau_criterion_backward(h, hop, _cp(logits[hop]), _cp(y), float(hop_w[hop]),
+                                           C.byref(o)))
+        dl = DevTensor.wrap(rau, o, c.B, c.K)
+        outs = [C.c_void_p() for _ in range(4)]
+        L.check(lib.rau_multimodal_backward(h, hop, _cp(rnn_out), _cp(feats), _cp(att_c[hop]),
+                                            _cp(att_h[hop]), _cp(dl), None, None, _cp(d_c),
+                                            _cp(d_h), C.byref(outs[0]), None, C.byref(outs[2]),
+                                            C.byref(outs[3])))
+        d_q.add(DevTensor.wrap(rau, outs[0], c.B, c.Q))      # ConcatTable backward, SS:579
+        d_c = DevTensor.wrap(rau, outs[2], c.B, c.R)
+        d_h = DevTensor.wrap(rau, outs[3], c.B, c.R)
+    d_state = DevTensor.zeros(rau, c.B, c.Q)
+    d_out = DevTensor.zeros(rau, c.B, c.Q)
+    for t in reversed(range(max_len)):
+        d_out.copy(d_state)
+        select(d_out, d_q, t + 1)                            # rows REPLACED by dq, SS:584-591
+        dx, ds = C.c_void_p(), C.c_void_p()
+        L.check(lib.rau_deeplstm_backward(h, t, _cp(we[t]), _cp(state[t]), _cp(d_out),
+                                          C.byref(dx), C.byref(ds)))
+        d_state = DevTensor.wrap(rau, ds, c.B, c.Q)
+        L.check(lib.rau_embed_backward(h, t, _cp(x[t]), dx))
+    return losses, correct, uni

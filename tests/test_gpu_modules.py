@@ -244,3 +244,102 @@ def test_criterion_clone_and_argument_checks():
     assert m._lib.rau_multimodal_forward(m._h, sh.H, None, None, None, None, None, None, None,
                                          None, None) == -1
     m.close()
+
+
+@pytest.mark.parametrize("row_loop", [False, True])
+def test_feval_with_device_tensor_glue_only(row_loop):
+    """The Lua shim's route (bindings/rau.lua RAU.Tensor): feval's loops over the module-level ABI
+    with NOTHING but rau_dev_* calls for the tensor algebra in between -- row selection by question
+    length (one call, or the reference's row-by-row loop), uni_pred accumulation, first-max
+    argmax, correct counts.  Same gradients as the oracle."""
+    from rau_vqa_amd import modules
+    from rau_vqa_amd.modules import DevTensor
+    sh = util.shapes(util.SMALL)
+    lens = np.array([0, 6, 1, 3, 6, 2, 0, 4], np.int32)
+    batch, params, masks = util.make_problem(sh, lens=lens, scale=0.5)
+    hop_w = np.full(sh.H, float(sh.H), np.float32)
+    ref = oracle.step(sh, params, batch["feats"], batch["tokens"], batch["lens"],
+                      batch["labels"], masks, hop_w, dtype=np.float64)
+    m = make_model(sh, params, masks)
+    layouts = {k: m.layout(k) for k in ("embed", "rnn", "mult")}
+    feats = DevTensor.zeros(m, sh.B, sh.D, sh.S).copy(batch["feats"])
+    x = [DevTensor.ints(m, batch["tokens"][t]) for t in range(sh.T)]
+    y = DevTensor.ints(m, batch["labels"])
+    m.zero_grads()
+    losses, correct, uni = modules.feval_dev(m, feats, x, batch["lens"], y, hop_w, row_loop=row_loop)
+    m.sync()
+    errs = grad_errs(m.get_grads(), ref, layouts)
+    errs["losses"] = util.rel_err(np.array(losses), ref["losses"])
+    errs["uni"] = util.rel_err(uni.numpy(), ref["logits"].sum(0))
+    bad = {k: v for k, v in errs.items() if not v < TOL}
+    assert not bad, bad
+    want = [(ref["argmax"][h] == batch["labels"]).sum() for h in range(sh.H)]
+    assert correct == [int(v) for v in want]
+    m.close()
+
+
+def test_device_tensor_ops():
+    from rau_vqa_amd.modules import DevTensor
+    sh = util.shapes(util.EDGE)
+    _, params, _ = util.make_problem(sh)
+    m = make_model(sh, params, mode="eval")
+    rng = np.random.default_rng(0)
+    a = rng.standard_normal((6, 10)).astype(np.float32)
+    a[2, 3] = a[2, 7] = a[2].max() + 1.0                     # a tie: the FIRST index wins
+    t = DevTensor.zeros(m, 6, 10).copy(a)
+    v, i = t.max(2)
+    assert np.array_equal(i.numpy("int32").ravel(), a.argmax(1) + 1)
+    assert np.array_equal(v.numpy().ravel(), a.max(1))
+    assert abs(t.sum() - float(a.astype(np.float64).sum())) < 1e-5
+    u = DevTensor.zeros(m, 6, 10).fill(2.0).add(0.5, t).mul(2.0)
+    assert np.allclose(u.numpy(), (2.0 + 0.5 * a) * 2.0)
+    key = DevTensor.ints(m, np.array([1, 3, 3, 0, 3, 2], np.int32))
+    w = DevTensor.zeros(m, 6, 10).select_rows(t, key, 3)
+    want = np.where((np.array([1, 3, 3, 0, 3, 2]) == 3)[:, None], a, 0.0)
+    assert np.array_equal(w.numpy(), want)
+    w[0] = t[5]                                              # row view / row assign
+    assert np.array_equal(w.numpy()[0], a[5])
+    assert key.eq_sum(DevTensor.ints(m, np.array([1, 0, 3, 0, 3, 9], np.int32))) == 4
+    w.free()
+    from rau_vqa_amd import _lib as L
+    with pytest.raises(L.RauError, match="rau_dev_free"):     # not one of the ctx's allocations
+        L.check(m._lib.rau_dev_free(m._h, 12345 * 16))
+    m.close()
+
+
+def test_module_level_calls_on_7x7_maps():
+    """S = 49 (the scripts' default feature grid, SS:36-37) through the MODULE-level entry points:
+    callers see dense [.., 49] tensors, the library re-pitches to 52 internally."""
+    import torch
+    from rau_vqa_amd import modules
+    dims = dict(B=6, T=5, V=40, E=8, Rq=16, D=24, S=49, M=40, A=20, R=16, K=12, H=3)
+    sh = util.shapes(dims)
+    batch, params, masks = util.make_problem(sh, scale=0.5)
+    hop_w = np.full(sh.H, float(sh.H), np.float32)
+    ref = oracle.step(sh, params, batch["feats"], batch["tokens"], batch["lens"],
+                      batch["labels"], masks, hop_w, dtype=np.float64)
+    m = make_model(sh, params, masks)
+    layouts = {k: m.layout(k) for k in ("embed", "rnn", "mult")}
+    m.zero_grads()
+    losses, answers = modules.feval(m, cuda(batch["feats"]), cuda(batch["tokens"], torch.int32),
+                                    cuda(batch["lens"], torch.int32),
+                                    cuda(batch["labels"], torch.int32), hop_w)
+    m.sync()
+    errs = grad_errs(m.get_grads(), ref, layouts)
+    errs["losses"] = util.rel_err(losses.numpy(), ref["losses"])
+    bad = {k: v for k, v in errs.items() if not v < TOL}
+    assert not bad, bad
+    # one clone with every gradOutput set, attprob in and out dense [B,49], d_X on request
+    q = cuda(np.random.default_rng(1).standard_normal((sh.B, 4 * sh.Rq)).astype(np.float32))
+    X = cuda(batch["feats"])
+    mm = modules.MultimodalClone(m, 1)
+    lg, dp, att, cn, hn = mm.forward(q, X, None, None)
+    assert att.shape == (sh.B, 49)
+    assert torch.allclose(att.sum(1), torch.ones(sh.B, device=att.device), atol=1e-5)
+    d_att = torch.ones_like(att)
+    dq, dX, dc, dh = mm.backward(q, X, None, None, torch.zeros_like(lg), None, d_att, None, None,
+                                 want_dX=True)
+    assert dX.shape == (sh.B, sh.D, 49) and bool(torch.isfinite(dX).all())
+    # softmax Jacobian: a constant gradient at the attention output gives no gradient upstream
+    assert float(dq.abs().max()) < 1e-5 and float(dX.abs().max()) < 1e-5
+    m.close()
