@@ -68,10 +68,15 @@ typedef enum rau_mask_site {   /* the five nn.Dropout sites on the path */
 
 typedef enum rau_dtype {
   RAU_F32 = 0,       /* f32 operands, f32 MFMA accumulate (exact fmaf chain) */
-  RAU_BF16 = 1       /* the five 1x1-conv GEMMs (i_embed, ifeatproj and their gradients: 94-98 %
+  RAU_BF16 = 1,      /* the five 1x1-conv GEMMs (i_embed, ifeatproj and their gradients: 94-98 %
                       * of the FLOPs) take bf16-rounded operands with f32 accumulation; all
                       * tensors in memory, the recurrences, attention and loss stay f32
                       * (BASELINE.json configs[2]: Ours_ResNet 14x14x2048, bf16 MFMA) */
+  RAU_F32S = 2       /* same five GEMMs with every f32 operand SPLIT into three bf16 terms
+                      * (hi + mid + lo = all 24 significand bits) and six bf16 MFMA products per
+                      * operand pair, f32 accumulate: f32-grade accuracy (dropped terms <= 2^-24
+                      * relative) on the 16x faster bf16 matrix pipe.  Not bitwise the fmaf chain
+                      * of RAU_F32; selectable, never the default. */
 } rau_dtype;
 
 /* Network hyper-parameters: the hard-coded locals of SS:202,209-229 plus the

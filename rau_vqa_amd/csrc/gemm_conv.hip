@@ -26,6 +26,7 @@ hipError_t conv_embed_fwd(hipStream_t st, int nB, int D, int S, int M, const flo
   P.C = I; P.c_bs = (long)M * S;
   P.bias = bi;
   P.act = 1;
+  if (bf16 == 2) return launch_gemm<128, 128, BK, SRC_RC, SRC_RC_FLAT, EPI_CONV, 2>(st, P, 1);
   if (bf16) return launch_gemm<128, 128, BK, SRC_RC, SRC_RC_FLAT, EPI_CONV, 1>(st, P, 1);
   return launch_gemm<128, 128, BK, SRC_RC, SRC_RC_FLAT, EPI_CONV>(st, P, 1);
 }
@@ -43,6 +44,7 @@ hipError_t conv_att_pre(hipStream_t st, int nB, int M, int S, int A, const float
   P.C = Pout; P.c_bs = (long)A * S;
   P.bias = bp;
   P.act = 0;
+  if (bf16 == 2) return launch_gemm<128, 128, BK, SRC_RC, SRC_RC_FLAT, EPI_CONV, 2>(st, P, 1);
   if (bf16) return launch_gemm<128, 128, BK, SRC_RC, SRC_RC_FLAT, EPI_CONV, 1>(st, P, 1);
   return launch_gemm<128, 128, BK, SRC_RC, SRC_RC_FLAT, EPI_CONV>(st, P, 1);
 }
@@ -61,6 +63,7 @@ hipError_t conv_att_dgrad(hipStream_t st, int nB, int M, int S, int A, const flo
   P.S = S;
   P.C = dI; P.c_bs = (long)M * S;
   P.v1 = dj; P.v2 = a;
+  if (bf16 == 2) return launch_gemm<128, 128, BK, SRC_RC, SRC_RC_FLAT, EPI_OUTER, 2>(st, P, 1);
   if (bf16) return launch_gemm<128, 128, BK, SRC_RC, SRC_RC_FLAT, EPI_OUTER, 1>(st, P, 1);
   return launch_gemm<128, 128, BK, SRC_RC, SRC_RC_FLAT, EPI_OUTER>(st, P, 1);
 }
@@ -128,6 +131,7 @@ template <int ASRC>
 static hipError_t conv_wgrad_any(hipStream_t st, const GemmParams& P, int nB, int S, float* dW,
                                  float* slab, int bf16, float* drow = nullptr) {
   // bf16 MFMA steps are 16 deep: 32-wide chunks, the last one of a 196-position map zero-filled
+  if (bf16 == 2) return conv_wgrad<32, ASRC, 2>(st, P, nB, S, dW, slab, drow);
   if (bf16) return conv_wgrad<32, ASRC, 1>(st, P, nB, S, dW, slab, drow);
   // 14x14 maps: 196 = 7 * 28, so a 28-deep K-step wastes no MFMA work on padding
   if (S % 28 == 0) return conv_wgrad<28, ASRC>(st, P, nB, S, dW, slab, drow);

@@ -19,7 +19,12 @@
 
 namespace rau {
 
-constexpr int LPAD = 4;   // row padding (floats): keeps 16-B alignment
+constexpr int LPAD = 4;   // row padding (floats) of tiles staged with 16-byte LDS stores
+// Tiles staged by TRANSPOSING scalar stores (LoadKC, LoadSC: a thread's float4 of 4 consecutive k
+// goes to 4 k-rows of one column) use a pad of 1 instead: with a pitch of 4 mod 32 the 8 k-chunks
+// of a row land on only two banks (4-way conflicts, measured SQ_LDS_BANK_CONFLICT = 52 % of the LDS
+// cycles of the conv weight-gradient kernels); with an odd pitch (k-chunk + row) spreads over all 32.
+constexpr int SPAD = 1;
 
 // ---- bf16-operand mode (rau_dtype RAU_BF16): operands are rounded to bf16 (RNE) while they
 // are staged into LDS, products accumulate in f32 (v_mfma_f32_32x32x16_bf16, 16x the f32 MFMA
@@ -34,6 +39,35 @@ __device__ __forceinline__ uint2 pack_bf16x4(float a, float b, float c, float d)
   bf16x4 v;
   v[0] = (__bf16)a; v[1] = (__bf16)b; v[2] = (__bf16)c; v[3] = (__bf16)d;
   return __builtin_bit_cast(uint2, v);
+}
+// ---- split-operand mode (rau_dtype RAU_F32S): every f32 operand x is staged as THREE bf16 terms
+// x = hi + mid + lo (hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid): 3 x 8 significand
+// bits = all 24 bits of the f32 value), and each product a*b is formed as the six bf16 MFMA terms
+// of relative weight >= 2^-16: hi*hi, hi*mid, mid*hi, hi*lo, mid*mid, lo*hi, accumulated in f32.
+// The terms left out (mid*lo, lo*mid, lo*lo) are <= 2^-24 of the product -- the size of one f32
+// rounding -- so the result has f32-grade accuracy (measured against the fp64 oracle in
+// tests/test_gpu_split.py) at 6 bf16 MFMAs per 8 f32 MFMAs of a quarter the length: 2.7x fewer
+// matrix-pipe cycles.  LDS image: three plane sets (hi, mid, lo) of the bf16 layout above.
+// put_bf16<NPL>: NPL = 1 rounds (RAU_BF16), NPL = 3 splits (RAU_F32S).
+template <int NPL>
+__device__ __forceinline__ void put_bf16(uint2* img, int idx, int set_stride, float a, float b,
+                                         float c, float d) {
+  if constexpr (NPL == 1) {
+    img[idx] = pack_bf16x4(a, b, c, d);
+  } else {
+    bf16x4 h, m, l;
+    const float x[4] = {a, b, c, d};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      h[i] = (__bf16)x[i];
+      const float r1 = x[i] - (float)h[i];
+      m[i] = (__bf16)r1;
+      l[i] = (__bf16)(r1 - (float)m[i]);
+    }
+    img[idx] = __builtin_bit_cast(uint2, h);
+    img[idx + set_stride] = __builtin_bit_cast(uint2, m);
+    img[idx + 2 * set_stride] = __builtin_bit_cast(uint2, l);
+  }
 }
 
 // Superset of the arguments any loader/epilogue combination needs.
@@ -77,6 +111,7 @@ struct GemmParams {
 // Operand stored [rows][K], K contiguous.
 template <int BT, int BKT>
 struct LoadKC {
+  static constexpr int PAD = SPAD;
   static constexpr int LPR = BKT / 4;          // lanes (float4) per row
   static constexpr int RPP = 256 / LPR;        // rows per pass
   static constexpr int NI = BT / RPP;
@@ -107,18 +142,20 @@ struct LoadKC {
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
       const int r = tid / LPR + i * RPP;
-      float* d = lds + kc * (BT + LPAD) + r;
+      float* d = lds + kc * (BT + PAD) + r;
       d[0] = R.v[i].x;
-      d[BT + LPAD] = R.v[i].y;
-      d[2 * (BT + LPAD)] = R.v[i].z;
-      d[3 * (BT + LPAD)] = R.v[i].w;
+      d[BT + PAD] = R.v[i].y;
+      d[2 * (BT + PAD)] = R.v[i].z;
+      d[3 * (BT + PAD)] = R.v[i].w;
     }
   }
-  __device__ __forceinline__ void store_bf16(uint2* img, int tid, const Regs& R) const {
+  template <int NPL>
+  __device__ __forceinline__ void store_bf16(uint2* img, int set_stride, int tid, const Regs& R) const {
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
       const int r = tid / LPR + i * RPP;
-      img[(tid % LPR) * (BT + BPAD) + r] = pack_bf16x4(R.v[i].x, R.v[i].y, R.v[i].z, R.v[i].w);
+      put_bf16<NPL>(img, (tid % LPR) * (BT + BPAD) + r, set_stride, R.v[i].x, R.v[i].y, R.v[i].z,
+                    R.v[i].w);
     }
   }
 };
@@ -131,6 +168,7 @@ struct LoadKC {
 // its weight-gradient GEMM's dY operand).
 template <int BT, int BKT, bool FLAT, bool K4 = false, bool CS = false>
 struct LoadRC {
+  static constexpr int PAD = LPAD;
   static constexpr int CPR = BT / 4;
   static constexpr int RPP = 256 / CPR;
   static constexpr int NI = BKT / RPP;
@@ -181,13 +219,14 @@ struct LoadRC {
       }
     }
   }
-  __device__ __forceinline__ void store_bf16(uint2* img, int tid, const Regs& R) const {
+  template <int NPL>
+  __device__ __forceinline__ void store_bf16(uint2* img, int set_stride, int tid, const Regs& R) const {
     if constexpr (K4) {
-      uint2* d = img + kr * (BT + BPAD) + c4;   // plane kr, columns c4..c4+3
-      d[0] = pack_bf16x4(R.v[0].x, R.v[1].x, R.v[2].x, R.v[3].x);
-      d[1] = pack_bf16x4(R.v[0].y, R.v[1].y, R.v[2].y, R.v[3].y);
-      d[2] = pack_bf16x4(R.v[0].z, R.v[1].z, R.v[2].z, R.v[3].z);
-      d[3] = pack_bf16x4(R.v[0].w, R.v[1].w, R.v[2].w, R.v[3].w);
+      const int d = kr * (BT + BPAD) + c4;   // plane kr, columns c4..c4+3
+      put_bf16<NPL>(img, d, set_stride, R.v[0].x, R.v[1].x, R.v[2].x, R.v[3].x);
+      put_bf16<NPL>(img, d + 1, set_stride, R.v[0].y, R.v[1].y, R.v[2].y, R.v[3].y);
+      put_bf16<NPL>(img, d + 2, set_stride, R.v[0].z, R.v[1].z, R.v[2].z, R.v[3].z);
+      put_bf16<NPL>(img, d + 3, set_stride, R.v[0].w, R.v[1].w, R.v[2].w, R.v[3].w);
     }
   }
 };
@@ -200,6 +239,7 @@ struct LoadRC {
 // layout (gradient through tanh applied while staging, at LDS-store time).
 template <int BT, int BKT, bool DT = false>
 struct LoadSC {
+  static constexpr int PAD = SPAD;
   static constexpr int LPR = 8;
   static constexpr int RPP = 256 / LPR;
   static constexpr int NI = BT / RPP;
@@ -264,14 +304,15 @@ struct LoadSC {
         x.w *= (1.f - R.y[i].w * R.y[i].w);
         rsum[i] += (x.x + x.y) + (x.z + x.w);
       }
-      float* d = lds + kc * (BT + LPAD) + r;
+      float* d = lds + kc * (BT + PAD) + r;
       d[0] = x.x;
-      d[BT + LPAD] = x.y;
-      d[2 * (BT + LPAD)] = x.z;
-      d[3 * (BT + LPAD)] = x.w;
+      d[BT + PAD] = x.y;
+      d[2 * (BT + PAD)] = x.z;
+      d[3 * (BT + PAD)] = x.w;
     }
   }
-  __device__ __forceinline__ void store_bf16(uint2* img, int tid, const Regs& R) const {
+  template <int NPL>
+  __device__ __forceinline__ void store_bf16(uint2* img, int set_stride, int tid, const Regs& R) const {
     if (kc >= BKT) return;
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
@@ -284,7 +325,7 @@ struct LoadSC {
         x.w *= (1.f - R.y[i].w * R.y[i].w);
         rsum[i] += (x.x + x.y) + (x.z + x.w);
       }
-      img[(kc >> 2) * (BT + BPAD) + r] = pack_bf16x4(x.x, x.y, x.z, x.w);
+      put_bf16<NPL>(img, (kc >> 2) * (BT + BPAD) + r, set_stride, x.x, x.y, x.z, x.w);
     }
   }
 };
@@ -316,7 +357,8 @@ enum Epi : int {
 
 // One workgroup's tile; (bx, by, bz) = (tile id, batch problem, K split) -- blockIdx in the plain
 // launch, a table lookup in the grouped launch (gemm_group_kernel).
-template <int BM, int BN, int BKT, int ASRC, int BSRC, int EPI, int DT = 0 /* 1: bf16 operands */>
+template <int BM, int BN, int BKT, int ASRC, int BSRC, int EPI,
+          int DT = 0 /* 1: bf16-rounded operands, 2: 3 x bf16 split operands */>
 __device__ __forceinline__ void gemm_tile(const GemmParams& P, const int bx, const int by,
                                           const int bz) {
   constexpr int BK = BKT;
@@ -326,15 +368,19 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& P, const int bx, con
   if (BM < 128) RAU_CHAIN_PRIO();  // skinny tiles = chain-stream GEMMs
   constexpr int WM = BM / 2, WN = BN / 2;   // wave tile
   constexpr int IM = WM / 32, JN = WN / 32; // 32x32 blocks per wave
-  constexpr int LDA = BM + LPAD, LDB = BN + LPAD;
+  using LAT = typename LoaderOf<BM, BKT, ASRC, DT != 0>::type;
+  using LBT = typename LoaderOf<BN, BKT, BSRC, DT != 0>::type;
+  constexpr int LDA = BM + LAT::PAD, LDB = BN + LBT::PAD;   // k-row pitch of the f32 LDS tiles
   // 128-wide (bulk) tiles double-buffer their LDS stages; the 64-wide chain tiles keep ONE
   // stage (8.7 KB): next to two resident bulk workgroups (2 x 67.6 of 160 KB) only a
   // footprint under 12 KB lets two chain workgroups share a CU, and these launches are
   // latency-bound, so the second barrier per K-step costs nothing measurable.
-  constexpr int NST = BM >= 128 ? 2 : 1;
-  // bf16 mode: BK/4 planes of (BT + BPAD) 8-byte elements per operand and stage
-  constexpr int PLA = (BM + BPAD) * (BK / 4), PLB = (BN + BPAD) * (BK / 4);   // uint2 per stage
-  constexpr int kStage = DT ? 2 * NST * (PLA + PLB)
+  // (split mode: three plane sets per operand = 50.7 KB per stage, so a single stage)
+  constexpr int NST = DT == 2 ? 1 : (BM >= 128 ? 2 : 1);
+  constexpr int NPL = DT == 2 ? 3 : 1;          // bf16 plane sets per operand (hi | hi, mid, lo)
+  // bf16 modes: BK/4 planes of (BT + BPAD) 8-byte elements per operand, plane set and stage
+  constexpr int PLA = (BM + BPAD) * (BK / 4), PLB = (BN + BPAD) * (BK / 4);   // uint2 per set
+  constexpr int kStage = DT ? 2 * NST * NPL * (PLA + PLB)
                             : NST * BK * LDA + NST * BK * LDB;  // floats of operand staging
   // epilogue scratch lives in the (then idle) staging area: per-row vectors,
   // per-(sample,row) vectors of the samples this tile's columns touch, column sums
@@ -343,7 +389,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& P, const int bx, con
   float* As = smem;
   float* Bs = smem + NST * BK * LDA;
   uint2* Ab16 = reinterpret_cast<uint2*>(smem);
-  uint2* Bb16 = Ab16 + NST * PLA;
+  uint2* Bb16 = Ab16 + NST * NPL * PLA;
 
   const int tid = threadIdx.x;
   const int l = tid & 63, w = tid >> 6;
@@ -418,8 +464,41 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& P, const int bx, con
   // bf16 mode: per 16-deep k-step, fragment = planes 4s+2h and 4s+2h+1 of the lane's row
   auto compute_bf16 = [&](int cur) {
     const int r = l & 31, h = l >> 5;
-    const uint2* as = Ab16 + cur * PLA + wm * WM + r;
-    const uint2* bs = Bb16 + cur * PLB + wn * WN + r;
+    const uint2* as = Ab16 + cur * NPL * PLA + wm * WM + r;
+    const uint2* bs = Bb16 + cur * NPL * PLB + wn * WN + r;
+    if constexpr (DT == 2) {   // split operands: six products per 16-deep k-step
+#pragma unroll
+      for (int s = 0; s < BK / 16; ++s) {
+        bf16x8 a[IM][3], b[JN][3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+#pragma unroll
+          for (int i = 0; i < IM; ++i) {
+            const uint2 lo = as[p * PLA + (4 * s + 2 * h) * (BM + BPAD) + i * 32];
+            const uint2 hi = as[p * PLA + (4 * s + 2 * h + 1) * (BM + BPAD) + i * 32];
+            a[i][p] = __builtin_bit_cast(bf16x8, make_uint4(lo.x, lo.y, hi.x, hi.y));
+          }
+#pragma unroll
+          for (int j = 0; j < JN; ++j) {
+            const uint2 lo = bs[p * PLB + (4 * s + 2 * h) * (BN + BPAD) + j * 32];
+            const uint2 hi = bs[p * PLB + (4 * s + 2 * h + 1) * (BN + BPAD) + j * 32];
+            b[j][p] = __builtin_bit_cast(bf16x8, make_uint4(lo.x, lo.y, hi.x, hi.y));
+          }
+        }
+        // smallest terms first, so the large hi*hi term is added to an already formed correction
+        constexpr int TA[6] = {2, 1, 0, 1, 0, 0};
+        constexpr int TB[6] = {0, 1, 2, 0, 1, 0};
+#pragma unroll
+        for (int t = 0; t < 6; ++t)
+#pragma unroll
+          for (int i = 0; i < IM; ++i)
+#pragma unroll
+            for (int j = 0; j < JN; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][TA[t]], b[j][TB[t]],
+                                                                  acc[i][j], 0, 0, 0);
+      }
+      return;
+    }
 #pragma unroll
     for (int s = 0; s < BK / 16; ++s) {
       bf16x8 a[IM], b[JN];
@@ -443,8 +522,6 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& P, const int bx, con
     }
   };
 
-  using LAT = typename LoaderOf<BM, BKT, ASRC, DT != 0>::type;
-  using LBT = typename LoaderOf<BN, BKT, BSRC, DT != 0>::type;
   typename LAT::Regs ra0;
   typename LBT::Regs rb0;
   // Interior tiles (every row/column valid, reduction a whole number of K-steps: all
@@ -458,8 +535,8 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& P, const int bx, con
       LA.template load<FAST>(step0, ra0);
       LB.template load<FAST>(step0, rb0);
       if constexpr (DT != 0) {
-        LA.store_bf16(Ab16, tid, ra0);
-        LB.store_bf16(Bb16, tid, rb0);
+        LA.template store_bf16<NPL>(Ab16, PLA, tid, ra0);
+        LB.template store_bf16<NPL>(Bb16, PLB, tid, rb0);
       } else {
         LA.store(As, tid, ra0);
         LB.store(Bs, tid, rb0);
@@ -477,8 +554,8 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& P, const int bx, con
       if (NST == 1) __syncthreads();   // everyone is done reading the single stage
       if (more && !(P.dbg & 1)) {
         if constexpr (DT != 0) {
-          LA.store_bf16(Ab16 + (cur ^ 1) * PLA, tid, ra0);
-          LB.store_bf16(Bb16 + (cur ^ 1) * PLB, tid, rb0);
+          LA.template store_bf16<NPL>(Ab16 + (NST == 2 ? (cur ^ 1) : 0) * NPL * PLA, PLA, tid, ra0);
+          LB.template store_bf16<NPL>(Bb16 + (NST == 2 ? (cur ^ 1) : 0) * NPL * PLB, PLB, tid, rb0);
         } else {
           LA.store(As + (NST == 2 ? (cur ^ 1) * BK * LDA : 0), tid, ra0);
           LB.store(Bs + (NST == 2 ? (cur ^ 1) * BK * LDB : 0), tid, rb0);
@@ -630,7 +707,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& P, const int bx, con
 }
 
 template <int BM, int BN, int BKT, int ASRC, int BSRC, int EPI, int DT = 0>
-__global__ __launch_bounds__(256, DT ? 3 : 2) void gemm_kernel(const GemmParams P) {
+__global__ __launch_bounds__(256, DT == 1 ? 3 : 2) void gemm_kernel(const GemmParams P) {
   gemm_tile<BM, BN, BKT, ASRC, BSRC, EPI, DT>(P, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 

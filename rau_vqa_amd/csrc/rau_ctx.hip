@@ -120,7 +120,8 @@ int rau_create(const rau_config* cfg, rau_ctx** out) {
   NEED(c.Rq > 0 && c.Rq % 4 == 0 && c.R > 0 && c.R % 4 == 0 && c.M > 0 && c.M % 4 == 0 &&
            c.A > 0 && c.A % 4 == 0 && c.D > 0 && c.D % 4 == 0,
        "rau_create: Rq,R,M,A,D must be positive multiples of 4");
-  NEED(c.dtype == RAU_F32 || c.dtype == RAU_BF16, "rau_create: dtype %d not supported", c.dtype);
+  NEED(c.dtype == RAU_F32 || c.dtype == RAU_BF16 || c.dtype == RAU_F32S,
+       "rau_create: dtype %d not supported", c.dtype);
   const float ps[5] = {c.p_we, c.p_rnn, c.p_q, c.p_x, c.p_mf};
   for (float p : ps) NEED(p >= 0.f && p < 1.f, "rau_create: dropout p=%f out of [0,1)", p);
 
@@ -141,7 +142,7 @@ int rau_create(const rau_config* cfg, rau_ctx** out) {
   ctx->cfg = c;
   ctx->Q = 4 * c.Rq;
   ctx->Sp = (c.S + 3) & ~3;
-  ctx->bf16 = c.dtype == RAU_BF16;
+  ctx->bf16 = c.dtype;   // 0 exact f32, 1 bf16-rounded operands, 2 split operands (conv GEMMs)
   // The device Philox masks keep an element when an 8-bit draw >= round(p * 256) (fill_masks): the
   // effective drop probability is p quantised to 1/256, and the inverted-dropout scale 1/(1-p)
   // uses THAT value so that E[mask * scale] = 1 exactly (the reference's 0.5 is representable).

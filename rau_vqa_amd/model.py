@@ -37,7 +37,7 @@ class Config:
     p_x: float = 0.5
     p_mf: float = 0.5
     device_id: int = 0
-    dtype: str = "f32"      # "f32" | "bf16" (rau_dtype: bf16-operand conv GEMMs, f32 accumulate)
+    dtype: str = "f32"      # "f32" | "bf16" (bf16-rounded conv-GEMM operands) | "f32s" (3 x bf16 split)
 
     @property
     def Q(self) -> int:
@@ -77,7 +77,7 @@ class RAU:
         c = L.RauConfig(B=cfg.B, T=cfg.T, V=cfg.V, E=cfg.E, Rq=cfg.Rq, D=cfg.D, S=cfg.S,
                         M=cfg.M, A=cfg.A, R=cfg.R, K=cfg.K, H=cfg.H, p_we=cfg.p_we,
                         p_rnn=cfg.p_rnn, p_q=cfg.p_q, p_x=cfg.p_x, p_mf=cfg.p_mf,
-                        dtype={"f32": 0, "bf16": 1}[cfg.dtype],
+                        dtype={"f32": 0, "bf16": 1, "f32s": 2}[cfg.dtype],
                         device_id=cfg.device_id)
         h = C.c_void_p()
         L.check(self._lib.rau_create(C.byref(c), C.byref(h)))

@@ -7,7 +7,7 @@ from rau_vqa_amd import synth
 from rau_vqa_amd.model import RAU, Config, hop_weights
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 D = int(sys.argv[2]) if len(sys.argv) > 2 else 512
-m = RAU(Config(B=B, D=D))
+m = RAU(Config(B=B, D=D, dtype=os.environ.get('RAU_TL_DTYPE', 'f32')))
 m.init_uniform(seed=123)
 m.set_batch(**synth.make_batch(B, 26, 14000, D, 196, 1000, lens="full"))
 m.training()
