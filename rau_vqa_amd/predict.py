@@ -15,12 +15,19 @@ from __future__ import annotations
 import numpy as np
 
 
-def merge_hops(logits, dopred, att):
-    """tab_pred / tab_att of SS:690-704: H per-hop entries, then uni, then select."""
+def merge_hops(logits, dopred, att, select_att_state=None):
+    """tab_pred / tab_att of SS:690-704: H per-hop entries, then uni, then select.
+
+    select_att_state: the reference zeroes test_select_pred, test_uni_* and test_did_pred at the
+    top of predict_result (SS:671-674) but NOT test_select_att, so its "select" attention map
+    keeps accumulating across batches (it only feeds the attention PNGs).  Pass the array a
+    previous call returned as tab_att[-1] to reproduce that; None starts from zeros (what the
+    first batch sees)."""
     H, B, K = logits.shape
     did = np.zeros(B, np.float32)                       # test_did_pred:zero(), SS:674
     select_pred = np.zeros((B, K), np.float32)
-    select_att = np.zeros((B, att.shape[2]), np.float32)
+    select_att = (np.zeros((B, att.shape[2]), np.float32) if select_att_state is None
+                  else np.array(select_att_state, np.float32))   # never zeroed, SS:671-674
     for h in range(H):
         do = (dopred[h] > 0.5).astype(np.float32)       # SS:683
         if h == H - 1:
@@ -60,11 +67,13 @@ def answers(tab_pred, mc_ans=None):
     return oe, mc
 
 
-def predict_result(rau, feats, tokens, lens, mc_ans=None):
-    """SS:633-705 + SS:877-900 for one batch: returns dict(tab_pred, tab_att, oe, mc)."""
+def predict_result(rau, feats, tokens, lens, mc_ans=None, select_att_state=None):
+    """SS:633-705 + SS:877-900 for one batch: returns dict(tab_pred, tab_att, oe, mc).
+    select_att_state: see merge_hops (carry tab_att[-1] from batch to batch to reproduce the
+    reference's never-zeroed test_select_att)."""
     rau.evaluate()
     rau.set_batch(feats, tokens, lens, None)
     rau.forward()
-    tab_pred, tab_att = merge_hops(rau.logits(), rau.dopred(), rau.attention())
+    tab_pred, tab_att = merge_hops(rau.logits(), rau.dopred(), rau.attention(), select_att_state)
     oe, mc = answers(tab_pred, mc_ans)
     return {"tab_pred": tab_pred, "tab_att": tab_att, "oe": oe, "mc": mc}

@@ -84,3 +84,16 @@ def test_predict_result_on_device_matches_oracle_forward():
         assert util.rel_err(a, b) < 1e-4
     roe, rmc = predict.answers(rp, mc)
     assert np.array_equal(out["oe"], roe) and np.array_equal(out["mc"], rmc)
+
+
+def test_select_att_accumulates_across_batches_like_the_reference():
+    """SS:671-674 zero every merge buffer except test_select_att: carried over, it accumulates."""
+    rng = np.random.default_rng(3)
+    H, B, K, S = 3, 5, 7, 4
+    lg = rng.standard_normal((H, B, K)).astype(np.float32)
+    dp = rng.random((H, B)).astype(np.float32)
+    att = rng.random((H, B, S)).astype(np.float32)
+    _, ta1 = predict.merge_hops(lg, dp, att)
+    _, ta2 = predict.merge_hops(lg, dp, att, select_att_state=ta1[-1])
+    assert np.allclose(ta2[-1], 2.0 * ta1[-1])
+    assert np.array_equal(ta2[-2], ta1[-2])            # uni_att IS zeroed every batch
