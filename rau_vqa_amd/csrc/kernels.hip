@@ -373,9 +373,9 @@ hipError_t lstm_bwd_multi(hipStream_t st, int order, int nB, int R, const LstmBw
 static int att_waves(bool bwd) {
   static const int v[2] = {
       [] { const char* e = std::getenv("RAU_ATT_WAVES_FWD"); const int n = e ? std::atoi(e) : 0;
-           return (n == 4 || n == 8 || n == 16) ? n : 8; }(),
+           return (n == 4 || n == 8 || n == 16) ? n : 16; }(),
       [] { const char* e = std::getenv("RAU_ATT_WAVES_BWD"); const int n = e ? std::atoi(e) : 0;
-           return (n == 4 || n == 8 || n == 16) ? n : 8; }()};
+           return (n == 4 || n == 8 || n == 16) ? n : 16; }()};
   return v[bwd ? 1 : 0];
 }
 

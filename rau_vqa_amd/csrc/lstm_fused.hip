@@ -30,7 +30,6 @@ namespace {
 
 constexpr int FBK = 16;          // k per LDS stage and per source
 constexpr int FLD = 64 + 16;     // k-row pitch (floats): 16 mod 32 -> conflict-free fragment reads
-constexpr int FD = 8;            // K-steps of global loads in flight per thread
 
 template <int ORDER> struct Slots;
 template <> struct Slots<GATES_ATT> { enum { I = 0, G = 1, F = 2, O = 3 }; };

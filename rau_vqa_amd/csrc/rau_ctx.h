@@ -118,8 +118,8 @@ struct rau_ctx {
       *dl, *lossrow, *dopred, *losses_d, *hopw_d;
   int32_t* argmax_d;
   float* att_part = nullptr;  // [B][chunks][S] partial column sums of the split attention kernels
-  bool att_fused = false;
-  bool enc_fused = true;      // encoder forward: one fused GEMM + cell launch per wavefront step
+  bool att_split_env = false; // RAU_ATT_SPLIT: 4-wave row-chunk attention kernels instead of the fused ones
+  bool enc_fused_env = false; // RAU_ENC_FUSED: fused GEMM + cell launch per encoder step also in training
   float* hopw_h = nullptr;    // pinned staging of the hop weights, 2 slots of H
   int hopw_slot = 0;
   // backward temporaries

@@ -331,8 +331,12 @@ int rau_create(const rau_config* cfg, rau_ctx** out) {
   CK(dalloc(ctx, &ctx->WpT, (size_t)A * M));
   CK(dalloc(ctx, &ctx->zm, (size_t)B * S));
   CK(dalloc(ctx, &ctx->att_part, att_split_part_floats(B, S)));
-  ctx->att_fused = std::getenv("RAU_ATT_FUSED") != nullptr;
-  ctx->enc_fused = std::getenv("RAU_ENC_UNFUSED") == nullptr;    // A/B knob: split-K GEMM + cell launches   // A/B knob: the one-workgroup-per-sample kernels
+  // Same-box A/B (B=256, D=512, ms/step): fused 16-wave attention + split-K encoder 10.54-10.59,
+  // split attention + fused encoder step 10.92-10.95, round-1 library 10.75-10.82.  The split
+  // attention kernels and the fused LSTM step are faster ALONE (no bulk GEMM beside them): the
+  // evaluate-mode forward uses the fused LSTM step; RAU_ATT_SPLIT / RAU_ENC_FUSED force them.
+  ctx->att_split_env = std::getenv("RAU_ATT_SPLIT") != nullptr;
+  ctx->enc_fused_env = std::getenv("RAU_ENC_FUSED") != nullptr;
   CK(dalloc(ctx, &ctx->a, HB * S));
   CK(dalloc(ctx, &ctx->jv, (size_t)B * M));
   CK(dalloc(ctx, &ctx->j, HB * M));
@@ -712,7 +716,7 @@ int hop_forward_chain(rau_ctx* ctx, int h, const float* cp, const float* hp, flo
     ap.z_ns = ns_z; ap.z_bias = ctx->att_mem.b;
     ap.SL = SL;
     ap.u_out = ctx->u + (size_t)h * B * A;   // tanh(P + u) itself is not kept: 25 % less traffic here
-    if (ctx->att_fused)
+    if (!(ctx->att_split_env))
       RUN("att_fwd_fused", 2.0 * B * S * (A + M), ((double)B * A * S + BM_ * S) * 4,
           att_fwd_fused(st, B, M, A, S, Pin, slab_u, ctx->att_score.W, ctx->att_score.b, slab_z, Ih, qf,
                         nullptr, ah, ctx->jv, ap));
@@ -900,7 +904,7 @@ int hop_backward(rau_ctx* ctx, int h, const float* cp, const float* Ih, const Ho
     RUN("small_gemm", gflop(B, SL, M), 0,
         gemm_nn(st, B, SL, M, djh, M, ctx->feat_attprob.W, SL, ctx->da_lin, S, o));
   }
-  if (ctx->att_fused)
+  if (!(ctx->att_split_env))
     RUN("att_bwd_fused", 2.0 * B * S * (A + M), ((double)B * A * S * 2 + BM_ * S) * 4,
         att_bwd_fused(st, B, M, A, S, Ih, djh, ah, ctx->slab, ctx->att_score.W, Th, dzh, duh,
                       ctx->dwsp + (size_t)h * B * A, ctx->I_shared ? ctx->P0 : Th,
@@ -999,7 +1003,7 @@ int rau_forward(rau_ctx* ctx) {
       RUN("enc_i2h_gemm", gflop(rows, 4 * Rq, E), 0,
           gemm_nt(st, rows, 4 * Rq, E, ctx->we, E, ctx->i2h[0].W, E, ctx->G1, 4 * Rq, o));
     }
-    if (ctx->enc_fused) {
+    if (ctx->enc_fused_env || ctx->mode == RAU_MODE_EVAL) {
       // one launch per wavefront step: gate GEMM + cell fused (lstm_fused.hip)
       for (int s = 1; s <= TL + 1; ++s) {
         LstmStepParams sp{};

@@ -1,13 +1,8 @@
 run() { echo "== $*"; env "$@" python tools/tlrun.py 2>&1 | grep ms/step; }
+for i in 1 2; do
 run A=1
-run RAU_SKINNY_WGS=256
-run RAU_SKINNY_WGS=96
-run RAU_HOP_GROUPS=3,2,2,1
-run RAU_HOP_GROUPS=2,2,2,2
-run RAU_HOP_GROUPS=4,2,2
-run RAU_ATT_CHUNKS=8
-run RAU_ATT_FUSED=1
-run RAU_WGRAD_WGS=768
-run RAU_GROUP_WGS=1024
-run RAU_ENC_CHUNKS=3
-run A=1
+run RAU_LIB=rau_vqa_amd/librau_r01.so
+run RAU_ATT_SPLIT=1
+run RAU_ENC_FUSED=1
+run RAU_ATT_WAVES_BWD=8
+done
