@@ -26,6 +26,8 @@ hipError_t conv_embed_fwd(hipStream_t st, int nB, int D, int S, int M, const flo
   P.C = I; P.c_bs = (long)M * S;
   P.bias = bi;
   P.act = 1;
+  if (!bf16 && conv_sample_ok(S, 1))   // 14 x 14 maps: one sample per tile column block (gemm_sample.hip)
+    return conv_sample(st, 0, nB, M, D, S, WiT, M, X, (long)D * S, I, (long)M * S, bi, 1, nullptr, nullptr);
   if (bf16 == 2) return launch_gemm<128, 128, BK, SRC_RC, SRC_RC_FLAT, EPI_CONV, 2>(st, P, 1);
   if (bf16) return launch_gemm<128, 128, BK, SRC_RC, SRC_RC_FLAT, EPI_CONV, 1>(st, P, 1);
   return launch_gemm<128, 128, BK, SRC_RC, SRC_RC_FLAT, EPI_CONV>(st, P, 1);
@@ -44,6 +46,8 @@ hipError_t conv_att_pre(hipStream_t st, int nB, int M, int S, int A, const float
   P.C = Pout; P.c_bs = (long)A * S;
   P.bias = bp;
   P.act = 0;
+  if (!bf16 && conv_sample_ok(S, 2))
+    return conv_sample(st, 0, nB, A, M, S, WpT, A, I, (long)M * S, Pout, (long)A * S, bp, 0, nullptr, nullptr);
   if (bf16 == 2) return launch_gemm<128, 128, BK, SRC_RC, SRC_RC_FLAT, EPI_CONV, 2>(st, P, 1);
   if (bf16) return launch_gemm<128, 128, BK, SRC_RC, SRC_RC_FLAT, EPI_CONV, 1>(st, P, 1);
   return launch_gemm<128, 128, BK, SRC_RC, SRC_RC_FLAT, EPI_CONV>(st, P, 1);
@@ -63,6 +67,8 @@ hipError_t conv_att_dgrad(hipStream_t st, int nB, int M, int S, int A, const flo
   P.S = S;
   P.C = dI; P.c_bs = (long)M * S;
   P.v1 = dj; P.v2 = a;
+  if (!bf16 && conv_sample_ok(S, 4))
+    return conv_sample(st, 1, nB, M, A, S, Wp, M, dS, (long)A * S, dI, (long)M * S, nullptr, 0, dj, a);
   if (bf16 == 2) return launch_gemm<128, 128, BK, SRC_RC, SRC_RC_FLAT, EPI_OUTER, 2>(st, P, 1);
   if (bf16) return launch_gemm<128, 128, BK, SRC_RC, SRC_RC_FLAT, EPI_OUTER, 1>(st, P, 1);
   return launch_gemm<128, 128, BK, SRC_RC, SRC_RC_FLAT, EPI_OUTER>(st, P, 1);
@@ -81,6 +87,8 @@ hipError_t conv_embed_dgrad(hipStream_t st, int nB, int D, int S, int M, const f
   P.C = dX; P.c_bs = (long)D * S;
   P.bias = nullptr;
   P.act = 0;
+  if (conv_sample_ok(S, 8))
+    return conv_sample(st, 0, nB, D, M, S, Wi, D, dZ, (long)M * S, dX, (long)D * S, nullptr, 0, nullptr, nullptr);
   return launch_gemm<128, 128, BK, SRC_RC, SRC_RC_FLAT, EPI_CONV>(st, P, 1);
 }
 

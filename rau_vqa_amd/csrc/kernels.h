@@ -76,6 +76,12 @@ hipError_t conv_embed_fwd(hipStream_t st, int nB, int D, int S, int M, const flo
 // P[b,k,s] = sum_m Wp[k,m] I[b,m,s] + bp[k]   (hop-invariant half of SS:244-252)
 hipError_t conv_att_pre(hipStream_t st, int nB, int M, int S, int A, const float* I,
                         const float* WpT /* [M][A] */, const float* bp, float* P, int bf16 = 0);
+// Same three products with one sample per tile (gemm_sample.hip), used for 14 x 14 maps:
+// C[b,m,s] = epi(sum_k Wt[k,m] X[b,k,s]); epi 0: act(. + bias[m]), epi 1: . + dj[b,m] a[b,s]
+bool conv_sample_ok(int S, int which);
+hipError_t conv_sample(hipStream_t st, int epi, int nB, int M, int K, int S, const float* Wt,
+                       long w_rs, const float* X, long x_bs, float* C, long c_bs,
+                       const float* bias, int act, const float* dj, const float* av);
 // out[c][r] = in[r][c]  (rows x cols -> cols x rows); used once per step on the two
 // 1x1-conv weights so the forward conv GEMMs get a row-contiguous A operand
 hipError_t transpose2d(hipStream_t st, int rows, int cols, const float* in, float* out);
