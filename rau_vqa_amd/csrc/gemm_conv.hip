@@ -126,9 +126,16 @@ static hipError_t conv_wgrad(hipStream_t st, GemmParams P, int nB, int S, float*
   P.nk_per_split = spb * P.cps;
   const int splits = (P.nk + P.nk_per_split - 1) / P.nk_per_split;
   P.rs_out = drow ? slab + (size_t)splits * P.M * P.N : nullptr;
-  dim3 grid(P.tiles_m * P.tiles_n, 1, splits);
-  hipLaunchKernelGGL((gemm_kernel<128, 128, BKT, ASRC, SRC_SC, EPI_SLAB, DT>), grid, dim3(256), 0,
-                     st, P);
+  static const bool xcd_off = std::getenv("RAU_WGRAD_NOXCD") != nullptr;   // A/B knob
+  if (xcd_off) {
+    dim3 grid(P.tiles_m * P.tiles_n, 1, splits);
+    hipLaunchKernelGGL((gemm_kernel<128, 128, BKT, ASRC, SRC_SC, EPI_SLAB, DT>), grid, dim3(256), 0,
+                       st, P);
+  } else {   // a split's tiles share an XCD (and its L2 copy of the split's samples)
+    dim3 grid(8 * ((splits + 7) / 8) * P.tiles_m * P.tiles_n);
+    hipLaunchKernelGGL((gemm_split_xcd_kernel<128, 128, BKT, ASRC, SRC_SC, EPI_SLAB, DT>), grid,
+                       dim3(256), 0, st, P, splits);
+  }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   e = splitk_reduce_acc(st, (size_t)P.M * P.N, splits, slab, (size_t)P.M * P.N, dW);

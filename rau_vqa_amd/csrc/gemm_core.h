@@ -711,6 +711,26 @@ __global__ __launch_bounds__(256, DT == 1 ? 3 : 2) void gemm_kernel(const GemmPa
   gemm_tile<BM, BN, BKT, ASRC, BSRC, EPI, DT>(P, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
+// Split-K launch whose workgroups are laid out so that ALL TILES OF ONE K-SPLIT SHARE AN XCD.
+// The conv weight gradients have few output tiles (8 or 16) and many K splits (whole samples per
+// split); every tile of a split streams the same samples' operand rows.  With a (tiles, 1, splits)
+// grid the linear workgroup id is x + tiles * z, and workgroups are dealt to the 8 XCDs round-robin
+// by that id: tiles a multiple of 8 puts tile x of EVERY split on XCD x % 8, i.e. the 16 tiles that
+// share operand data sit on 8 different L2s and each fetches it again (measured: 3.9x / 5.7x the
+// algorithmic bytes leave L2 for conv_att_wgrad / conv_embed_wgrad).  Here the grid is 1-D:
+// workgroup L -> XCD r = L % 8, q = L / 8, split = r + 8 * (q / tiles), tile = q % tiles, so a
+// split's tiles are consecutive on one XCD (placement is a speed matter only: any mapping is
+// correct).  Grid = 8 * ceil(splits / 8) * tiles; surplus workgroups exit.
+template <int BM, int BN, int BKT, int ASRC, int BSRC, int EPI, int DT = 0>
+__global__ __launch_bounds__(256, DT == 1 ? 3 : 2) void gemm_split_xcd_kernel(const GemmParams P,
+                                                                               const int splits) {
+  const int tiles = P.tiles_m * P.tiles_n;
+  const int L = blockIdx.x, r = L & 7, q = L >> 3;
+  const int split = r + 8 * (q / tiles), tile = q % tiles;
+  if (split >= splits) return;
+  gemm_tile<BM, BN, BKT, ASRC, BSRC, EPI, DT>(P, tile, 0, split);
+}
+
 // Grouped launch: up to kGroupMax independent split-K problems C_p = A_p^T B_p (the Linear weight
 // gradients of one parameter group) in ONE grid.  Workgroup g belongs to problem p with
 // wg0[p] <= g < wg0[p+1]; inside it, tile = (g - wg0[p]) % tiles, split = (g - wg0[p]) / tiles.

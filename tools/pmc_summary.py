@@ -8,8 +8,8 @@ import sys
 
 
 def short(n):
+    n = n.replace("(anonymous namespace)::", "")
     n = re.sub(r"\(.*", "", n).replace("void ", "").replace("rau::", "")
-    n = re.sub(r"\(anonymous namespace\)::", "", n)
     return n[:90]
 
 
