@@ -74,6 +74,17 @@ hipError_t conv_att_dgrad(hipStream_t st, int nB, int M, int S, int A, const flo
   return launch_gemm<128, 128, BK, SRC_RC, SRC_RC_FLAT, EPI_OUTER>(st, P, 1);
 }
 
+bool conv_dz_fused_ok(int S, int M, int bf16) {
+  static const bool off = std::getenv("RAU_DZ_UNFUSED") != nullptr;   // A/B knob
+  return !off && !bf16 && M % 4 == 0 && conv_sample_ok(S, 4);
+}
+hipError_t conv_att_dgrad_dz(hipStream_t st, int nB, int M, int S, int A, const float* dS,
+                             const float* Wp, const float* dj, const float* a, const float* I,
+                             float* dZ, float* rs) {
+  return conv_sample(st, 2, nB, M, A, S, Wp, M, dS, (long)A * S, dZ, (long)M * S, nullptr, 0, dj, a,
+                     I, rs);
+}
+
 // dX'[b,d,s] = sum_m Wi[m,d] dZ[b,m,s]: gradient w.r.t. i_embed's (dropped-out) input.  The
 // reference computes it and discards it (SS:579); only the module-level
 // rau_multimodal_backward forms it, and only on request.
@@ -167,11 +178,12 @@ hipError_t conv_att_wgrad(hipStream_t st, int nB, int M, int S, int A, const flo
 // staging the operand (nB may be a group of hops)
 hipError_t conv_embed_wgrad(hipStream_t st, int nB, int D, int S, int M, const float* dI,
                             const float* I, const float* X, float* dWi, float* slab, int bf16,
-                            float* dbi) {
+                            float* dbi, int dz_final) {
   GemmParams P{};
   P.M = M; P.N = D;
   P.A = dI; P.A2 = I; P.a_bs = (long)M * S;
   P.B = X; P.b_bs = (long)D * S;
+  if (dz_final) return conv_wgrad_any<SRC_SC>(st, P, nB, S, dWi, slab, bf16);
   return conv_wgrad_any<SRC_SC_DTANH>(st, P, nB, S, dWi, slab, bf16, dbi);
 }
 

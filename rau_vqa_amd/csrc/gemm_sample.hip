@@ -41,7 +41,8 @@ struct SampleParams {
   const float* X; long x_bs;           // [b][K][S]
   float* C; long c_bs;                 // [b][M][S]
   const float* bias; int act;          // EPI 0
-  const float* dj; const float* av;    // EPI 1: + dj[b,m] * a[b,s]
+  const float* dj; const float* av;    // EPI 1, 2: + dj[b,m] * a[b,s]
+  const float* Y; float* rs;           // EPI 2: * (1 - Y[b,m,s]^2); rs[b,m] = sum_s of the result
 };
 
 template <int EPI>
@@ -155,20 +156,22 @@ __global__ __launch_bounds__(256, 2) void k_conv_sample(const SampleParams P) {
     }
     rowv[tid] = v;
   }
-  if (EPI == 1 && tid < SBN) colv[tid] = tid < S ? P.av[(size_t)b * S + tid] : 0.f;
+  if (EPI >= 1 && tid < SBN) colv[tid] = tid < S ? P.av[(size_t)b * S + tid] : 0.f;
   __syncthreads();
   float* Cb = P.C + (size_t)b * P.c_bs;
+  const float* Yb = EPI == 2 ? P.Y + (size_t)b * P.c_bs : nullptr;
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int rl = w * 32 + i * 16 + lr;
     const int m = m0 + rl;
-    if (m >= P.M) continue;
+    const bool mok = m < P.M;
     const float rv = rowv[rl];
-    float* crow = Cb + (size_t)m * S;
+    float* crow = Cb + (size_t)(mok ? m : 0) * S;
+    float rsum = 0.f;
 #pragma unroll
     for (int j = 0; j < SNCB; ++j) {
       const int s = j * 16 + 4 * lq;
-      if (s >= S) continue;        // S % 4 == 0: a float4 is all valid or all pad
+      if (s >= S || !mok) continue;   // S % 4 == 0: a float4 is all valid or all pad
       float4 v = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
       if (EPI == 0) {
         v.x += rv; v.y += rv; v.z += rv; v.w += rv;
@@ -176,8 +179,19 @@ __global__ __launch_bounds__(256, 2) void k_conv_sample(const SampleParams P) {
       } else {
         const float4 c4 = *reinterpret_cast<const float4*>(colv + s);
         v.x += rv * c4.x; v.y += rv * c4.y; v.z += rv * c4.z; v.w += rv * c4.w;
+        if (EPI == 2) {   // gradient through i_embed's tanh, and its row sums (the bias gradient)
+          const float4 y = *reinterpret_cast<const float4*>(Yb + (size_t)m * S + s);
+          v.x *= 1.f - y.x * y.x; v.y *= 1.f - y.y * y.y;
+          v.z *= 1.f - y.z * y.z; v.w *= 1.f - y.w * y.w;
+          rsum += (v.x + v.y) + (v.z + v.w);
+        }
       }
       *reinterpret_cast<float4*>(crow + s) = v;
+    }
+    if (EPI == 2) {   // the four lanes lr, lr+16, lr+32, lr+48 hold the row's four position quarters
+      rsum += __shfl_xor(rsum, 16, 64);
+      rsum += __shfl_xor(rsum, 32, 64);
+      if (lq == 0 && mok) P.rs[(size_t)b * P.M + m] = rsum;
     }
   }
 }
@@ -192,10 +206,12 @@ bool conv_sample_ok(int S, int which) {
   return (mask & which) && S % 4 == 0 && S > 176 && S <= SBN;
 }
 
-// EPI 0: C = act(acc + bias[m]);  EPI 1: C = acc + dj[b,m] a[b,s]
+// EPI 0: C = act(acc + bias[m]);  EPI 1: C = acc + dj[b,m] a[b,s];
+// EPI 2: C = (acc + dj[b,m] a[b,s]) (1 - Y[b,m,s]^2) and rs[b,m] = sum_s C[b,m,s]
 hipError_t conv_sample(hipStream_t st, int epi, int nB, int M, int K, int S, const float* Wt,
                        long w_rs, const float* X, long x_bs, float* C, long c_bs,
-                       const float* bias, int act, const float* dj, const float* av) {
+                       const float* bias, int act, const float* dj, const float* av,
+                       const float* Y, float* rs) {
   if (!(S % 4 == 0 && S > 176 && S <= SBN) || M % 4 != 0) return hipErrorInvalidValue;
   SampleParams P{};
   P.M = M; P.K = K; P.S = S; P.nB = nB;
@@ -205,11 +221,14 @@ hipError_t conv_sample(hipStream_t st, int epi, int nB, int M, int K, int S, con
   P.C = C; P.c_bs = c_bs;
   P.bias = bias; P.act = act;
   P.dj = dj; P.av = av;
+  P.Y = Y; P.rs = rs;
   const dim3 grid(P.tiles_m * nB), block(256);
   if (epi == 0)
     hipLaunchKernelGGL(k_conv_sample<0>, grid, block, 0, st, P);
-  else
+  else if (epi == 1)
     hipLaunchKernelGGL(k_conv_sample<1>, grid, block, 0, st, P);
+  else
+    hipLaunchKernelGGL(k_conv_sample<2>, grid, block, 0, st, P);
   return hipGetLastError();
 }
 

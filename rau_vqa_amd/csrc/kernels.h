@@ -81,7 +81,8 @@ hipError_t conv_att_pre(hipStream_t st, int nB, int M, int S, int A, const float
 bool conv_sample_ok(int S, int which);
 hipError_t conv_sample(hipStream_t st, int epi, int nB, int M, int K, int S, const float* Wt,
                        long w_rs, const float* X, long x_bs, float* C, long c_bs,
-                       const float* bias, int act, const float* dj, const float* av);
+                       const float* bias, int act, const float* dj, const float* av,
+                       const float* Y = nullptr, float* rs = nullptr);
 // out[c][r] = in[r][c]  (rows x cols -> cols x rows); used once per step on the two
 // 1x1-conv weights so the forward conv GEMMs get a row-contiguous A operand
 hipError_t transpose2d(hipStream_t st, int rows, int cols, const float* in, float* out);
@@ -89,6 +90,14 @@ hipError_t transpose2d(hipStream_t st, int rows, int cols, const float* in, floa
 hipError_t conv_att_dgrad(hipStream_t st, int nB, int M, int S, int A, const float* dS,
                           const float* Wp, const float* dj, const float* a, float* dI,
                           int bf16 = 0);
+// Same product with the gradient through i_embed's tanh and the bias-gradient row sums in its
+// epilogue: dZ[b,m,s] = (sum_k Wp[k,m] dS[b,k,s] + dj[b,m] a[b,s]) (1 - I[b,m,s]^2),
+// rs[b,m] = sum_s dZ[b,m,s].  Only where the per-sample tiling applies (conv_dz_fused_ok): the
+// i_embed weight gradient then takes dZ with its plain operand loader (dz_final below).
+bool conv_dz_fused_ok(int S, int M, int bf16);
+hipError_t conv_att_dgrad_dz(hipStream_t st, int nB, int M, int S, int A, const float* dS,
+                             const float* Wp, const float* dj, const float* a, const float* I,
+                             float* dZ, float* rs);
 // dX'[b,d,s] = sum_m Wi[m,d] dZ[b,m,s]   (dead in feval, SS:579; module-level API only)
 hipError_t conv_embed_dgrad(hipStream_t st, int nB, int D, int S, int M, const float* dZ,
                             const float* Wi, float* dX);
@@ -99,7 +108,8 @@ hipError_t conv_att_wgrad(hipStream_t st, int nB, int M, int S, int A, const flo
                           const float* I, float* dWp, float* slab, int bf16 = 0);
 hipError_t conv_embed_wgrad(hipStream_t st, int nB, int D, int S, int M, const float* dI,
                             const float* I, const float* X, float* dWi, float* slab,
-                            int bf16 = 0, float* dbi = nullptr /* += sum_{b,s} dZ[b,m,s] */);
+                            int bf16 = 0, float* dbi = nullptr /* += sum_{b,s} dZ[b,m,s] */,
+                            int dz_final = 0 /* dI already holds dZ: no tanh factor, no dbi */);
 
 // --------------------------------------------------------- pointwise (kernels.hip)
 enum GateOrder { GATES_ATT = 0 /* i g f o, ATTLSTM.lua:12-19 */,

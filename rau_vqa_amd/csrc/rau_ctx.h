@@ -125,7 +125,7 @@ struct rau_ctx {
   // backward temporaries
   // dZ holds dI (gradient at i_embed's OUTPUT); the tanh derivative is applied by its consumers
   float *dpre, *dhn, *dg4, *dcn[2], *dhp[2], *dj, *da_lin, *dz, *du, *dwsp, *dZ,
-      *dqt, *dQD, *dq, *slab, *slab2, *slab3, *coltmp3, *tmpS;
+      *dqt, *dQD, *dq, *slab, *slab2, *slab3, *coltmp3, *tmpS, *coltmp2, *dbi_part;
   size_t slab3_floats = 0;
   float *dG1, *dG2, *dwe, *edc[2][2];
   size_t slab_floats = 0;

@@ -406,6 +406,8 @@ int rau_create(const rau_config* cfg, rau_ctx** out) {
   {
     const int widest = std::max({4 * R, 4 * Rq, K, M, S, A, Q});
     CK(dalloc(ctx, &ctx->coltmp3, (size_t)32 * widest));
+    CK(dalloc(ctx, &ctx->coltmp2, (size_t)32 * widest));      // the bulk stream's column-sum scratch
+    CK(dalloc(ctx, &ctx->dbi_part, (size_t)H * B * M));       // per-sample row sums of dZ
     CK(dalloc(ctx, &ctx->tmpS, (size_t)S));
   }
   CK(dalloc(ctx, &ctx->dG1, TB * 4 * Rq));
@@ -1278,19 +1280,33 @@ int rau_backward(rau_ctx* ctx, const float* hop_w) {
       if (!ctx->I_shared) {
         const int nH = (std::min(h + gsz[h], HA) - h) * B;   // active hops of this group
         const size_t hb = (size_t)h * B;
-        RUNS(sb, "conv_att_dgrad", gflop(M, (double)nH * S, A),
-             ((double)nH * A * S + 2.0 * nH * M * S) * 4,
-             conv_att_dgrad(sb, nH, M, S, A, ctx->T + hb * A * S, ctx->att_i.W, ctx->dj + hb * M,
-                            ctx->a + hb * S, ctx->dZ + hb * M * S, ctx->bf16));
+        // Where the per-sample tiling applies the dgrad's epilogue also applies (1 - I^2) and
+        // hands back per-sample row sums (the i_embed bias gradient): the i_embed weight gradient
+        // then stages a plain operand (one global load and no VALU work per element less).
+        const int dzf = conv_dz_fused_ok(S, M, ctx->bf16);
+        if (dzf)
+          RUNS(sb, "conv_att_dgrad", gflop(M, (double)nH * S, A),
+               ((double)nH * A * S + 3.0 * nH * M * S) * 4,
+               conv_att_dgrad_dz(sb, nH, M, S, A, ctx->T + hb * A * S, ctx->att_i.W, ctx->dj + hb * M,
+                                 ctx->a + hb * S, ctx->I + hb * M * S, ctx->dZ + hb * M * S,
+                                 ctx->dbi_part + hb * M));
+        else
+          RUNS(sb, "conv_att_dgrad", gflop(M, (double)nH * S, A),
+               ((double)nH * A * S + 2.0 * nH * M * S) * 4,
+               conv_att_dgrad(sb, nH, M, S, A, ctx->T + hb * A * S, ctx->att_i.W, ctx->dj + hb * M,
+                              ctx->a + hb * S, ctx->dZ + hb * M * S, ctx->bf16));
         RUNS(sb, "conv_att_wgrad", gflop(A, M, (double)nH * S),
              ((double)nH * A * S + (double)nH * M * S) * 4,
              conv_att_wgrad(sb, nH, M, S, A, ctx->T + hb * A * S, ctx->I + hb * M * S,
                             ctx->att_i.dW, ctx->slab2, ctx->bf16));
         RUNS(sb, "conv_embed_wgrad", gflop(M, D, (double)nH * S),
-             ((double)nH * M * S + (double)nH * D * S) * 4,
+             ((double)nH * M * S * (dzf ? 1 : 2) + (double)nH * D * S) * 4,
              conv_embed_wgrad(sb, nH, D, S, M, ctx->dZ + hb * M * S, ctx->I + hb * M * S,
                               ctx->xd + hb * D * S, ctx->i_embed.dW, ctx->slab2, ctx->bf16,
-                              ctx->i_embed.db));
+                              ctx->i_embed.db, dzf));
+        if (dzf && h == 0)   // last group: i_embed bias gradient = column sums of the per-sample rows
+          RUNS(sb, "colsum", 0, (double)HA * B * M * 4,
+               colsum_acc(sb, HA * B, M, ctx->dbi_part, M, ctx->i_embed.db, ctx->coltmp2));
       } else {
         for (int hh2 = 0; hh2 < HA; ++hh2) {  // evaluate mode: I (and X) shared by all hops
           float* Th2 = ctx->T + (size_t)hh2 * B * A * S;

@@ -1,5 +1,5 @@
 run() { echo "== $*"; env "$@" python tools/tlrun.py 2>&1 | grep ms/step; }
 for i in 1 2 3; do
 run A=1
-run RAU_WGRAD_NOXCD=1
+run RAU_DZ_UNFUSED=1
 done
