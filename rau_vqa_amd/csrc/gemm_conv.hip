@@ -17,7 +17,7 @@ constexpr int BK = 32;
 // loader), B = X' [b][d][s] (position contiguous; dropout already applied by
 // dropout_features).  nB may be a group of hops.
 hipError_t conv_embed_fwd(hipStream_t st, int nB, int D, int S, int M, const float* X,
-                          const float* WiT, const float* bi, float* I, int bf16) {
+                          const float* WiT, const float* bi, float* I, int bf16, int one_per_cu) {
   GemmParams P{};
   P.M = M; P.N = nB * S; P.K = D; P.nk = (D + BK - 1) / BK;
   P.A = WiT; P.a_rs = M;
@@ -30,14 +30,14 @@ hipError_t conv_embed_fwd(hipStream_t st, int nB, int D, int S, int M, const flo
     return conv_sample(st, 0, nB, M, D, S, WiT, M, X, (long)D * S, I, (long)M * S, bi, 1, nullptr, nullptr);
   if (bf16 == 2) return launch_gemm<128, 128, BK, SRC_RC, SRC_RC_FLAT, EPI_CONV, 2>(st, P, 1);
   if (bf16) return launch_gemm<128, 128, BK, SRC_RC, SRC_RC_FLAT, EPI_CONV, 1>(st, P, 1);
-  return launch_gemm<128, 128, BK, SRC_RC, SRC_RC_FLAT, EPI_CONV>(st, P, 1);
+  return launch_gemm<128, 128, BK, SRC_RC, SRC_RC_FLAT, EPI_CONV>(st, P, 1, one_per_cu ? 30 * 1024 : 0);
 }
 
 // P[b,k,s] = sum_m Wp[k,m] I[b,m,s] + bp[k]: the hop-invariant part of attbycontent's
 // pre-activation (reference SS:247-249); nB may be H*B.  The per-hop part
 // (+ u[b,k], tanh, score, softmax) is att_fwd_fused in kernels.hip.
 hipError_t conv_att_pre(hipStream_t st, int nB, int M, int S, int A, const float* I,
-                        const float* WpT, const float* bp, float* Pout, int bf16) {
+                        const float* WpT, const float* bp, float* Pout, int bf16, int one_per_cu) {
   GemmParams P{};
   P.M = A; P.N = nB * S; P.K = M; P.nk = (M + BK - 1) / BK;
   P.A = WpT; P.a_rs = A;                // Wp^T [M][A]: reduction-major
@@ -50,7 +50,7 @@ hipError_t conv_att_pre(hipStream_t st, int nB, int M, int S, int A, const float
     return conv_sample(st, 0, nB, A, M, S, WpT, A, I, (long)M * S, Pout, (long)A * S, bp, 0, nullptr, nullptr);
   if (bf16 == 2) return launch_gemm<128, 128, BK, SRC_RC, SRC_RC_FLAT, EPI_CONV, 2>(st, P, 1);
   if (bf16) return launch_gemm<128, 128, BK, SRC_RC, SRC_RC_FLAT, EPI_CONV, 1>(st, P, 1);
-  return launch_gemm<128, 128, BK, SRC_RC, SRC_RC_FLAT, EPI_CONV>(st, P, 1);
+  return launch_gemm<128, 128, BK, SRC_RC, SRC_RC_FLAT, EPI_CONV>(st, P, 1, one_per_cu ? 30 * 1024 : 0);
 }
 
 // backward of attbycontent + attselect into the gradient w.r.t. i_embed's OUTPUT:

@@ -767,7 +767,7 @@ __global__ __launch_bounds__(256, 2) void gemm_group_kernel(const GroupParams G)
 
 // ------------------------------------------------------------ host launch
 template <int BM, int BN, int BKT, int ASRC, int BSRC, int EPI, int DT = 0>
-inline hipError_t launch_gemm(hipStream_t st, GemmParams P, int splits) {
+inline hipError_t launch_gemm(hipStream_t st, GemmParams P, int splits, int dyn_lds = 0) {
   P.tiles_m = (P.M + BM - 1) / BM;
   P.tiles_n = (P.N + BN - 1) / BN;
   if (splits < 1) splits = 1;
@@ -775,7 +775,8 @@ inline hipError_t launch_gemm(hipStream_t st, GemmParams P, int splits) {
   P.nk_per_split = (P.nk + splits - 1) / splits;
   splits = P.nk_per_split > 0 ? (P.nk + P.nk_per_split - 1) / P.nk_per_split : 1;
   dim3 grid(P.tiles_m * P.tiles_n, P.nbatch ? P.nbatch : 1, splits);
-  hipLaunchKernelGGL((gemm_kernel<BM, BN, BKT, ASRC, BSRC, EPI, DT>), grid, dim3(256), 0, st, P);
+  // dyn_lds: unused dynamic LDS that only lowers how many of these workgroups share a CU
+  hipLaunchKernelGGL((gemm_kernel<BM, BN, BKT, ASRC, BSRC, EPI, DT>), grid, dim3(256), dyn_lds, st, P);
   return hipGetLastError();
 }
 

@@ -220,14 +220,26 @@ static int group_splits(const TnProblem* pr, int np, int K) {
   int tiles = 0;
   for (int i = 0; i < np; ++i) tiles += ((pr[i].M + 127) / 128) * ((pr[i].N + 127) / 128);
   const int nk = (K + BK - 1) / BK;
-  static const int target = [] {
+  static const int target = [] {   // RAU_GROUP_WGS=n: fixed workgroup target instead of the fit below
     const char* e = std::getenv("RAU_GROUP_WGS");
-    const int v = e ? std::atoi(e) : 0;
-    return v > 0 ? v : 640;
+    return e ? std::atoi(e) : 0;
   }();
-  int s = (target + tiles / 2) / (tiles > 0 ? tiles : 1);
-  if (s > nk / 16) s = nk / 16;
-  if (s < 1) s = 1;
+  const int smax = std::max(1, nk / 16);
+  int s = 1;
+  if (target > 0) {
+    s = (target + tiles / 2) / (tiles > 0 ? tiles : 1);
+    s = std::min(std::max(s, 1), smax);
+  } else {
+    // the split that fills whole rounds of the 512 resident workgroups best (the encoder's group
+    // runs alone at the end of the step: a 1.3-round launch wastes a third of it); ties -> fewer
+    // splits (less slab traffic)
+    double best = -1.0;
+    for (int c = 1; c <= smax; ++c) {
+      const int wgs = tiles * c;
+      const double eff = (double)wgs / (512.0 * ((wgs + 511) / 512));
+      if (eff > best + 0.02) { best = eff; s = c; }
+    }
+  }
   const int per = (nk + s - 1) / s;
   return (nk + per - 1) / per;
 }

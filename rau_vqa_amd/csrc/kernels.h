@@ -72,10 +72,12 @@ hipError_t gemm_tn_group_acc(hipStream_t st, const TnProblem* pr, int np, int K,
 // bf16 != 0 (rau_dtype RAU_BF16) on the five hop-batched conv GEMMs: operands rounded to bf16
 // while staged into LDS, f32 accumulate (v_mfma_f32_32x32x16_bf16); tensors in HBM stay f32.
 hipError_t conv_embed_fwd(hipStream_t st, int nB, int D, int S, int M, const float* X,
-                          const float* WiT /* [D][M] */, const float* bi, float* I, int bf16 = 0);
+                          const float* WiT /* [D][M] */, const float* bi, float* I, int bf16 = 0,
+                          int one_per_cu = 0 /* cap residency at one workgroup per CU */);
 // P[b,k,s] = sum_m Wp[k,m] I[b,m,s] + bp[k]   (hop-invariant half of SS:244-252)
 hipError_t conv_att_pre(hipStream_t st, int nB, int M, int S, int A, const float* I,
-                        const float* WpT /* [M][A] */, const float* bp, float* P, int bf16 = 0);
+                        const float* WpT /* [M][A] */, const float* bp, float* P, int bf16 = 0,
+                        int one_per_cu = 0);
 // Same three products with one sample per tile (gemm_sample.hip), used for 14 x 14 maps:
 // C[b,m,s] = epi(sum_k Wt[k,m] X[b,k,s]); epi 0: act(. + bias[m]), epi 1: . + dj[b,m] a[b,s]
 bool conv_sample_ok(int S, int which);

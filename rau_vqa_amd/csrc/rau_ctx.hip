@@ -1111,7 +1111,10 @@ int rau_forward(rau_ctx* ctx) {
       RUNS(sb, "dropout_features", 0, (double)(H + 1) * B * D * S * 4,
            dropout_features(sb, H, (size_t)B * D * S, ctx->feats, m_x, sc(RAU_MASK_X), ctx->xd, 0, SL,
                             S));
+    static const int cap_hops = [] { const char* e = std::getenv("RAU_FWD_CAP_HOPS");   // A/B knob
+                                     return e ? std::atoi(e) : 0; }();
     for (int h0 = 0; h0 < H; h0 += gsz[h0]) {
+      const int cap = !ctx->I_shared && h0 < cap_hops;   // groups that run beside the encoder
       const int nBI = ctx->I_shared ? B : gsz[h0] * B;
       const size_t hb = ctx->I_shared ? 0 : (size_t)h0 * B;  // first (hop, sample) row
       const float* xin = m_x ? ctx->xd + hb * D * S : ctx->feats;
@@ -1119,10 +1122,10 @@ int rau_forward(rau_ctx* ctx) {
       float* Pg = ctx->I_shared ? ctx->P0 : ctx->T + hb * A * S;
       RUNS(sb, "conv_embed_fwd", gflop(M, (double)nBI * S, D),
            ((double)nBI * D * S + (double)nBI * M * S) * 4,
-           conv_embed_fwd(sb, nBI, D, S, M, xin, ctx->WiT, ctx->i_embed.b, Ig, ctx->bf16));
+           conv_embed_fwd(sb, nBI, D, S, M, xin, ctx->WiT, ctx->i_embed.b, Ig, ctx->bf16, cap));
       RUNS(sb, "conv_att_pre", gflop(A, (double)nBI * S, M),
            ((double)nBI * M * S + (double)nBI * A * S) * 4,
-           conv_att_pre(sb, nBI, M, S, A, Ig, ctx->WpT, ctx->att_i.b, Pg, ctx->bf16));
+           conv_att_pre(sb, nBI, M, S, A, Ig, ctx->WpT, ctx->att_i.b, Pg, ctx->bf16, cap));
       HIPC(hipEventRecord(ctx->evF[h0], sb));
     }
   }
