@@ -56,12 +56,21 @@ def classify(rows):
             out[i] = ("conv_embed_fwd", None)
         else:
             out[i] = ("conv_att_pre", None)
-    for i, n in enumerate(names):
-        if n == "gemm_kernel<128, 128, 28, 4, 3, 1, 0>":
-            out[i] = ("conv_embed_wgrad", None)
-        elif n == "gemm_kernel<128, 128, 28, 3, 3, 1, 0>":
+    # conv weight gradients: with the tanh factor applied in the dgrad's epilogue both use the
+    # plain (SC, SC) kernel; in stream order conv_att_wgrad precedes conv_embed_wgrad in every group
+    plain = [i for i, n in enumerate(names) if "128, 128, 28, 3, 3, 1, 0>" in n]
+    dtanh = [i for i, n in enumerate(names) if "128, 128, 28, 4, 3, 1, 0>" in n]
+    if dtanh:
+        for i in plain:
             out[i] = ("conv_att_wgrad", None)
-        elif n.startswith("k_conv_sample<1>") or n == "gemm_kernel<128, 128, 32, 1, 2, 3, 0>":
+        for i in dtanh:
+            out[i] = ("conv_embed_wgrad", None)
+    else:
+        for pos, i in enumerate(plain):
+            out[i] = ("conv_att_wgrad" if pos % 2 == 0 else "conv_embed_wgrad", None)
+    for i, n in enumerate(names):
+        if n.startswith("k_conv_sample<1>") or n.startswith("k_conv_sample<2>") or \
+                n == "gemm_kernel<128, 128, 32, 1, 2, 3, 0>":
             out[i] = ("conv_att_dgrad", None)
     return out
 
@@ -93,9 +102,9 @@ for rows, key in ((fr, "fetch"), (wr, "write")):
 alg_per_hop = {
     "conv_embed_fwd": (B * D * S + B * M * S) * 4 + M * D * 4,
     "conv_att_pre": (B * M * S + B * A * S) * 4 + A * M * 4,
-    "conv_att_dgrad": (B * A * S + B * M * S) * 4 + A * M * 4,
+    "conv_att_dgrad": (B * A * S + 2 * B * M * S) * 4 + A * M * 4,   # reads dS and I, writes dZ
     "conv_att_wgrad": (B * A * S + B * M * S) * 4,
-    "conv_embed_wgrad": (2 * B * M * S + B * D * S) * 4,
+    "conv_embed_wgrad": (B * M * S + B * D * S) * 4,                  # reads dZ and X
 }
 # workgroups per hop where the grid scales with the hops of a launch (else: 1.6 hops per launch
 # on average with hop groups 2,2,2,1,1)
