@@ -40,13 +40,21 @@ def run_gpu(sh, batch, params, masks, hop_w, mode="train"):
     return out, layouts
 
 
-def check(sh, seed=123, lens="ragged", mode="train", hop_w=None, scale=None):
+def check(sh, seed=123, lens="ragged", mode="train", hop_w=None, scale=None, torch_oracle=False):
+    """torch_oracle: take the fp64 reference from the autograd restatement (oracle/ref_torch.py,
+    BLAS-backed, seconds at the model's real dimensions) instead of the C++ oracle; the two agree
+    to 1e-10 (tests/test_oracle_agree.py)."""
     batch, params, masks = util.make_problem(sh, seed=seed, lens=lens, scale=scale)
     if hop_w is None:
         hop_w = np.full(sh.H, float(sh.H), np.float32)
-    ref = oracle.step(sh, params, batch["feats"], batch["tokens"], batch["lens"],
-                      batch["labels"], masks if mode == "train" else None, hop_w,
-                      dtype=np.float64)
+    if torch_oracle:
+        from oracle import ref_torch
+        ref = ref_torch.step(sh, params, batch["feats"], batch["tokens"], batch["lens"],
+                             batch["labels"], masks if mode == "train" else None, hop_w)
+    else:
+        ref = oracle.step(sh, params, batch["feats"], batch["tokens"], batch["lens"],
+                          batch["labels"], masks if mode == "train" else None, hop_w,
+                          dtype=np.float64)
     got, layouts = run_gpu(sh, batch, params, masks, hop_w, mode)
     errs = {}
     for k in util.OUT_KEYS:
