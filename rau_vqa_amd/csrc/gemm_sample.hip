@@ -30,10 +30,8 @@ namespace rau {
 
 namespace {
 
-constexpr int SBM = 128, SBK = 16, SNCB = 13, SBN = SNCB * 16;   // 208 columns
-constexpr int SLDA = SBM + 16;      // 144 = 16 mod 32
+constexpr int SBK = 16, SNCB = 13, SBN = SNCB * 16;   // 208 columns
 constexpr int SLDB = SBN + 32;      // 240 = 16 mod 32
-constexpr int SSTAGE = SBK * (SLDA + SLDB);   // floats per stage
 
 struct SampleParams {
   int M, K, S, nB, tiles_m;
@@ -45,8 +43,12 @@ struct SampleParams {
   const float* Y; float* rs;           // EPI 2: * (1 - Y[b,m,s]^2); rs[b,m] = sum_s of the result
 };
 
-template <int EPI>
+// RB = 16-row blocks per wave: tile rows SBM = 4 waves x RB x 16 (128 or 64)
+template <int EPI, int RB>
 __global__ __launch_bounds__(256, 2) void k_conv_sample(const SampleParams P) {
+  constexpr int SBM = 64 * RB;
+  constexpr int SLDA = SBM + 16;      // 144 / 80 = 16 mod 32
+  constexpr int SSTAGE = SBK * (SLDA + SLDB);   // floats per stage
   __shared__ __attribute__((aligned(16))) float smem[2 * SSTAGE];
   const int tid = threadIdx.x, l = tid & 63, w = tid >> 6;
   const int lr = l & 15, lq = l >> 4;
@@ -57,8 +59,10 @@ __global__ __launch_bounds__(256, 2) void k_conv_sample(const SampleParams P) {
   const int S = P.S, S4 = S >> 2;
   const float* Xb = P.X + (size_t)b * P.x_bs;
 
-  // staging maps (the same every K-step): A = 16 k-rows x 32 float4, B = 16 k-rows x S4 float4
-  const int a_row = tid >> 5, a_c4 = (tid & 31) * 4;           // rows a_row, a_row + 8
+  // staging maps (the same every K-step): A = 16 k-rows x SBM/4 float4, B = 16 k-rows x S4 float4
+  constexpr int ACL = SBM / 4;                                  // float4 per A row (32 or 16)
+  constexpr int ARS = 256 / ACL;                                // A rows per pass (8 or 16)
+  const int a_row = tid / ACL, a_c4 = (tid % ACL) * 4;          // rows a_row (+ ARS)
   const bool a_ok = m0 + a_c4 < P.M;                           // M % 4 == 0
   const float* a_ptr = P.Wt + (size_t)a_row * P.w_rs + m0 + (a_ok ? a_c4 : 0);
   int b_row[4], b_q[4];
@@ -77,20 +81,20 @@ __global__ __launch_bounds__(256, 2) void k_conv_sample(const SampleParams P) {
     smem[st * SSTAGE + SBK * SLDA + (r / (SBN - S)) * SLDB + S + r % (SBN - S)] = 0.f;
   }
 
-  f32x4 acc[2][SNCB];
+  f32x4 acc[RB][SNCB];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < RB; ++i)
 #pragma unroll
     for (int j = 0; j < SNCB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int nsteps = (P.K + SBK - 1) / SBK;
-  float4 ra[2], rb[4];
+  float4 ra[RB], rb[4];
   auto load = [&](int T) {
     const int k0 = T * SBK;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int k = k0 + a_row + 8 * i;
-      ra[i] = (a_ok && k < P.K) ? *reinterpret_cast<const float4*>(a_ptr + (size_t)(k0 + 8 * i) * P.w_rs)
+    for (int i = 0; i < RB; ++i) {
+      const int k = k0 + a_row + ARS * i;
+      ra[i] = (a_ok && k < P.K) ? *reinterpret_cast<const float4*>(a_ptr + (size_t)(k0 + ARS * i) * P.w_rs)
                                 : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 #pragma unroll
@@ -104,26 +108,26 @@ __global__ __launch_bounds__(256, 2) void k_conv_sample(const SampleParams P) {
     float* As = smem + stage * SSTAGE;
     float* Bs = As + SBK * SLDA;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
-      *reinterpret_cast<float4*>(As + (a_row + 8 * i) * SLDA + a_c4) = ra[i];
+    for (int i = 0; i < RB; ++i)
+      *reinterpret_cast<float4*>(As + (a_row + ARS * i) * SLDA + a_c4) = ra[i];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
       if (b_ok[i]) *reinterpret_cast<float4*>(Bs + b_row[i] * SLDB + b_q[i] * 4) = rb[i];
   };
   auto compute = [&](int stage) {
-    const float* As = smem + stage * SSTAGE + lq * SLDA + w * 32 + lr;
+    const float* As = smem + stage * SSTAGE + lq * SLDA + w * 16 * RB + lr;
     const float* Bs = smem + stage * SSTAGE + SBK * SLDA + lq * SLDB + lr;
 #pragma unroll
     for (int kb = 0; kb < SBK / 4; ++kb) {
-      float a[2], bb[SNCB];
+      float a[RB], bb[SNCB];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) a[i] = As[kb * 4 * SLDA + i * 16];
+      for (int i = 0; i < RB; ++i) a[i] = As[kb * 4 * SLDA + i * 16];
 #pragma unroll
       for (int j = 0; j < SNCB; ++j) bb[j] = Bs[kb * 4 * SLDB + j * 16];
 #pragma unroll
       for (int j = 0; j < SNCB; ++j)
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < RB; ++i)
           // X as the MFMA's A operand, W as its B operand: the accumulator block is C^T, i.e. a
           // lane's 4 registers are 4 CONSECUTIVE positions of one row m -> 16-byte stores
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bb[j], a[i], acc[i][j], 0, 0, 0);
@@ -144,8 +148,8 @@ __global__ __launch_bounds__(256, 2) void k_conv_sample(const SampleParams P) {
     __syncthreads();
   }
 
-  // ---- epilogue: accumulator (i, j) register r = C[m0 + w*32 + i*16 + lr][j*16 + 4*lq + r]
-  float* rowv = smem;            // [128] bias / dj of this sample's rows
+  // ---- epilogue: accumulator (i, j) register r = C[m0 + w*16*RB + i*16 + lr][j*16 + 4*lq + r]
+  float* rowv = smem;            // [SBM] bias / dj of this sample's rows
   float* colv = smem + SBM;      // [208] a of this sample's positions
   if (tid < SBM) {
     const int m = m0 + tid;
@@ -161,8 +165,8 @@ __global__ __launch_bounds__(256, 2) void k_conv_sample(const SampleParams P) {
   float* Cb = P.C + (size_t)b * P.c_bs;
   const float* Yb = EPI == 2 ? P.Y + (size_t)b * P.c_bs : nullptr;
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int rl = w * 32 + i * 16 + lr;
+  for (int i = 0; i < RB; ++i) {
+    const int rl = w * 16 * RB + i * 16 + lr;
     const int m = m0 + rl;
     const bool mok = m < P.M;
     const float rv = rowv[rl];
@@ -213,9 +217,12 @@ hipError_t conv_sample(hipStream_t st, int epi, int nB, int M, int K, int S, con
                        const float* bias, int act, const float* dj, const float* av,
                        const float* Y, float* rs) {
   if (!(S % 4 == 0 && S > 176 && S <= SBN) || M % 4 != 0) return hipErrorInvalidValue;
+  static const int rb_env = [] { const char* e = std::getenv("RAU_CONV_SAMPLE_RB");   // A/B knob
+                                 return e ? std::atoi(e) : 2; }();
+  const int rb = rb_env == 1 ? 1 : 2;
   SampleParams P{};
   P.M = M; P.K = K; P.S = S; P.nB = nB;
-  P.tiles_m = (M + SBM - 1) / SBM;
+  P.tiles_m = (M + 64 * rb - 1) / (64 * rb);
   P.Wt = Wt; P.w_rs = w_rs;
   P.X = X; P.x_bs = x_bs;
   P.C = C; P.c_bs = c_bs;
@@ -223,12 +230,16 @@ hipError_t conv_sample(hipStream_t st, int epi, int nB, int M, int K, int S, con
   P.dj = dj; P.av = av;
   P.Y = Y; P.rs = rs;
   const dim3 grid(P.tiles_m * nB), block(256);
-  if (epi == 0)
-    hipLaunchKernelGGL(k_conv_sample<0>, grid, block, 0, st, P);
-  else if (epi == 1)
-    hipLaunchKernelGGL(k_conv_sample<1>, grid, block, 0, st, P);
-  else
-    hipLaunchKernelGGL(k_conv_sample<2>, grid, block, 0, st, P);
+  // 64-row tiles: 41 KB of static LDS would let three workgroups share a CU (a ragged 2.67
+  // rounds per hop); 16 KB of unused dynamic LDS keeps it at two
+  const int dyn = rb == 1 ? 16 * 1024 : 0;
+#define LAUNCH(E, R) hipLaunchKernelGGL((k_conv_sample<E, R>), grid, block, dyn, st, P)
+  if (rb == 1) {
+    if (epi == 0) LAUNCH(0, 1); else if (epi == 1) LAUNCH(1, 1); else LAUNCH(2, 1);
+  } else {
+    if (epi == 0) LAUNCH(0, 2); else if (epi == 1) LAUNCH(1, 2); else LAUNCH(2, 2);
+  }
+#undef LAUNCH
   return hipGetLastError();
 }
 

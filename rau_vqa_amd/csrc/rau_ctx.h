@@ -83,7 +83,7 @@ struct rau_ctx {
   // hops per bulk launch (pipelines the bulk GEMMs with the hop loops): gsize[h] = n if hops
   // [h, h+n) form one launch group, else 0.  `groups` is the configured partition, `cur` the one
   // the last forward used (evaluate mode: one group of H).
-  std::vector<int> groups, cur;
+  std::vector<int> groups, cur, bgroups;   // bgroups: backward partition (empty = same as forward)
   std::vector<void*> allocs;
   Group grp[3];
   // mult

@@ -227,6 +227,23 @@ int rau_create(const rau_config* cfg, rau_ctx** out) {
     ctx->groups.assign(c.H, 0);
     int h0 = 0;
     for (int n : sizes) { ctx->groups[h0] = n; h0 += n; }
+    if (const char* eg = std::getenv("RAU_BWD_GROUPS")) {
+      std::vector<int> bs;
+      int sum = 0;
+      for (const char* p = eg; *p;) {
+        const int v = std::atoi(p);
+        if (v < 1) { bs.clear(); sum = -1; break; }
+        bs.push_back(v);
+        sum += v;
+        while (*p && *p != ',') ++p;
+        if (*p == ',') ++p;
+      }
+      if (sum == c.H) {
+        ctx->bgroups.assign(c.H, 0);
+        int b0 = 0;
+        for (int n : bs) { ctx->bgroups[b0] = n; b0 += n; }
+      }
+    }
   }
   ctx->evF.resize(c.H);
   ctx->evK.resize(c.H);
@@ -1208,7 +1225,15 @@ int rau_backward(rau_ctx* ctx, const float* hop_w) {
   const int B = c.B, E = c.E, Rq = c.Rq, D = c.D, S = ctx->Sp, SL = c.S, M = c.M, A = c.A, R = c.R,
             K = c.K, H = c.H, Q = ctx->Q;
   const int TL = ctx->max_len;
-  const std::vector<int>& gsz = ctx->cur;
+  // Backward launch groups of the bulk stream.  Forward groups want to be large (the flattened-
+  // column kernels lose a ragged last round per launch); the backward kernels do not (per-sample
+  // dgrad tiles and the split-K weight gradients fill whole rounds at any hop count), and a
+  // group's gradients can only start once its LAST hop's chain is done, so the backward partition
+  // is its own: RAU_BWD_GROUPS="1,1,2,2,2" (sizes in HOP order, must sum to H), default = the
+  // forward partition.  Evaluate mode (I shared): one group.
+  std::vector<int> bsz_store;
+  if (!ctx->I_shared && !ctx->bgroups.empty()) bsz_store = ctx->bgroups;
+  const std::vector<int>& gsz = bsz_store.empty() ? ctx->cur : bsz_store;
   hipStream_t st = ctx->st;
   const bool tr = ctx->mode == RAU_MODE_TRAIN;
   auto mk = [&](int site) -> const uint32_t* {
