@@ -1,5 +1,8 @@
 run() { echo "== $*"; env "$@" python tools/tlrun.py 2>&1 | grep ms/step; }
-for i in 1 2 3; do
+for i in 1 2; do
 run A=1
-run RAU_LIB=rau_vqa_amd/librau_l6.so
+run RAU_SKINNY_WGS=64
+run RAU_SKINNY_WGS=96
+run RAU_SKINNY_WGS=128
+run RAU_SKINNY_WGS=200
 done
