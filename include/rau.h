@@ -71,7 +71,9 @@ typedef enum rau_dtype {
   RAU_BF16 = 1,      /* the five 1x1-conv GEMMs (i_embed, ifeatproj and their gradients: 94-98 %
                       * of the FLOPs) take bf16-rounded operands with f32 accumulation; all
                       * tensors in memory, the recurrences, attention and loss stay f32
-                      * (BASELINE.json configs[2]: Ours_ResNet 14x14x2048, bf16 MFMA) */
+                      * (BASELINE.json configs[2]: Ours_ResNet 14x14x2048, bf16 MFMA).  On 14x14
+                      * maps the attention input gradient (K = 256) stays exact f32: four of the
+                      * five GEMMs are rounded. */
   RAU_F32S = 2       /* same five GEMMs with every f32 operand SPLIT into three bf16 terms
                       * (hi + mid + lo = all 24 significand bits) and six bf16 MFMA products per
                       * operand pair, f32 accumulate: f32-grade accuracy (dropped terms <= 2^-24

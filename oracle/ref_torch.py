@@ -60,23 +60,27 @@ class _Conv1x1BF16(torch.autograd.Function):
     of a rounded forward would not round dY; the device does, because dY is a GEMM operand.)"""
 
     @staticmethod
-    def forward(ctx, x, W, b):
+    def forward(ctx, x, W, b, exact_dx=False):
         ctx.save_for_backward(x, W)
+        ctx.exact_dx = exact_dx
         return torch.einsum("oi,bis->bos", _rb(W), _rb(x)) + b.view(1, -1, 1)
 
     @staticmethod
     def backward(ctx, dy):
         x, W = ctx.saved_tensors
         dyr = _rb(dy)
-        dx = torch.einsum("oi,bos->bis", _rb(W), dyr)
+        # exact_dx: on 14x14 maps the attention dgrad runs on the exact-f32 per-sample kernel in
+        # every dtype (its epilogue also forms dZ and the bias row sums), so no operand is rounded
+        dx = (torch.einsum("oi,bos->bis", W, dy) if ctx.exact_dx
+              else torch.einsum("oi,bos->bis", _rb(W), dyr))
         dW = torch.einsum("bos,bis->oi", dyr, _rb(x))
-        return dx, dW, dy.sum((0, 2))
+        return dx, dW, dy.sum((0, 2)), None
 
 
-def _conv1x1(x3, W, b, bf16):
+def _conv1x1(x3, W, b, bf16, exact_dx=False):
     """1x1 SpatialConvolution on [B, C, S] (reference SS:240, SS:247)."""
     if bf16:
-        return _Conv1x1BF16.apply(x3, W, b)
+        return _Conv1x1BF16.apply(x3, W, b, exact_dx)
     return F.conv2d(x3.unsqueeze(3), W.view(W.shape[0], W.shape[1], 1, 1), b).squeeze(3)
 
 
@@ -136,7 +140,9 @@ def multimodal(sh, P, q, feats4d, prev_c, prev_h, mq, mx, mmf, bf16=False):
     ifeat = torch.tanh(_conv1x1(xi.reshape(B, sh.D, sh.S), P["i_embed.W"], P["i_embed.b"], bf16))
     # attbycontent
     qatt = F.linear(qf, P["att_q.W"], P["att_q.b"]).unsqueeze(2).expand(B, sh.A, sh.S)
-    iproj = _conv1x1(ifeat, P["att_i.W"], P["att_i.b"], bf16)
+    # librau dispatch: per-sample exact-f32 dgrad when 176 < S <= 208 and S % 4 == 0 (gemm_sample.hip)
+    iproj = _conv1x1(ifeat, P["att_i.W"], P["att_i.b"], bf16,
+                     exact_dx=(sh.S % 4 == 0 and 176 < sh.S <= 208 and sh.M % 4 == 0))
     addfeat = torch.tanh(iproj + qatt).reshape(B, sh.A, sh.S, 1)
     attscore = F.conv2d(addfeat, P["att_score.W"].view(1, sh.A, 1, 1),
                         P["att_score.b"]).reshape(B, sh.S)

@@ -67,7 +67,7 @@ hipError_t conv_att_dgrad(hipStream_t st, int nB, int M, int S, int A, const flo
   P.S = S;
   P.C = dI; P.c_bs = (long)M * S;
   P.v1 = dj; P.v2 = a;
-  if (!bf16 && conv_sample_ok(S, 4))
+  if (bf16 != 2 && M % 4 == 0 && conv_sample_ok(S, 4))   // exact f32 also in RAU_BF16 mode (see conv_dz_fused_ok)
     return conv_sample(st, 1, nB, M, A, S, Wp, M, dS, (long)A * S, dI, (long)M * S, nullptr, 0, dj, a);
   if (bf16 == 2) return launch_gemm<128, 128, BK, SRC_RC, SRC_RC_FLAT, EPI_OUTER, 2>(st, P, 1);
   if (bf16) return launch_gemm<128, 128, BK, SRC_RC, SRC_RC_FLAT, EPI_OUTER, 1>(st, P, 1);
@@ -76,7 +76,9 @@ hipError_t conv_att_dgrad(hipStream_t st, int nB, int M, int S, int A, const flo
 
 bool conv_dz_fused_ok(int S, int M, int bf16) {
   static const bool off = std::getenv("RAU_DZ_UNFUSED") != nullptr;   // A/B knob
-  return !off && !bf16 && M % 4 == 0 && conv_sample_ok(S, 4);
+  // bf16 == 1 too: the dgrad then runs on the exact-f32 per-sample kernel (K = A = 256: cheap) and
+  // the i_embed weight gradient re-reads one A operand (dZ) instead of two (dI, I) per tile column
+  return !off && bf16 != 2 && M % 4 == 0 && conv_sample_ok(S, 4);
 }
 hipError_t conv_att_dgrad_dz(hipStream_t st, int nB, int M, int S, int A, const float* dS,
                              const float* Wp, const float* dj, const float* a, const float* I,
