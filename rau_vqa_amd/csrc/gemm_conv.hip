@@ -33,6 +33,19 @@ hipError_t conv_embed_fwd(hipStream_t st, int nB, int D, int S, int M, const flo
   return launch_gemm<128, 128, BK, SRC_RC, SRC_RC_FLAT, EPI_CONV>(st, P, 1, one_per_cu ? 30 * 1024 : 0);
 }
 
+hipError_t conv_embed_fwd_b16(hipStream_t st, int nB, int D, int S, int M, const void* X16,
+                              const float* WiT, const float* bi, float* I) {
+  GemmParams P{};
+  P.M = M; P.N = nB * S; P.K = D; P.nk = (D + BK - 1) / BK;
+  P.A = WiT; P.a_rs = M;
+  P.B = reinterpret_cast<const float*>(X16); P.b_rs = S; P.b_bs = (long)D * S;   // in bf16 elements
+  P.S = S;
+  P.C = I; P.c_bs = (long)M * S;
+  P.bias = bi;
+  P.act = 1;
+  return launch_gemm<128, 128, BK, SRC_RC, SRC_RC_FLAT_B16, EPI_CONV, 1>(st, P, 1);
+}
+
 // P[b,k,s] = sum_m Wp[k,m] I[b,m,s] + bp[k]: the hop-invariant part of attbycontent's
 // pre-activation (reference SS:247-249); nB may be H*B.  The per-hop part
 // (+ u[b,k], tanh, score, softmax) is att_fwd_fused in kernels.hip.
@@ -124,7 +137,7 @@ size_t conv_wgrad_slab_floats(int nB, int rowsA, int rowsB, int S) {
 
 // dW[ra, rb] += sum_{b,s} Aop[b,ra,s] * Bop[b,rb,s]; whole samples per split,
 // partial tiles to slabs, fixed-order reduction into dW.
-template <int BKT, int ASRC, int DT = 0>
+template <int BKT, int ASRC, int DT = 0, int BSRC = SRC_SC>
 static hipError_t conv_wgrad(hipStream_t st, GemmParams P, int nB, int S, float* dW,
                              float* slab, float* drow = nullptr) {
   P.S = S;
@@ -142,11 +155,11 @@ static hipError_t conv_wgrad(hipStream_t st, GemmParams P, int nB, int S, float*
   static const bool xcd_off = std::getenv("RAU_WGRAD_NOXCD") != nullptr;   // A/B knob
   if (xcd_off) {
     dim3 grid(P.tiles_m * P.tiles_n, 1, splits);
-    hipLaunchKernelGGL((gemm_kernel<128, 128, BKT, ASRC, SRC_SC, EPI_SLAB, DT>), grid, dim3(256), 0,
+    hipLaunchKernelGGL((gemm_kernel<128, 128, BKT, ASRC, BSRC, EPI_SLAB, DT>), grid, dim3(256), 0,
                        st, P);
   } else {   // a split's tiles share an XCD (and its L2 copy of the split's samples)
     dim3 grid(8 * ((splits + 7) / 8) * P.tiles_m * P.tiles_n);
-    hipLaunchKernelGGL((gemm_split_xcd_kernel<128, 128, BKT, ASRC, SRC_SC, EPI_SLAB, DT>), grid,
+    hipLaunchKernelGGL((gemm_split_xcd_kernel<128, 128, BKT, ASRC, BSRC, EPI_SLAB, DT>), grid,
                        dim3(256), 0, st, P, splits);
   }
   hipError_t e = hipGetLastError();
@@ -187,6 +200,15 @@ hipError_t conv_embed_wgrad(hipStream_t st, int nB, int D, int S, int M, const f
   P.B = X; P.b_bs = (long)D * S;
   if (dz_final) return conv_wgrad_any<SRC_SC>(st, P, nB, S, dWi, slab, bf16);
   return conv_wgrad_any<SRC_SC_DTANH>(st, P, nB, S, dWi, slab, bf16, dbi);
+}
+
+hipError_t conv_embed_wgrad_b16(hipStream_t st, int nB, int D, int S, int M, const float* dZ,
+                                const void* X16, float* dWi, float* slab) {
+  GemmParams P{};
+  P.M = M; P.N = D;
+  P.A = dZ; P.a_bs = (long)M * S;
+  P.B = reinterpret_cast<const float*>(X16); P.b_bs = (long)D * S;   // in bf16 elements
+  return conv_wgrad<32, SRC_SC, 1, SRC_SC_B16>(st, P, nB, S, dWi, slab);
 }
 
 }  // namespace rau

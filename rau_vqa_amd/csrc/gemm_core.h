@@ -330,6 +330,104 @@ struct LoadSC {
   }
 };
 
+// bf16 mode, operand ALREADY STORED AS bf16 in HBM (the dropped-out feature maps, xd16): the same
+// two mappings as LoadRC<FLAT, K4> and LoadSC, with half the bytes per load and no conversion --
+// the [K][cols] form only regroups the 16-bit halves of its four k-rows into 4-k plane elements
+// (two v_perm_b32 per element), the sample-chunk form stores what it loaded.
+template <int BT, int BKT>
+struct LoadRC16 {
+  static constexpr int PAD = LPAD;
+  static constexpr int CPR = BT / 4;
+  static constexpr int RPP = 256 / CPR;
+  static constexpr int NI = BKT / RPP;
+  static_assert(NI == 4, "4-k plane mapping needs four rows per thread");
+  struct Regs { uint2 v[NI]; };
+  const uint16_t* p;
+  long rs;
+  bool ok;
+  int kr, c4, K;
+  __device__ __forceinline__ void init(const GemmParams& P, const float* base, long rs_,
+                                       long bs, int col0, int cols, int tid) {
+    K = P.K;
+    rs = rs_;
+    c4 = (tid % CPR) * 4;
+    kr = tid / CPR;
+    const int col = col0 + c4;
+    ok = col < cols;
+    long off = (long)(col / P.S) * bs + (col % P.S);
+    if (!ok) off = 0;
+    p = reinterpret_cast<const uint16_t*>(base) + off;
+  }
+  template <bool FAST>
+  __device__ __forceinline__ void load(int step, Regs& R) const {
+    const int k0 = step * BKT + 4 * kr;
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+      R.v[i] = (FAST || (ok && k0 + i < K)) ? *reinterpret_cast<const uint2*>(p + (long)(k0 + i) * rs)
+                                            : make_uint2(0u, 0u);
+  }
+  __device__ __forceinline__ void store(float*, int, const Regs&) const {}
+  template <int NPL>
+  __device__ __forceinline__ void store_bf16(uint2* img, int, int, const Regs& R) const {
+    static_assert(NPL == 1, "stored-bf16 operands exist in RAU_BF16 mode only");
+    constexpr uint32_t LO = 0x05040100u, HI = 0x07060302u;   // (src1.lo16 | src0.lo16 << 16), same of hi16
+    const int d = kr * (BT + BPAD) + c4;   // plane kr, columns c4..c4+3
+    img[d] = make_uint2(__builtin_amdgcn_perm(R.v[1].x, R.v[0].x, LO),
+                        __builtin_amdgcn_perm(R.v[3].x, R.v[2].x, LO));
+    img[d + 1] = make_uint2(__builtin_amdgcn_perm(R.v[1].x, R.v[0].x, HI),
+                            __builtin_amdgcn_perm(R.v[3].x, R.v[2].x, HI));
+    img[d + 2] = make_uint2(__builtin_amdgcn_perm(R.v[1].y, R.v[0].y, LO),
+                            __builtin_amdgcn_perm(R.v[3].y, R.v[2].y, LO));
+    img[d + 3] = make_uint2(__builtin_amdgcn_perm(R.v[1].y, R.v[0].y, HI),
+                            __builtin_amdgcn_perm(R.v[3].y, R.v[2].y, HI));
+  }
+};
+template <int BT, int BKT>
+struct LoadSC16 {
+  static constexpr int PAD = SPAD;
+  static constexpr int LPR = 8;
+  static constexpr int RPP = 256 / LPR;
+  static constexpr int NI = BT / RPP;
+  struct Regs { uint2 v[NI]; };
+  long roff[NI];
+  bool ok[NI];
+  const uint16_t* base;
+  long bs;
+  int kc, S, cps;
+  __device__ __forceinline__ void init(const GemmParams& P, const float* base_, long rs,
+                                       long bs_, int row0, int rows, int tid) {
+    base = reinterpret_cast<const uint16_t*>(base_);
+    bs = bs_;
+    S = P.S;
+    cps = P.cps;
+    kc = (tid % LPR) * 4;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int r = tid / LPR + i * RPP;
+      ok[i] = row0 + r < rows;
+      roff[i] = (long)(row0 + r) * S + kc;
+    }
+  }
+  template <bool FAST>
+  __device__ __forceinline__ void load(int g, Regs& R) const {
+    const int b = g / cps;
+    const int s0 = (g - b * cps) * BKT;
+    const bool kin = kc < BKT && s0 + kc < S;
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+      R.v[i] = ((FAST || ok[i]) && kin) ? *reinterpret_cast<const uint2*>(base + (long)b * bs + roff[i] + s0)
+                                        : make_uint2(0u, 0u);
+  }
+  __device__ __forceinline__ void store(float*, int, const Regs&) const {}
+  template <int NPL>
+  __device__ __forceinline__ void store_bf16(uint2* img, int, int tid, const Regs& R) const {
+    static_assert(NPL == 1, "stored-bf16 operands exist in RAU_BF16 mode only");
+    if (kc >= BKT) return;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) img[(kc >> 2) * (BT + BPAD) + tid / LPR + i * RPP] = R.v[i];
+  }
+};
+
 // A/B "source kinds" used to pick a loader in the kernel template.
 enum Src : int {
   SRC_KC = 0,        // [rows][K]
@@ -337,7 +435,9 @@ enum Src : int {
   SRC_RC_FLAT = 2,   // [sample][K][S], flattened columns
   SRC_SC = 3,        // [sample][rows][S], reduction over (sample, position)
   SRC_SC_DTANH = 4,  // same, operand = A * (1 - A2^2)
-  SRC_RC_SUM = 5     // [K][cols] + column sums of the operand handed back (P.rs_out)
+  SRC_RC_SUM = 5,    // [K][cols] + column sums of the operand handed back (P.rs_out)
+  SRC_RC_FLAT_B16 = 6,  // SRC_RC_FLAT, operand stored as bf16 (RAU_BF16 mode)
+  SRC_SC_B16 = 7     // SRC_SC, operand stored as bf16
 };
 template <int BT, int BKT, int SRC, bool K4 = false> struct LoaderOf;
 template <int BT, int BKT, bool K4> struct LoaderOf<BT, BKT, SRC_KC, K4> { using type = LoadKC<BT, BKT>; };
@@ -346,6 +446,8 @@ template <int BT, int BKT, bool K4> struct LoaderOf<BT, BKT, SRC_RC_FLAT, K4> { 
 template <int BT, int BKT, bool K4> struct LoaderOf<BT, BKT, SRC_SC, K4> { using type = LoadSC<BT, BKT>; };
 template <int BT, int BKT, bool K4> struct LoaderOf<BT, BKT, SRC_SC_DTANH, K4> { using type = LoadSC<BT, BKT, true>; };
 template <int BT, int BKT, bool K4> struct LoaderOf<BT, BKT, SRC_RC_SUM, K4> { using type = LoadRC<BT, BKT, false, K4, true>; };
+template <int BT, int BKT, bool K4> struct LoaderOf<BT, BKT, SRC_RC_FLAT_B16, K4> { using type = LoadRC16<BT, BKT>; };
+template <int BT, int BKT, bool K4> struct LoaderOf<BT, BKT, SRC_SC_B16, K4> { using type = LoadSC16<BT, BKT>; };
 
 // -------------------------------------------------------------- epilogues
 enum Epi : int {

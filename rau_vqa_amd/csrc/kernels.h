@@ -74,6 +74,9 @@ hipError_t gemm_tn_group_acc(hipStream_t st, const TnProblem* pr, int np, int K,
 hipError_t conv_embed_fwd(hipStream_t st, int nB, int D, int S, int M, const float* X,
                           const float* WiT /* [D][M] */, const float* bi, float* I, int bf16 = 0,
                           int one_per_cu = 0 /* cap residency at one workgroup per CU */);
+// RAU_BF16 mode with the feature maps stored as bf16 (X16 [nB][D][S] bf16; S % 4 == 0)
+hipError_t conv_embed_fwd_b16(hipStream_t st, int nB, int D, int S, int M, const void* X16,
+                              const float* WiT, const float* bi, float* I);
 // P[b,k,s] = sum_m Wp[k,m] I[b,m,s] + bp[k]   (hop-invariant half of SS:244-252)
 hipError_t conv_att_pre(hipStream_t st, int nB, int M, int S, int A, const float* I,
                         const float* WpT /* [M][A] */, const float* bp, float* P, int bf16 = 0,
@@ -112,6 +115,9 @@ hipError_t conv_embed_wgrad(hipStream_t st, int nB, int D, int S, int M, const f
                             const float* I, const float* X, float* dWi, float* slab,
                             int bf16 = 0, float* dbi = nullptr /* += sum_{b,s} dZ[b,m,s] */,
                             int dz_final = 0 /* dI already holds dZ: no tanh factor, no dbi */);
+// same with dZ already final (f32, bf16-rounded while staging) and X stored as bf16
+hipError_t conv_embed_wgrad_b16(hipStream_t st, int nB, int D, int S, int M, const float* dZ,
+                                const void* X16, float* dWi, float* slab);
 
 // --------------------------------------------------------- pointwise (kernels.hip)
 enum GateOrder { GATES_ATT = 0 /* i g f o, ATTLSTM.lua:12-19 */,
@@ -218,6 +224,10 @@ hipError_t att_bwd_split(hipStream_t st, int nB, int M, int A, int S, const floa
 hipError_t dropout_features(hipStream_t st, int H, size_t per_hop, const float* X,
                             const uint32_t* mask, float mscale, float* xd, size_t mask_e0 = 0,
                             int SL = 0, int Sp = 0);
+// RAU_BF16 mode (S % 4 == 0): the same values stored as bf16, [h][i], the form conv_embed_fwd_b16 /
+// conv_embed_wgrad_b16 read
+hipError_t dropout_features_b16(hipStream_t st, int H, size_t per_hop, const float* X,
+                                const uint32_t* mask, float mscale, void* xd16);
 // dst[n] += sum_rows X[row*ld + n]   (two-stage, deterministic; tmp >= 32*N floats)
 hipError_t colsum_acc(hipStream_t st, int rows, int N, const float* X, long ld, float* dst,
                       float* tmp);

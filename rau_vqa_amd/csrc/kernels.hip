@@ -1014,6 +1014,27 @@ __global__ void k_dropout_features(int H, size_t per4, const float4* __restrict_
     }
   }
 }
+// RAU_BF16 mode: the same pass writing bf16 (RNE of the f32 value the other form stores, i.e. exactly
+// what the bf16 operand staging would have made of it), the only form the bf16 step path reads
+__global__ void k_dropout_features_b16(int H, size_t per4, const float4* __restrict__ X,
+                                       const uint32_t* __restrict__ mask, size_t e0, float mscale,
+                                       uint2* __restrict__ xd) {
+  for (size_t q = blockIdx.x * (size_t)blockDim.x + threadIdx.x; q < per4;
+       q += (size_t)gridDim.x * blockDim.x) {
+    const float4 x = X[q];
+    for (int h = 0; h < H; ++h) {
+      const size_t e = e0 + ((size_t)h * per4 + q) * 4;
+      const uint32_t nib = mask_nib(mask, e);
+      typedef __bf16 b16x4 __attribute__((ext_vector_type(4)));
+      b16x4 o;
+      o[0] = (__bf16)((nib & 1u) ? x.x * mscale : 0.f);
+      o[1] = (__bf16)((nib & 2u) ? x.y * mscale : 0.f);
+      o[2] = (__bf16)((nib & 4u) ? x.z * mscale : 0.f);
+      o[3] = (__bf16)((nib & 8u) ? x.w * mscale : 0.f);
+      xd[(size_t)h * per4 + q] = __builtin_bit_cast(uint2, o);
+    }
+  }
+}
 // Pitched rows (S not a multiple of 4): the mask is defined over the LOGICAL tensor
 // [.., rows, SL], the data has row pitch Sp; pad columns are written as zeros.
 __global__ void k_dropout_features_pitch(int H, size_t rows, int SL, int Sp,
@@ -1044,6 +1065,14 @@ hipError_t dropout_features(hipStream_t st, int H, size_t per_hop, const float* 
   hipLaunchKernelGGL(k_dropout_features, dim3(grid_for(per_hop / 4)), dim3(256), 0, st, H,
                      per_hop / 4, reinterpret_cast<const float4*>(X), mask, mask_e0, mscale,
                      reinterpret_cast<float4*>(xd));
+  return hipGetLastError();
+}
+
+hipError_t dropout_features_b16(hipStream_t st, int H, size_t per_hop, const float* X,
+                                const uint32_t* mask, float mscale, void* xd16) {
+  hipLaunchKernelGGL(k_dropout_features_b16, dim3(grid_for(per_hop / 4)), dim3(256), 0, st, H,
+                     per_hop / 4, reinterpret_cast<const float4*>(X), mask, (size_t)0, mscale,
+                     reinterpret_cast<uint2*>(xd16));
   return hipGetLastError();
 }
 

@@ -340,6 +340,12 @@ int rau_create(const rau_config* cfg, rau_ctx** out) {
   CK(dalloc(ctx, &ctx->Yq, HB * M));
   CK(dalloc(ctx, &ctx->qf, HB * M));
   CK(dalloc(ctx, &ctx->xd, HB * D * S));
+  // bf16 mode on maps the fused-dZ backward handles (the only backward that reads the bf16 form)
+  if (ctx->bf16 == 1 && ctx->Sp == c.S && conv_dz_fused_ok(S, M, 1) && !std::getenv("RAU_XD_F32")) {
+    float* x16 = nullptr;
+    CK(dalloc(ctx, &x16, (HB * D * S + 1) / 2));
+    ctx->xd16 = x16;
+  }
   CK(dalloc(ctx, &ctx->I, HB * M * S));
   CK(dalloc(ctx, &ctx->T, HB * A * S));
   CK(dalloc(ctx, &ctx->u, HB * A));   // finished u = qf Wa^T + ba per hop (the backward's tanh(P + u))
@@ -1124,7 +1130,11 @@ int rau_forward(rau_ctx* ctx) {
     }
     RUNS(sb, "transpose", 0, (double)M * D * 8, transpose2d(sb, M, D, ctx->i_embed.W, ctx->WiT));
     RUNS(sb, "transpose", 0, (double)A * M * 8, transpose2d(sb, A, M, ctx->att_i.W, ctx->WpT));
-    if (m_x)
+    const bool x16 = m_x && ctx->xd16;   // bf16 mode: the hop copies of the feature map are stored as bf16
+    if (x16)
+      RUNS(sb, "dropout_features", 0, (double)(H + 2) * B * D * S * 2,
+           dropout_features_b16(sb, H, (size_t)B * D * S, ctx->feats, m_x, sc(RAU_MASK_X), ctx->xd16));
+    else if (m_x)
       RUNS(sb, "dropout_features", 0, (double)(H + 1) * B * D * S * 4,
            dropout_features(sb, H, (size_t)B * D * S, ctx->feats, m_x, sc(RAU_MASK_X), ctx->xd, 0, SL,
                             S));
@@ -1137,9 +1147,15 @@ int rau_forward(rau_ctx* ctx) {
       const float* xin = m_x ? ctx->xd + hb * D * S : ctx->feats;
       float* Ig = ctx->I + hb * M * S;
       float* Pg = ctx->I_shared ? ctx->P0 : ctx->T + hb * A * S;
-      RUNS(sb, "conv_embed_fwd", gflop(M, (double)nBI * S, D),
-           ((double)nBI * D * S + (double)nBI * M * S) * 4,
-           conv_embed_fwd(sb, nBI, D, S, M, xin, ctx->WiT, ctx->i_embed.b, Ig, ctx->bf16, cap));
+      if (x16)
+        RUNS(sb, "conv_embed_fwd", gflop(M, (double)nBI * S, D),
+             (double)nBI * D * S * 2 + (double)nBI * M * S * 4,
+             conv_embed_fwd_b16(sb, nBI, D, S, M, (const uint16_t*)ctx->xd16 + hb * D * S, ctx->WiT,
+                                ctx->i_embed.b, Ig));
+      else
+        RUNS(sb, "conv_embed_fwd", gflop(M, (double)nBI * S, D),
+             ((double)nBI * D * S + (double)nBI * M * S) * 4,
+             conv_embed_fwd(sb, nBI, D, S, M, xin, ctx->WiT, ctx->i_embed.b, Ig, ctx->bf16, cap));
       RUNS(sb, "conv_att_pre", gflop(A, (double)nBI * S, M),
            ((double)nBI * M * S + (double)nBI * A * S) * 4,
            conv_att_pre(sb, nBI, M, S, A, Ig, ctx->WpT, ctx->att_i.b, Pg, ctx->bf16, cap));
@@ -1327,11 +1343,17 @@ int rau_backward(rau_ctx* ctx, const float* hop_w) {
              ((double)nH * A * S + (double)nH * M * S) * 4,
              conv_att_wgrad(sb, nH, M, S, A, ctx->T + hb * A * S, ctx->I + hb * M * S,
                             ctx->att_i.dW, ctx->slab2, ctx->bf16));
-        RUNS(sb, "conv_embed_wgrad", gflop(M, D, (double)nH * S),
-             ((double)nH * M * S * (dzf ? 1 : 2) + (double)nH * D * S) * 4,
-             conv_embed_wgrad(sb, nH, D, S, M, ctx->dZ + hb * M * S, ctx->I + hb * M * S,
-                              ctx->xd + hb * D * S, ctx->i_embed.dW, ctx->slab2, ctx->bf16,
-                              ctx->i_embed.db, dzf));
+        if (ctx->xd16 && dzf)
+          RUNS(sb, "conv_embed_wgrad", gflop(M, D, (double)nH * S),
+               (double)nH * M * S * 4 + (double)nH * D * S * 2,
+               conv_embed_wgrad_b16(sb, nH, D, S, M, ctx->dZ + hb * M * S,
+                                    (const uint16_t*)ctx->xd16 + hb * D * S, ctx->i_embed.dW, ctx->slab2));
+        else
+          RUNS(sb, "conv_embed_wgrad", gflop(M, D, (double)nH * S),
+               ((double)nH * M * S * (dzf ? 1 : 2) + (double)nH * D * S) * 4,
+               conv_embed_wgrad(sb, nH, D, S, M, ctx->dZ + hb * M * S, ctx->I + hb * M * S,
+                                  ctx->xd + hb * D * S, ctx->i_embed.dW, ctx->slab2, ctx->bf16,
+                                  ctx->i_embed.db, dzf));
         if (dzf && h == 0)   // last group: i_embed bias gradient = column sums of the per-sample rows
           RUNS(sb, "colsum", 0, (double)HA * B * M * 4,
                colsum_acc(sb, HA * B, M, ctx->dbi_part, M, ctx->i_embed.db, ctx->coltmp2));
