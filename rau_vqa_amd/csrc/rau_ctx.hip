@@ -199,6 +199,12 @@ int rau_create(const rau_config* cfg, rau_ctx** out) {
     int plo = 0, phi = 0;
     hipDeviceGetStreamPriorityRange(&plo, &phi);
     hipStreamCreateWithPriority(&ctx->st3, hipStreamNonBlocking, plo);
+    if (const char* eb = std::getenv("RAU_BULK2")) {   // A/B knob: 1 forward groups alternate, 2 att_i wgrad aside
+      ctx->bulk2 = std::atoi(eb);
+      hipStreamCreateWithPriority(&ctx->st2b, hipStreamNonBlocking, plo);
+      hipEventCreateWithFlags(&ctx->evP, evflags);
+      hipEventCreateWithFlags(&ctx->evJ, evflags);
+    }
   }
   // Default partition: pairs, then the last two hops alone.  The forward phase ends one hop after
   // the last group's GEMMs and the backward bulk work can start one hop into the backward chain
@@ -404,6 +410,7 @@ int rau_create(const rau_config* cfg, rau_ctx** out) {
     const size_t sl2 = std::max(conv_wgrad_slab_floats(H * B, A, M, S),
                                 conv_wgrad_slab_floats(H * B, M, D, S));
     CK(dalloc(ctx, &ctx->slab2, sl2));
+    if (ctx->st2b) CK(dalloc(ctx, &ctx->slab2b, sl2));
     const int rowsH = H * B, rowsT = T * B;
     const int shapes[][3] = {{K, M, rowsH},      {M, R, rowsH},      {4 * R, M, rowsH},
                              {4 * R, R, rowsH},  {M, S, rowsH},      {S, R, rowsH},
@@ -476,6 +483,9 @@ void rau_destroy(rau_ctx* ctx) {
   for (hipEvent_t e : {ctx->evA, ctx->evD, ctx->evW, ctx->evE, ctx->evW3, ctx->evM3, ctx->evEnd, ctx->evE1})
     if (e) hipEventDestroy(e);
   if (ctx->st3) hipStreamDestroy(ctx->st3);
+  if (ctx->st2b) { hipStreamSynchronize(ctx->st2b); hipStreamDestroy(ctx->st2b); }
+  if (ctx->evP) hipEventDestroy(ctx->evP);
+  if (ctx->evJ) hipEventDestroy(ctx->evJ);
   for (hipEvent_t e : ctx->evF) hipEventDestroy(e);
   for (hipEvent_t e : ctx->evK) hipEventDestroy(e);
   for (hipEvent_t e : ctx->evH) hipEventDestroy(e);
@@ -1140,7 +1150,14 @@ int rau_forward(rau_ctx* ctx) {
                             S));
     static const int cap_hops = [] { const char* e = std::getenv("RAU_FWD_CAP_HOPS");   // A/B knob
                                      return e ? std::atoi(e) : 0; }();
-    for (int h0 = 0; h0 < H; h0 += gsz[h0]) {
+    hipStream_t sb0 = sb;
+    if (ctx->st2b) {   // operands (transposed weights, dropped-out maps) are ready for the second bulk stream
+      HIPC(hipEventRecord(ctx->evP, sb0));
+      HIPC(hipStreamWaitEvent(ctx->st2b, ctx->evP, 0));
+    }
+    int gi = 0;
+    for (int h0 = 0; h0 < H; h0 += gsz[h0], ++gi) {
+      sb = (ctx->st2b && (ctx->bulk2 & 1) && (gi & 1)) ? ctx->st2b : sb0;
       const int cap = !ctx->I_shared && h0 < cap_hops;   // groups that run beside the encoder
       const int nBI = ctx->I_shared ? B : gsz[h0] * B;
       const size_t hb = ctx->I_shared ? 0 : (size_t)h0 * B;  // first (hop, sample) row
@@ -1160,6 +1177,10 @@ int rau_forward(rau_ctx* ctx) {
            ((double)nBI * M * S + (double)nBI * A * S) * 4,
            conv_att_pre(sb, nBI, M, S, A, Ig, ctx->WpT, ctx->att_i.b, Pg, ctx->bf16, cap));
       HIPC(hipEventRecord(ctx->evF[h0], sb));
+    }
+    if (ctx->st2b) {   // everything later on the bulk stream is ordered after both
+      HIPC(hipEventRecord(ctx->evJ, ctx->st2b));
+      HIPC(hipStreamWaitEvent(sb0, ctx->evJ, 0));
     }
   }
 
@@ -1339,10 +1360,14 @@ int rau_backward(rau_ctx* ctx, const float* hop_w) {
                ((double)nH * A * S + 2.0 * nH * M * S) * 4,
                conv_att_dgrad(sb, nH, M, S, A, ctx->T + hb * A * S, ctx->att_i.W, ctx->dj + hb * M,
                               ctx->a + hb * S, ctx->dZ + hb * M * S, ctx->bf16));
-        RUNS(sb, "conv_att_wgrad", gflop(A, M, (double)nH * S),
-             ((double)nH * A * S + (double)nH * M * S) * 4,
-             conv_att_wgrad(sb, nH, M, S, A, ctx->T + hb * A * S, ctx->I + hb * M * S,
-                            ctx->att_i.dW, ctx->slab2, ctx->bf16));
+        {   // RAU_BULK2: the att_i weight gradient (independent of dZ) on the second bulk stream
+          hipStream_t sa = (ctx->st2b && (ctx->bulk2 & 2)) ? ctx->st2b : sb;
+          if (sa != sb) HIPC(hipStreamWaitEvent(sa, ctx->evK[h], 0));
+          RUNS(sa, "conv_att_wgrad", gflop(A, M, (double)nH * S),
+               ((double)nH * A * S + (double)nH * M * S) * 4,
+               conv_att_wgrad(sa, nH, M, S, A, ctx->T + hb * A * S, ctx->I + hb * M * S,
+                              ctx->att_i.dW, sa != sb ? ctx->slab2b : ctx->slab2, ctx->bf16));
+        }
         if (ctx->xd16 && dzf)
           RUNS(sb, "conv_embed_wgrad", gflop(M, D, (double)nH * S),
                (double)nH * M * S * 4 + (double)nH * D * S * 2,
@@ -1385,6 +1410,10 @@ int rau_backward(rau_ctx* ctx, const float* hop_w) {
   // row sums of its staged dZ operand)
   {
     hipStream_t sb = ctx->st2;
+    if (ctx->st2b) {
+      HIPC(hipEventRecord(ctx->evJ, ctx->st2b));
+      HIPC(hipStreamWaitEvent(sb, ctx->evJ, 0));
+    }
     HIPC(hipEventRecord(ctx->evD, sb));
   }
   // ---------------- mult-group weight gradients, one GEMM per weight over all hops.
