@@ -34,16 +34,28 @@ hipError_t conv_embed_fwd(hipStream_t st, int nB, int D, int S, int M, const flo
 }
 
 hipError_t conv_embed_fwd_b16(hipStream_t st, int nB, int D, int S, int M, const void* X16,
-                              const float* WiT, const float* bi, float* I) {
+                              const void* WiT16, const float* bi, float* I) {
   GemmParams P{};
   P.M = M; P.N = nB * S; P.K = D; P.nk = (D + BK - 1) / BK;
-  P.A = WiT; P.a_rs = M;
+  P.A = reinterpret_cast<const float*>(WiT16); P.a_rs = M;
   P.B = reinterpret_cast<const float*>(X16); P.b_rs = S; P.b_bs = (long)D * S;   // in bf16 elements
   P.S = S;
   P.C = I; P.c_bs = (long)M * S;
   P.bias = bi;
   P.act = 1;
-  return launch_gemm<128, 128, BK, SRC_RC, SRC_RC_FLAT_B16, EPI_CONV, 1>(st, P, 1);
+  return launch_gemm<128, 128, BK, SRC_RC_B16, SRC_RC_FLAT_B16, EPI_CONV, 1>(st, P, 1);
+}
+hipError_t conv_att_pre_b16(hipStream_t st, int nB, int M, int S, int A, const float* I,
+                            const void* WpT16, const float* bp, float* Pout) {
+  GemmParams P{};
+  P.M = A; P.N = nB * S; P.K = M; P.nk = (M + BK - 1) / BK;
+  P.A = reinterpret_cast<const float*>(WpT16); P.a_rs = A;
+  P.B = I; P.b_rs = S; P.b_bs = (long)M * S;
+  P.S = S;
+  P.C = Pout; P.c_bs = (long)A * S;
+  P.bias = bp;
+  P.act = 0;
+  return launch_gemm<128, 128, BK, SRC_RC_B16, SRC_RC_FLAT, EPI_CONV, 1>(st, P, 1);
 }
 
 // P[b,k,s] = sum_m Wp[k,m] I[b,m,s] + bp[k]: the hop-invariant part of attbycontent's
@@ -95,9 +107,9 @@ bool conv_dz_fused_ok(int S, int M, int bf16) {
 }
 hipError_t conv_att_dgrad_dz(hipStream_t st, int nB, int M, int S, int A, const float* dS,
                              const float* Wp, const float* dj, const float* a, const float* I,
-                             float* dZ, float* rs) {
+                             float* dZ, float* rs, int dz16) {
   return conv_sample(st, 2, nB, M, A, S, Wp, M, dS, (long)A * S, dZ, (long)M * S, nullptr, 0, dj, a,
-                     I, rs);
+                     I, rs, dz16);
 }
 
 // dX'[b,d,s] = sum_m Wi[m,d] dZ[b,m,s]: gradient w.r.t. i_embed's (dropped-out) input.  The
@@ -202,13 +214,13 @@ hipError_t conv_embed_wgrad(hipStream_t st, int nB, int D, int S, int M, const f
   return conv_wgrad_any<SRC_SC_DTANH>(st, P, nB, S, dWi, slab, bf16, dbi);
 }
 
-hipError_t conv_embed_wgrad_b16(hipStream_t st, int nB, int D, int S, int M, const float* dZ,
+hipError_t conv_embed_wgrad_b16(hipStream_t st, int nB, int D, int S, int M, const void* dZ16,
                                 const void* X16, float* dWi, float* slab) {
   GemmParams P{};
   P.M = M; P.N = D;
-  P.A = dZ; P.a_bs = (long)M * S;
-  P.B = reinterpret_cast<const float*>(X16); P.b_bs = (long)D * S;   // in bf16 elements
-  return conv_wgrad<32, SRC_SC, 1, SRC_SC_B16>(st, P, nB, S, dWi, slab);
+  P.A = reinterpret_cast<const float*>(dZ16); P.a_bs = (long)M * S;  // both in bf16 elements
+  P.B = reinterpret_cast<const float*>(X16); P.b_bs = (long)D * S;
+  return conv_wgrad<32, SRC_SC_B16, 1, SRC_SC_B16>(st, P, nB, S, dWi, slab);
 }
 
 }  // namespace rau

@@ -334,7 +334,7 @@ struct LoadSC {
 // two mappings as LoadRC<FLAT, K4> and LoadSC, with half the bytes per load and no conversion --
 // the [K][cols] form only regroups the 16-bit halves of its four k-rows into 4-k plane elements
 // (two v_perm_b32 per element), the sample-chunk form stores what it loaded.
-template <int BT, int BKT>
+template <int BT, int BKT, bool FLAT = true>
 struct LoadRC16 {
   static constexpr int PAD = LPAD;
   static constexpr int CPR = BT / 4;
@@ -354,7 +354,8 @@ struct LoadRC16 {
     kr = tid / CPR;
     const int col = col0 + c4;
     ok = col < cols;
-    long off = (long)(col / P.S) * bs + (col % P.S);
+    long off = col;
+    if (FLAT) off = (long)(col / P.S) * bs + (col % P.S);
     if (!ok) off = 0;
     p = reinterpret_cast<const uint16_t*>(base) + off;
   }
@@ -437,7 +438,8 @@ enum Src : int {
   SRC_SC_DTANH = 4,  // same, operand = A * (1 - A2^2)
   SRC_RC_SUM = 5,    // [K][cols] + column sums of the operand handed back (P.rs_out)
   SRC_RC_FLAT_B16 = 6,  // SRC_RC_FLAT, operand stored as bf16 (RAU_BF16 mode)
-  SRC_SC_B16 = 7     // SRC_SC, operand stored as bf16
+  SRC_SC_B16 = 7,    // SRC_SC, operand stored as bf16
+  SRC_RC_B16 = 8     // SRC_RC, operand stored as bf16 (pre-converted weights)
 };
 template <int BT, int BKT, int SRC, bool K4 = false> struct LoaderOf;
 template <int BT, int BKT, bool K4> struct LoaderOf<BT, BKT, SRC_KC, K4> { using type = LoadKC<BT, BKT>; };
@@ -448,6 +450,7 @@ template <int BT, int BKT, bool K4> struct LoaderOf<BT, BKT, SRC_SC_DTANH, K4> {
 template <int BT, int BKT, bool K4> struct LoaderOf<BT, BKT, SRC_RC_SUM, K4> { using type = LoadRC<BT, BKT, false, K4, true>; };
 template <int BT, int BKT, bool K4> struct LoaderOf<BT, BKT, SRC_RC_FLAT_B16, K4> { using type = LoadRC16<BT, BKT>; };
 template <int BT, int BKT, bool K4> struct LoaderOf<BT, BKT, SRC_SC_B16, K4> { using type = LoadSC16<BT, BKT>; };
+template <int BT, int BKT, bool K4> struct LoaderOf<BT, BKT, SRC_RC_B16, K4> { using type = LoadRC16<BT, BKT, false>; };
 
 // -------------------------------------------------------------- epilogues
 enum Epi : int {

@@ -41,6 +41,7 @@ struct SampleParams {
   const float* bias; int act;          // EPI 0
   const float* dj; const float* av;    // EPI 1, 2: + dj[b,m] * a[b,s]
   const float* Y; float* rs;           // EPI 2: * (1 - Y[b,m,s]^2); rs[b,m] = sum_s of the result
+  int c16;                             // EPI 2: C is stored as bf16 ([b][M][S] 2-byte elements, RNE)
 };
 
 // RB = 16-row blocks per wave: tile rows SBM = 4 waves x RB x 16 (128 or 64)
@@ -190,7 +191,15 @@ __global__ __launch_bounds__(256, 2) void k_conv_sample(const SampleParams P) {
           rsum += (v.x + v.y) + (v.z + v.w);
         }
       }
-      *reinterpret_cast<float4*>(crow + s) = v;
+      if (EPI == 2 && P.c16) {
+        typedef __bf16 b16x4 __attribute__((ext_vector_type(4)));
+        b16x4 o;
+        o[0] = (__bf16)v.x; o[1] = (__bf16)v.y; o[2] = (__bf16)v.z; o[3] = (__bf16)v.w;
+        uint16_t* c16 = reinterpret_cast<uint16_t*>(P.C) + (size_t)b * P.c_bs + (size_t)m * S + s;
+        *reinterpret_cast<uint2*>(c16) = __builtin_bit_cast(uint2, o);
+      } else {
+        *reinterpret_cast<float4*>(crow + s) = v;
+      }
     }
     if (EPI == 2) {   // the four lanes lr, lr+16, lr+32, lr+48 hold the row's four position quarters
       rsum += __shfl_xor(rsum, 16, 64);
@@ -215,7 +224,7 @@ bool conv_sample_ok(int S, int which) {
 hipError_t conv_sample(hipStream_t st, int epi, int nB, int M, int K, int S, const float* Wt,
                        long w_rs, const float* X, long x_bs, float* C, long c_bs,
                        const float* bias, int act, const float* dj, const float* av,
-                       const float* Y, float* rs) {
+                       const float* Y, float* rs, int c16) {
   if (!(S % 4 == 0 && S > 176 && S <= SBN) || M % 4 != 0) return hipErrorInvalidValue;
   static const int rb_env = [] { const char* e = std::getenv("RAU_CONV_SAMPLE_RB");   // A/B knob
                                  return e ? std::atoi(e) : 2; }();
@@ -228,7 +237,7 @@ hipError_t conv_sample(hipStream_t st, int epi, int nB, int M, int K, int S, con
   P.C = C; P.c_bs = c_bs;
   P.bias = bias; P.act = act;
   P.dj = dj; P.av = av;
-  P.Y = Y; P.rs = rs;
+  P.Y = Y; P.rs = rs; P.c16 = c16;
   const dim3 grid(P.tiles_m * nB), block(256);
   // 64-row tiles: 41 KB of static LDS would let three workgroups share a CU (a ragged 2.67
   // rounds per hop); 16 KB of unused dynamic LDS keeps it at two

@@ -76,7 +76,10 @@ hipError_t conv_embed_fwd(hipStream_t st, int nB, int D, int S, int M, const flo
                           int one_per_cu = 0 /* cap residency at one workgroup per CU */);
 // RAU_BF16 mode with the feature maps stored as bf16 (X16 [nB][D][S] bf16; S % 4 == 0)
 hipError_t conv_embed_fwd_b16(hipStream_t st, int nB, int D, int S, int M, const void* X16,
-                              const float* WiT, const float* bi, float* I);
+                              const void* WiT16, const float* bi, float* I);
+// ifeatproj in RAU_BF16 mode with the transposed weight pre-converted (WpT16 [M][A] bf16)
+hipError_t conv_att_pre_b16(hipStream_t st, int nB, int M, int S, int A, const float* I,
+                            const void* WpT16, const float* bp, float* Pout);
 // P[b,k,s] = sum_m Wp[k,m] I[b,m,s] + bp[k]   (hop-invariant half of SS:244-252)
 hipError_t conv_att_pre(hipStream_t st, int nB, int M, int S, int A, const float* I,
                         const float* WpT /* [M][A] */, const float* bp, float* P, int bf16 = 0,
@@ -87,10 +90,11 @@ bool conv_sample_ok(int S, int which);
 hipError_t conv_sample(hipStream_t st, int epi, int nB, int M, int K, int S, const float* Wt,
                        long w_rs, const float* X, long x_bs, float* C, long c_bs,
                        const float* bias, int act, const float* dj, const float* av,
-                       const float* Y = nullptr, float* rs = nullptr);
+                       const float* Y = nullptr, float* rs = nullptr, int c16 = 0);
 // out[c][r] = in[r][c]  (rows x cols -> cols x rows); used once per step on the two
 // 1x1-conv weights so the forward conv GEMMs get a row-contiguous A operand
-hipError_t transpose2d(hipStream_t st, int rows, int cols, const float* in, float* out);
+hipError_t transpose2d(hipStream_t st, int rows, int cols, const float* in, float* out,
+                       void* out16 = nullptr);   // out16: a bf16 copy of out (RAU_BF16 mode)
 // dI[b,m,s] = sum_k Wp[k,m] dS[b,k,s] + dj[b,m] a[b,s]   (gradient at i_embed's output)
 hipError_t conv_att_dgrad(hipStream_t st, int nB, int M, int S, int A, const float* dS,
                           const float* Wp, const float* dj, const float* a, float* dI,
@@ -102,7 +106,7 @@ hipError_t conv_att_dgrad(hipStream_t st, int nB, int M, int S, int A, const flo
 bool conv_dz_fused_ok(int S, int M, int bf16);
 hipError_t conv_att_dgrad_dz(hipStream_t st, int nB, int M, int S, int A, const float* dS,
                              const float* Wp, const float* dj, const float* a, const float* I,
-                             float* dZ, float* rs);
+                             float* dZ, float* rs, int dz16 = 0);   // dz16: dZ stored as bf16
 // dX'[b,d,s] = sum_m Wi[m,d] dZ[b,m,s]   (dead in feval, SS:579; module-level API only)
 hipError_t conv_embed_dgrad(hipStream_t st, int nB, int D, int S, int M, const float* dZ,
                             const float* Wi, float* dX);
@@ -115,8 +119,8 @@ hipError_t conv_embed_wgrad(hipStream_t st, int nB, int D, int S, int M, const f
                             const float* I, const float* X, float* dWi, float* slab,
                             int bf16 = 0, float* dbi = nullptr /* += sum_{b,s} dZ[b,m,s] */,
                             int dz_final = 0 /* dI already holds dZ: no tanh factor, no dbi */);
-// same with dZ already final (f32, bf16-rounded while staging) and X stored as bf16
-hipError_t conv_embed_wgrad_b16(hipStream_t st, int nB, int D, int S, int M, const float* dZ,
+// same with dZ already final and both operands stored as bf16 (conv_att_dgrad_dz with dz16)
+hipError_t conv_embed_wgrad_b16(hipStream_t st, int nB, int D, int S, int M, const void* dZ16,
                                 const void* X16, float* dWi, float* slab);
 
 // --------------------------------------------------------- pointwise (kernels.hip)

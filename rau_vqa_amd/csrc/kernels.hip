@@ -979,7 +979,7 @@ hipError_t att_bwd_split(hipStream_t st, int nB, int M, int A, int S, const floa
 
 // 32x32 LDS-tiled transpose (bulk stream; no chain priority)
 __global__ void k_transpose2d(int rows, int cols, const float* __restrict__ in,
-                              float* __restrict__ out) {
+                              float* __restrict__ out, __bf16* __restrict__ out16) {
   __shared__ float tile[32][33];
   const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 256 threads: 32 x 8
@@ -987,11 +987,14 @@ __global__ void k_transpose2d(int rows, int cols, const float* __restrict__ in,
     if (r0 + j < rows && c0 + tx < cols) tile[j][tx] = in[(size_t)(r0 + j) * cols + c0 + tx];
   __syncthreads();
   for (int j = ty; j < 32; j += 8)
-    if (c0 + j < cols && r0 + tx < rows) out[(size_t)(c0 + j) * rows + r0 + tx] = tile[tx][j];
+    if (c0 + j < cols && r0 + tx < rows) {
+      out[(size_t)(c0 + j) * rows + r0 + tx] = tile[tx][j];
+      if (out16) out16[(size_t)(c0 + j) * rows + r0 + tx] = (__bf16)tile[tx][j];
+    }
 }
-hipError_t transpose2d(hipStream_t st, int rows, int cols, const float* in, float* out) {
+hipError_t transpose2d(hipStream_t st, int rows, int cols, const float* in, float* out, void* out16) {
   hipLaunchKernelGGL(k_transpose2d, dim3((cols + 31) / 32, (rows + 31) / 32), dim3(256), 0, st,
-                     rows, cols, in, out);
+                     rows, cols, in, out, reinterpret_cast<__bf16*>(out16));
   return hipGetLastError();
 }
 

@@ -116,6 +116,8 @@ struct rau_ctx {
   float *we, *G1, *G2, *c1, *h1, *c2, *h2, *tc1, *tc2, *x2, *q;
   // RAU activations
   float *xd;          // [H][B][D][S] feature map after per-hop dropout (train mode)
+  void* WiT16 = nullptr;  // with xd16: bf16 copies of the transposed conv weights WiT, WpT
+  void* WpT16 = nullptr;
   void* xd16 = nullptr;  // RAU_BF16 step path, S % 4 == 0: the same maps stored as bf16 (xd stays unwritten)
   bool I_shared = false;  // evaluate mode: i_embed output is hop-invariant, computed once
   float *WiT, *WpT;   // i_embed / ifeatproj weights transposed ([D][M], [M][A]), refreshed per forward

@@ -351,6 +351,11 @@ int rau_create(const rau_config* cfg, rau_ctx** out) {
     float* x16 = nullptr;
     CK(dalloc(ctx, &x16, (HB * D * S + 1) / 2));
     ctx->xd16 = x16;
+    float *w16 = nullptr, *p16 = nullptr;
+    CK(dalloc(ctx, &w16, ((size_t)M * D + 1) / 2));
+    CK(dalloc(ctx, &p16, ((size_t)A * M + 1) / 2));
+    ctx->WiT16 = w16;
+    ctx->WpT16 = p16;
   }
   CK(dalloc(ctx, &ctx->I, HB * M * S));
   CK(dalloc(ctx, &ctx->T, HB * A * S));
@@ -1138,8 +1143,8 @@ int rau_forward(rau_ctx* ctx) {
       HIPC(hipStreamWaitEvent(sb, ctx->evA, 0));
       enc_done = true;
     }
-    RUNS(sb, "transpose", 0, (double)M * D * 8, transpose2d(sb, M, D, ctx->i_embed.W, ctx->WiT));
-    RUNS(sb, "transpose", 0, (double)A * M * 8, transpose2d(sb, A, M, ctx->att_i.W, ctx->WpT));
+    RUNS(sb, "transpose", 0, (double)M * D * 8, transpose2d(sb, M, D, ctx->i_embed.W, ctx->WiT, ctx->WiT16));
+    RUNS(sb, "transpose", 0, (double)A * M * 8, transpose2d(sb, A, M, ctx->att_i.W, ctx->WpT, ctx->WpT16));
     const bool x16 = m_x && ctx->xd16;   // bf16 mode: the hop copies of the feature map are stored as bf16
     if (x16)
       RUNS(sb, "dropout_features", 0, (double)(H + 2) * B * D * S * 2,
@@ -1167,15 +1172,20 @@ int rau_forward(rau_ctx* ctx) {
       if (x16)
         RUNS(sb, "conv_embed_fwd", gflop(M, (double)nBI * S, D),
              (double)nBI * D * S * 2 + (double)nBI * M * S * 4,
-             conv_embed_fwd_b16(sb, nBI, D, S, M, (const uint16_t*)ctx->xd16 + hb * D * S, ctx->WiT,
+             conv_embed_fwd_b16(sb, nBI, D, S, M, (const uint16_t*)ctx->xd16 + hb * D * S, ctx->WiT16,
                                 ctx->i_embed.b, Ig));
       else
         RUNS(sb, "conv_embed_fwd", gflop(M, (double)nBI * S, D),
              ((double)nBI * D * S + (double)nBI * M * S) * 4,
              conv_embed_fwd(sb, nBI, D, S, M, xin, ctx->WiT, ctx->i_embed.b, Ig, ctx->bf16, cap));
-      RUNS(sb, "conv_att_pre", gflop(A, (double)nBI * S, M),
-           ((double)nBI * M * S + (double)nBI * A * S) * 4,
-           conv_att_pre(sb, nBI, M, S, A, Ig, ctx->WpT, ctx->att_i.b, Pg, ctx->bf16, cap));
+      if (x16)
+        RUNS(sb, "conv_att_pre", gflop(A, (double)nBI * S, M),
+             ((double)nBI * M * S + (double)nBI * A * S) * 4,
+             conv_att_pre_b16(sb, nBI, M, S, A, Ig, ctx->WpT16, ctx->att_i.b, Pg));
+      else
+        RUNS(sb, "conv_att_pre", gflop(A, (double)nBI * S, M),
+             ((double)nBI * M * S + (double)nBI * A * S) * 4,
+             conv_att_pre(sb, nBI, M, S, A, Ig, ctx->WpT, ctx->att_i.b, Pg, ctx->bf16, cap));
       HIPC(hipEventRecord(ctx->evF[h0], sb));
     }
     if (ctx->st2b) {   // everything later on the bulk stream is ordered after both
@@ -1353,8 +1363,9 @@ int rau_backward(rau_ctx* ctx, const float* hop_w) {
           RUNS(sb, "conv_att_dgrad", gflop(M, (double)nH * S, A),
                ((double)nH * A * S + 3.0 * nH * M * S) * 4,
                conv_att_dgrad_dz(sb, nH, M, S, A, ctx->T + hb * A * S, ctx->att_i.W, ctx->dj + hb * M,
-                                 ctx->a + hb * S, ctx->I + hb * M * S, ctx->dZ + hb * M * S,
-                                 ctx->dbi_part + hb * M));
+                                 ctx->a + hb * S, ctx->I + hb * M * S,
+                                 ctx->xd16 ? (float*)((uint16_t*)ctx->dZ + hb * M * S) : ctx->dZ + hb * M * S,
+                                 ctx->dbi_part + hb * M, ctx->xd16 ? 1 : 0));
         else
           RUNS(sb, "conv_att_dgrad", gflop(M, (double)nH * S, A),
                ((double)nH * A * S + 2.0 * nH * M * S) * 4,
@@ -1370,8 +1381,8 @@ int rau_backward(rau_ctx* ctx, const float* hop_w) {
         }
         if (ctx->xd16 && dzf)
           RUNS(sb, "conv_embed_wgrad", gflop(M, D, (double)nH * S),
-               (double)nH * M * S * 4 + (double)nH * D * S * 2,
-               conv_embed_wgrad_b16(sb, nH, D, S, M, ctx->dZ + hb * M * S,
+               (double)nH * M * S * 2 + (double)nH * D * S * 2,
+               conv_embed_wgrad_b16(sb, nH, D, S, M, (const uint16_t*)ctx->dZ + hb * M * S,
                                     (const uint16_t*)ctx->xd16 + hb * D * S, ctx->i_embed.dW, ctx->slab2));
         else
           RUNS(sb, "conv_embed_wgrad", gflop(M, D, (double)nH * S),
