@@ -101,3 +101,37 @@ def test_f32_results_do_not_depend_on_the_bf16_code_path():
         m.close()
     assert np.array_equal(outs[0], outs[1])
     assert not np.array_equal(outs[0], outs[2])
+
+
+def test_bf16_storage_of_operands_changes_nothing(monkeypatch):
+    """On 14x14 maps the bf16 step path keeps the dropped-out feature maps, dZ and the transposed conv
+    weights as bf16 IN HBM (rau_ctx.hip: xd16 / WiT16 / WpT16).  Those values are rounded to bf16
+    when staged anyway, so every output and gradient must be bitwise what the f32-storage path
+    (RAU_XD_F32=1, read when the context is created) produces."""
+    from rau_vqa_amd.model import RAU, Config
+    dims = dict(B=6, T=4, V=40, E=16, Rq=16, D=96, S=196, M=64, A=32, R=32, K=24, H=3)
+    sh = util.shapes(dims)
+    batch, params, masks = util.make_problem(sh, scale=0.3)
+    hop_w = np.full(sh.H, float(sh.H), np.float32)
+    res = []
+    for f32_storage in (True, False):
+        if f32_storage:
+            monkeypatch.setenv("RAU_XD_F32", "1")
+        else:
+            monkeypatch.delenv("RAU_XD_F32", raising=False)
+        m = RAU(Config(**{k: getattr(sh, k) for k in
+                          ("B", "T", "V", "E", "Rq", "D", "S", "M", "A", "R", "K", "H")}, dtype="bf16"))
+        m.set_params(params)
+        m.training()
+        m.set_masks(masks)
+        m.set_batch(batch["feats"], batch["tokens"], batch["lens"], batch["labels"])
+        m.zero_grads()
+        m.forward()
+        out = m.outputs()
+        m.backward(hop_w)
+        res.append((out, m.get_grads()))
+        m.close()
+    for k in util.OUT_KEYS:
+        assert np.array_equal(res[0][0][k], res[1][0][k]), k
+    for grp in ("embed", "rnn", "mult"):
+        assert np.array_equal(res[0][1][grp], res[1][1][grp]), grp
