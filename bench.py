@@ -261,11 +261,13 @@ def main():
         # PMC passes of the same command (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs,
         # FETCH_SIZE doubled per the gfx950 correction) when one exists for this kernel and shape
         traffic, traffic_src = None, None
+        shape = (args.batch, args.D, args.dtype)
         for rnd in ("r02", "r01"):
-            pmc = os.path.join(ROOT, "profiles", f"{rnd}_pmc_{dom_name}.json")
-            if os.path.exists(pmc) and (args.batch, args.D, args.dtype) == (256, 512, "f32"):
+            tag = {(256, 512, "f32"): rnd, (256, 2048, "bf16"): rnd + "_bf16"}.get(shape)
+            pmc = os.path.join(ROOT, "profiles", f"{tag}_pmc_{dom_name}.json")
+            if tag and os.path.exists(pmc):
                 traffic = json.load(open(pmc))["hbm_bytes_per_launch"]
-                traffic_src = f"profiles/{rnd}_pmc_{dom_name}.json (separate rocprofv3 --pmc passes)"
+                traffic_src = f"profiles/{tag}_pmc_{dom_name}.json (separate rocprofv3 --pmc passes)"
                 break
         mfma_peak = MFMA_F32_PEAK_TFLOPS if args.dtype == "f32" else MFMA_BF16_PEAK_TFLOPS
         both = {"mfma_frac": tfl / mfma_peak, "hbm_frac": gbs / HBM_PEAK_GBS,

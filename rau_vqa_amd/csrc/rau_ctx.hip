@@ -1029,6 +1029,7 @@ int rau_forward(rau_ctx* ctx) {
   // advance as a wavefront: per step ONE batched split-K GEMM (h1 W_h2h1^T for layer 1;
   // x2 W_i2h2^T and h2 W_h2h2^T for layer 2; same shapes) and ONE two-cell LSTM kernel
   // that sums the partials -- TL+1 steps of 2 launches instead of 2*TL steps of 2.
+  int enc_rec_step = 0;   // RAU_ENC_FIRST=k: evA is recorded again behind wavefront step k
   auto encoder_forward = [&]() -> int {
   if (TL > 0) {
     const int rows = TL * B;
@@ -1077,6 +1078,7 @@ int rau_forward(rau_ctx* ctx) {
           fl += C2.nsrc * gflop(B, 4 * Rq, Rq);
         }
         RUN("enc_step_fused", fl, 0, lstm_step_fused(st, GATES_DEEP, sp));
+        if (s == enc_rec_step) HIPC(hipEventRecord(ctx->evA, st));
       }
     } else
     for (int s = 1; s <= TL + 1; ++s) {
@@ -1120,6 +1122,7 @@ int rau_forward(rau_ctx* ctx) {
         C2.drop_out = nullptr; C2.mask = nullptr; C2.mask_e0 = 0; C2.mscale = 1.f;
       }
       RUN("lstm_fwd", 0, BRq * 4.0 * 10 * cells.n, lstm_fwd_multi(st, GATES_DEEP, B, Rq, cells));
+      if (s == enc_rec_step) HIPC(hipEventRecord(ctx->evA, st));
     }
   }
   return 0;
@@ -1136,10 +1139,12 @@ int rau_forward(rau_ctx* ctx) {
     hipStream_t sb = ctx->st2;
     HIPC(hipEventRecord(ctx->evA, st));
     HIPC(hipStreamWaitEvent(sb, ctx->evA, 0));
-    static const bool enc_first = std::getenv("RAU_ENC_FIRST") != nullptr;
-    if (enc_first && TL > 0) {   // A/B knob: the encoder gets the machine to itself first
+    // A/B knob: the encoder gets the machine to itself for its first k wavefront steps (k >= T+1: all)
+    static const int enc_first = [] { const char* e = std::getenv("RAU_ENC_FIRST");
+                                      return e ? std::max(1, std::atoi(e)) : 0; }();
+    if (enc_first && TL > 0) {
+      enc_rec_step = std::min(enc_first, TL + 1);
       if (int rc = encoder_forward()) return rc;
-      HIPC(hipEventRecord(ctx->evA, st));
       HIPC(hipStreamWaitEvent(sb, ctx->evA, 0));
       enc_done = true;
     }

@@ -47,6 +47,23 @@ for (name, wg), f in fetch.items():
         alg = alg_hop * (wg / wg_hop if wg_hop else H / 5.0)
     rows.append((cls, name, wg, len(f), us, hbm, alg))
 rows.sort()
+# per class: launch-count-weighted averages, the form bench.py reads (roofline.traffic)
+by_cls = collections.defaultdict(list)
+for r in rows: by_cls[r[0]].append(r)
+for cls, rr in by_cls.items():
+    n = sum(r[3] for r in rr)
+    json.dump({"kernel": cls,
+               "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace --output-format csv -- python3 "
+                          "bench.py --dtype bf16 --D 2048 --variant ResNet --no-cpu-baseline --steps 2 --warmup 1 "
+                          "(two separate passes)",
+               "launch_shapes": [{"kernel_name": r[1], "workgroups": r[2], "dispatches": r[3], "avg_us": r[4],
+                                  "hbm_bytes": r[5], "algorithmic_bytes": r[6]} for r in rr],
+               "hbm_bytes_per_launch": sum(r[5] * r[3] for r in rr) / n,
+               "algorithmic_bytes_per_launch": sum(r[6] * r[3] for r in rr) / n,
+               "ratio": sum(r[5] * r[3] for r in rr) / sum(r[6] * r[3] for r in rr),
+               "note": "hbm_bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (gfx950 FETCH_SIZE correction, "
+                       "MI355X_MICROARCH.md); operands counted at their stored width"},
+              open(os.path.join(OUT, f"{tag}_bf16_pmc_{cls}.json"), "w"), indent=1)
 lines = [f"# {tag} bf16 mode (BASELINE.json configs[2]: Ours_ResNet, B=256, D=2048, bf16 conv operands)", ""]
 bl = os.path.join(src, "b16_bench_line.json")
 for l in open(bl):
