@@ -10,6 +10,11 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
+# rau_graph_step: ROCm 7.2's graph executor spreads a captured graph's branches over its own
+# queues; with its default the three-stream step replays 1.5-2x slower than the eager calls, with
+# two queues within 9-13 %.  The runtime reads the variable when it
+# initialises, i.e. at the first HIP call of the process, which comes after this import.
+os.environ.setdefault("DEBUG_HIP_FORCE_GRAPH_QUEUES", "2")
 # RAU_LIB overrides the library path (A/B runs of two builds on one GPU box)
 LIB_PATH = os.environ.get("RAU_LIB") or os.path.join(_HERE, "librau.so")
 CSRC = os.path.join(_HERE, "csrc")
