@@ -605,13 +605,16 @@ int rau_set_mask(rau_ctx* ctx, int site, const uint8_t* keep, size_t n) {
   ctx->mod_masks_valid = false;
   return RAU_OK;
 }
-static int gen_masks(rau_ctx* ctx) {
+// only: -1 = every site on the ctx stream; rau_forward fills the feature-map site (by far the largest,
+// and read by the bulk stream only) on the bulk stream instead: skip = RAU_MASK_X, then only = RAU_MASK_X
+static int gen_masks(rau_ctx* ctx, int skip = -1, int only = -1, hipStream_t stream = nullptr) {
   if (ctx->mode != RAU_MODE_TRAIN) return 0;
+  hipStream_t s = stream ? stream : ctx->st;
   for (int i = 0; i < 5; ++i)
-    if (!ctx->mexplicit[i] && ctx->mp[i] > 0.f)
-      RUN("fill_masks", 0, ctx->mcount[i] / 8.0,
-          fill_masks(ctx->st, ctx->seed, (uint32_t)i, ctx->step, ctx->mp[i], ctx->mcount[i],
-                     ctx->mbits[i], ctx->dkey));
+    if (i != skip && (only < 0 || i == only) && !ctx->mexplicit[i] && ctx->mp[i] > 0.f)
+      RUNS(s, "fill_masks", 0, ctx->mcount[i] / 8.0,
+           fill_masks(s, ctx->seed, (uint32_t)i, ctx->step, ctx->mp[i], ctx->mcount[i],
+                      ctx->mbits[i], ctx->dkey));
   return 0;
 }
 int rau_get_mask(rau_ctx* ctx, int site, uint8_t* keep, size_t n) {
@@ -1003,7 +1006,7 @@ int rau_forward(rau_ctx* ctx) {
             H = c.H, Q = ctx->Q;
   const int TL = ctx->max_len;
   hipStream_t st = ctx->st;
-  if (int rc = gen_masks(ctx)) return rc;
+  if (int rc = gen_masks(ctx, RAU_MASK_X)) return rc;
   const bool tr = ctx->mode == RAU_MODE_TRAIN;
   auto mk = [&](int site) -> const uint32_t* {
     return (tr && ctx->mp[site] > 0.f) ? ctx->mbits[site] : nullptr;
@@ -1148,6 +1151,7 @@ int rau_forward(rau_ctx* ctx) {
       HIPC(hipStreamWaitEvent(sb, ctx->evA, 0));
       enc_done = true;
     }
+    if (int rc = gen_masks(ctx, -1, RAU_MASK_X, sb)) return rc;
     RUNS(sb, "transpose", 0, (double)M * D * 8, transpose2d(sb, M, D, ctx->i_embed.W, ctx->WiT, ctx->WiT16));
     RUNS(sb, "transpose", 0, (double)A * M * 8, transpose2d(sb, A, M, ctx->att_i.W, ctx->WpT, ctx->WpT16));
     const bool x16 = m_x && ctx->xd16;   // bf16 mode: the hop copies of the feature map are stored as bf16
