@@ -813,10 +813,11 @@ __global__ __launch_bounds__(256) void k_att_ctx(
   }
 }
 
-static int att_chunks() {
-  static const int v = [] { const char* e = std::getenv("RAU_ATT_CHUNKS"); const int n = e ? std::atoi(e) : 0;
-                            return (n >= 1 && n <= 8) ? n : 4; }();
-  return v;
+// row chunks per sample: 8 for small batches (the launch should still cover the chip), else 4
+static int att_chunks(int nB) {
+  const char* e = std::getenv("RAU_ATT_CHUNKS");   // read per call: tests switch it between contexts
+  const int n = e ? std::atoi(e) : 0;
+  return (n >= 1 && n <= 8) ? n : (nB <= 64 ? 8 : 4);
 }
 size_t att_split_part_floats(int nB, int S) { return (size_t)nB * 8 * S; }
 
@@ -824,7 +825,7 @@ hipError_t att_fwd_split(hipStream_t st, int nB, int M, int A, int S, const floa
                          const float* u, const float* ws, const float* bs, const float* zm,
                          const float* I, const float* qf, float* a, float* jv, float* part,
                          const AttPartials& ap) {
-  const int nc = att_chunks();
+  const int nc = att_chunks(nB);
   hipLaunchKernelGGL(k_att_score_part, dim3(nc, nB), dim3(256), (size_t)4 * S * sizeof(float), st, nB,
                      A, S, P, u, ws, part, ap);
   hipLaunchKernelGGL(k_att_ctx, dim3(nc, nB), dim3(256), (size_t)(S + 8) * sizeof(float), st, nB, M, S,
@@ -969,7 +970,7 @@ hipError_t att_bwd_split(hipStream_t st, int nB, int M, int A, int S, const floa
                          const float* dj, const float* a, const float* da_lin, const float* ws,
                          float* T_to_dS, float* dz, float* du, float* dwsp, const float* Psrc,
                          const float* u, float* part, int da_ns, int SL, const float* da_add) {
-  const int nc = att_chunks();
+  const int nc = att_chunks(nB);
   hipLaunchKernelGGL(k_att_da_part, dim3(nc, nB), dim3(256), (size_t)4 * S * sizeof(float), st, M, S, I,
                      dj, part);
   hipLaunchKernelGGL(k_att_ds, dim3(nc, nB), dim3(256), (size_t)(S + 4) * sizeof(float), st, nB, A, S,

@@ -369,7 +369,11 @@ int rau_create(const rau_config* cfg, rau_ctx** out) {
   // split attention + fused encoder step 10.92-10.95, round-1 library 10.75-10.82.  The split
   // attention kernels and the fused LSTM step are faster ALONE (no bulk GEMM beside them): the
   // evaluate-mode forward uses the fused LSTM step; RAU_ATT_SPLIT / RAU_ENC_FUSED force them.
-  ctx->att_split_env = std::getenv("RAU_ATT_SPLIT") != nullptr;
+  // Small batches (one 16-wave workgroup per sample leaves most CUs idle): B = 32 / 64 / 128 fused
+  // 3.83 / 4.57 / 6.06 ms, split in 8 row chunks 3.63 / 4.39 / 6.05 ms -> split up to B = 64
+  // (RAU_ATT_FUSED keeps the fused kernels).
+  ctx->att_split_env = std::getenv("RAU_ATT_SPLIT") != nullptr ||
+                       (c.B <= 64 && std::getenv("RAU_ATT_FUSED") == nullptr);
   ctx->enc_fused_env = std::getenv("RAU_ENC_FUSED") != nullptr;
   CK(dalloc(ctx, &ctx->a, HB * S));
   CK(dalloc(ctx, &ctx->jv, (size_t)B * M));
