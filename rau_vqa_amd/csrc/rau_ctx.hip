@@ -224,6 +224,11 @@ int rau_create(const rau_config* cfg, rau_ctx** out) {
       }
       if (sum != c.H) sizes.clear();
     }
+    if (sizes.empty() && c.B <= 64) {
+      // small batches are bound by the recurrence's launches, not by the conv GEMMs: one group
+      // (B = 32 / 64: 3.64 / 4.43 -> 3.55 / 4.33 ms; B = 128: 6.09 -> 6.49, so not there)
+      sizes.push_back(c.H);
+    }
     if (sizes.empty()) {
       int left = c.H;
       while (left > 3) { sizes.push_back(2); left -= 2; }
