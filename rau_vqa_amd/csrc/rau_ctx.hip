@@ -430,7 +430,9 @@ int rau_create(const rau_config* cfg, rau_ctx** out) {
                              {4 * R, R, rowsH},  {M, S, rowsH},      {S, R, rowsH},
                              {A, M, rowsH},      {M, Q, rowsH},      {4 * Rq, E, rowsT},
                              {4 * Rq, Rq, rowsT}};
-    size_t sl = (size_t)16 * B * std::max({4 * R, 4 * Rq, K, Q});  // skinny split-K partials
+    // skinny split-K partials: every deferred GEMM of the hop loop must fit un-split in its share of
+    // the slab (a quarter to a sixth), whatever its output width (4R, 4Rq, K, Q, M, A or S)
+    size_t sl = (size_t)16 * B * std::max({4 * R, 4 * Rq, K, Q, M, A, S});
     for (auto& s : shapes) sl = std::max(sl, gemm_tn_slab_floats(s[0], s[1], s[2]));
     ctx->slab_floats = sl;
     CK(dalloc(ctx, &ctx->slab, sl));

@@ -147,3 +147,12 @@ def test_snapshot_round_trip_through_t7(tmp_path):
         np.testing.assert_array_equal(pa[g], pb[g])
     a.close()
     b.close()
+
+
+def test_multfeat_wider_than_every_recurrent_width():
+    """M = 128 beside R = 8, Rq = 4, K = 32 (found by tools/soak.py): the split-K workspace of the hop
+    loop used to be sized from 4R / 4Rq / K / Q only, and the deferred dj GEMM ([B, M] partials) did
+    not fit -> `kernel small_gemm: invalid argument`."""
+    dims = dict(B=18, T=6, V=25, E=20, Rq=4, D=136, S=4, M=128, A=20, R=8, K=32, H=4)
+    check(util.shapes(dims), scale=0.3, mode="eval")
+    check(util.shapes(dims), scale=0.3, mode="train")
