@@ -186,7 +186,11 @@ int rau_backward(rau_ctx* ctx, const float* hop_w /* [H] host */);
  * (they batch across clones); do not interleave the two within one step. */
 
 /* word_embed = LookupTable -> Dropout(0.5) -> Tanh, SS:203-206; :forward SS:451,
- * :backward SS:593 (LookupTable has no gradInput).  tokens_dev [B] int32 1-based. */
+ * :backward SS:593 (LookupTable has no gradInput).  tokens_dev [B] int32 1-based.
+ * Ids in DEVICE tensors (tokens_dev here, labels_dev of rau_criterion_*) cannot be range-checked
+ * by the call: the kernels clamp them into [1, V] / [1, K], so a bad id uses a wrong row where
+ * the reference's LookupTable / ClassNLLCriterion would raise -- it never faults the GPU.  (The
+ * host arrays of rau_set_batch ARE checked and rejected with RAU_ERR_ARG.) */
 int rau_embed_forward(rau_ctx* ctx, int t, const int32_t* tokens_dev, float** we /* [B,E] */);
 int rau_embed_backward(rau_ctx* ctx, int t, const int32_t* tokens_dev, const float* d_we);
 

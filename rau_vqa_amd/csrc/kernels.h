@@ -130,9 +130,9 @@ enum GateOrder { GATES_ATT = 0 /* i g f o, ATTLSTM.lua:12-19 */,
 // key_dev != nullptr: (seed, step) are read from key_dev[0], key_dev[1] on the device instead
 hipError_t fill_masks(hipStream_t st, uint64_t seed, uint32_t site, uint32_t step, float p,
                       size_t n, uint32_t* bits, const uint64_t* key_dev = nullptr);
-hipError_t embed_fwd(hipStream_t st, int rows, int E, const float* emb, const int32_t* tokens,
+hipError_t embed_fwd(hipStream_t st, int rows, int E, int V, const float* emb, const int32_t* tokens,
                      const uint32_t* mask, float mscale, float* we, size_t mask_e0 = 0);
-hipError_t embed_bwd_rows(hipStream_t st, int rows, int E, const int32_t* tokens, const float* dwe,
+hipError_t embed_bwd_rows(hipStream_t st, int rows, int E, int V, const int32_t* tokens, const float* dwe,
                           const float* we, const uint32_t* mask, size_t mask_e0, float mscale,
                           float* gE);
 // in place on g4: pre-activations (+ sum of `nsplit` split-K partials [nB,4R] in `slab`)

@@ -63,7 +63,10 @@ hipError_t uniform_fill(hipStream_t st, uint64_t seed, uint32_t stream, size_t n
 
 // ------------------------------------------------------------ word embedding
 // we[row, e] = tanh(drop(E[token[row]-1, e]))      reference SS:203-206
-__global__ void k_embed_fwd(int rows, int E, const float* __restrict__ emb,
+// Token ids of the step-level path are range-checked on the host (rau_set_batch); the module-level calls
+// take DEVICE id tensors, which nobody has looked at: ids are clamped into [1, V] so that a bad id
+// reads / updates a wrong row instead of faulting the GPU (the reference's LookupTable would raise).
+__global__ void k_embed_fwd(int rows, int E, int V, const float* __restrict__ emb,
                             const int32_t* __restrict__ tokens,
                             const uint32_t* __restrict__ mask, size_t mask_e0, float mscale,
                             float* __restrict__ we) {
@@ -72,21 +75,22 @@ __global__ void k_embed_fwd(int rows, int E, const float* __restrict__ emb,
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n;
        i += (size_t)gridDim.x * blockDim.x) {
     const int row = (int)(i / E), e = (int)(i - (size_t)row * E);
-    float v = emb[(size_t)(tokens[row] - 1) * E + e];
+    const int tk = min(max(tokens[row], 1), V);
+    float v = emb[(size_t)(tk - 1) * E + e];
     if (mask) v = mask_bit(mask, mask_e0 + i) ? v * mscale : 0.f;
     we[i] = tanh_fast(v);
   }
 }
-hipError_t embed_fwd(hipStream_t st, int rows, int E, const float* emb, const int32_t* tokens,
+hipError_t embed_fwd(hipStream_t st, int rows, int E, int V, const float* emb, const int32_t* tokens,
                      const uint32_t* mask, float mscale, float* we, size_t mask_e0) {
-  hipLaunchKernelGGL(k_embed_fwd, dim3(grid_for((size_t)rows * E)), dim3(256), 0, st, rows, E,
+  hipLaunchKernelGGL(k_embed_fwd, dim3(grid_for((size_t)rows * E)), dim3(256), 0, st, rows, E, V,
                      emb, tokens, mask, mask_e0, mscale, we);
   return hipGetLastError();
 }
 
 // LookupTable gradient of ONE token row set (module-level word_embed:backward, SS:593):
 // thread e walks the rows in order, so repeated tokens accumulate deterministically.
-__global__ void k_embed_bwd_rows(int rows, int E, const int32_t* __restrict__ tokens,
+__global__ void k_embed_bwd_rows(int rows, int E, int V, const int32_t* __restrict__ tokens,
                                  const float* __restrict__ dwe, const float* __restrict__ we,
                                  const uint32_t* __restrict__ mask, size_t mask_e0, float mscale,
                                  float* __restrict__ gE) {
@@ -97,13 +101,13 @@ __global__ void k_embed_bwd_rows(int rows, int E, const int32_t* __restrict__ to
     const float y = we[i];
     float d = dwe[i] * (1.f - y * y);
     if (mask) d = mask_bit(mask, mask_e0 + i) ? d * mscale : 0.f;
-    gE[(size_t)(tokens[r] - 1) * E + e] += d;
+    gE[(size_t)(min(max(tokens[r], 1), V) - 1) * E + e] += d;
   }
 }
-hipError_t embed_bwd_rows(hipStream_t st, int rows, int E, const int32_t* tokens, const float* dwe,
+hipError_t embed_bwd_rows(hipStream_t st, int rows, int E, int V, const int32_t* tokens, const float* dwe,
                           const float* we, const uint32_t* mask, size_t mask_e0, float mscale,
                           float* gE) {
-  hipLaunchKernelGGL(k_embed_bwd_rows, dim3((E + 63) / 64), dim3(64), 0, st, rows, E, tokens, dwe,
+  hipLaunchKernelGGL(k_embed_bwd_rows, dim3((E + 63) / 64), dim3(64), 0, st, rows, E, V, tokens, dwe,
                      we, mask, mask_e0, mscale, gE);
   return hipGetLastError();
 }
@@ -1222,7 +1226,8 @@ __global__ void k_ce_fwd(int nB, int K, int M, const float* __restrict__ logits,
   const float lse = mx + logf(den);
   if (tid == 0) argmax[b] = ai + 1;
   if (labels) {
-    const int y = labels[b % Bper] - 1;   // rows = [hop][sample]: labels repeat every Bper rows
+    // rows = [hop][sample]: labels repeat every Bper rows; clamped like the token ids above
+    const int y = min(max(labels[b % Bper], 1), K) - 1;
     const float invB = 1.f / (float)Bper;
     for (int k = tid; k < K; k += 256) {
       float p = expf(lg[k] - lse) * invB;

@@ -1049,7 +1049,7 @@ int rau_forward(rau_ctx* ctx) {
     const int rows = TL * B;
     const size_t G4 = (size_t)B * 4 * Rq;
     RUN("embed_fwd", 0, rows * E * 8.0,
-        embed_fwd(st, rows, E, ctx->grp[RAU_GROUP_EMBED].w, ctx->tokens, m_we, sc(RAU_MASK_WE),
+        embed_fwd(st, rows, E, c.V, ctx->grp[RAU_GROUP_EMBED].w, ctx->tokens, m_we, sc(RAU_MASK_WE),
                   ctx->we));
     {  // layer-1 input projection of every token at once (no recurrence in it)
       LINOPTS(o);

@@ -119,7 +119,7 @@ int rau_embed_forward(rau_ctx* ctx, int t, const int32_t* tokens_dev, float** we
   const Masks m = masks_of(ctx);
   float* out = ctx->we + (size_t)t * c.B * c.E;
   RUN("embed_fwd", 0, c.B * c.E * 8.0,
-      embed_fwd(ctx->st, c.B, c.E, ctx->grp[RAU_GROUP_EMBED].w, tokens_dev, m.we, m.s_we, out,
+      embed_fwd(ctx->st, c.B, c.E, c.V, ctx->grp[RAU_GROUP_EMBED].w, tokens_dev, m.we, m.s_we, out,
                 (size_t)t * c.B * c.E));
   *we = out;
   return RAU_OK;
@@ -136,7 +136,7 @@ int rau_embed_backward(rau_ctx* ctx, int t, const int32_t* tokens_dev, const flo
   }
   const Masks m = masks_of(ctx);
   RUN("embed_bwd", 0, c.B * c.E * 12.0,
-      embed_bwd_rows(ctx->st, c.B, c.E, tokens_dev, d_we, ctx->we + (size_t)t * c.B * c.E, m.we,
+      embed_bwd_rows(ctx->st, c.B, c.E, c.V, tokens_dev, d_we, ctx->we + (size_t)t * c.B * c.E, m.we,
                      (size_t)t * c.B * c.E, m.s_we, ctx->grp[RAU_GROUP_EMBED].g));
   return RAU_OK;
 }

@@ -343,3 +343,47 @@ def test_module_level_calls_on_7x7_maps():
     # softmax Jacobian: a constant gradient at the attention output gives no gradient upstream
     assert float(dq.abs().max()) < 1e-5 and float(dX.abs().max()) < 1e-5
     m.close()
+
+
+def test_out_of_range_ids_in_device_tensors_are_clamped_not_faulted():
+    """Module-level calls take DEVICE id tensors the library cannot range-check (include/rau.h): token
+    ids and labels are clamped into [1, V] / [1, K] by the kernels, so 0, negative and too-large ids
+    behave like the nearest valid id instead of reading or updating memory outside the tables."""
+    import torch
+    from rau_vqa_amd import modules
+    sh = util.shapes(util.SMALL)
+    batch, params, _ = util.make_problem(sh, scale=0.5)
+    m = make_model(sh, params, mode="eval")
+    bad = np.array([0, -7, sh.V + 1, 2 ** 30, 1, sh.V, 3, 2][:sh.B], np.int32)
+    good = np.clip(bad, 1, sh.V).astype(np.int32)
+    rng = np.random.default_rng(4)
+    d_we = rng.standard_normal((sh.B, sh.E)).astype(np.float32)
+    grads = []
+    ext = torch.cuda.ExternalStream(m.stream())
+    outs = []
+    for ids in (bad, good):
+        m.zero_grads()
+        with torch.cuda.stream(ext):
+            e = modules.EmbedClone(m, 0)
+            x = cuda(ids, torch.int32)
+            outs.append(e.forward(x).clone())
+            e.backward(x, cuda(d_we))
+        m.sync()
+        grads.append(m.get_grads()["embed"].copy())
+    assert torch.equal(outs[0], outs[1])
+    assert np.array_equal(grads[0], grads[1])
+    # labels: the criterion treats 0 / K+5 like 1 / K
+    lg = rng.standard_normal((sh.B, sh.K)).astype(np.float32)
+    ybad = np.array([0, sh.K + 5, 1, sh.K, 2, 3, 4, 5][:sh.B], np.int32)
+    ygood = np.clip(ybad, 1, sh.K).astype(np.int32)
+    crit = modules.CriterionClone(m, 0)
+    res = []
+    for y in (ybad, ygood):
+        with torch.cuda.stream(ext):
+            lgd, yd = cuda(lg), cuda(y, torch.int32)
+            loss = crit.forward(lgd, yd)
+            dl = crit.backward(lgd, yd).clone()
+        m.sync()
+        res.append((loss, dl))
+    assert res[0][0] == res[1][0] and torch.equal(res[0][1], res[1][1])
+    m.close()
