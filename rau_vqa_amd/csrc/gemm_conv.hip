@@ -16,9 +16,15 @@ constexpr int BK = 32;
 // 16-byte LDS writes and full-line global reads, ~10% faster than the k-contiguous
 // loader), B = X' [b][d][s] (position contiguous; dropout already applied by
 // dropout_features).  nB may be a group of hops.
+static int conv_epi_dbg() {
+  static const int v = std::getenv("RAU_CONV_EPI_DIRECT") ? 4 : 0;   // A/B knob, see gemm_core.h
+  return v;
+}
+
 hipError_t conv_embed_fwd(hipStream_t st, int nB, int D, int S, int M, const float* X,
                           const float* WiT, const float* bi, float* I, int bf16, int one_per_cu) {
   GemmParams P{};
+  P.dbg = conv_epi_dbg();
   P.M = M; P.N = nB * S; P.K = D; P.nk = (D + BK - 1) / BK;
   P.A = WiT; P.a_rs = M;
   P.B = X; P.b_rs = S; P.b_bs = (long)D * S;
@@ -36,6 +42,7 @@ hipError_t conv_embed_fwd(hipStream_t st, int nB, int D, int S, int M, const flo
 hipError_t conv_embed_fwd_b16(hipStream_t st, int nB, int D, int S, int M, const void* X16,
                               const void* WiT16, const float* bi, float* I) {
   GemmParams P{};
+  P.dbg = conv_epi_dbg();
   P.M = M; P.N = nB * S; P.K = D; P.nk = (D + BK - 1) / BK;
   P.A = reinterpret_cast<const float*>(WiT16); P.a_rs = M;
   P.B = reinterpret_cast<const float*>(X16); P.b_rs = S; P.b_bs = (long)D * S;   // in bf16 elements
@@ -48,6 +55,7 @@ hipError_t conv_embed_fwd_b16(hipStream_t st, int nB, int D, int S, int M, const
 hipError_t conv_att_pre_b16(hipStream_t st, int nB, int M, int S, int A, const float* I,
                             const void* WpT16, const float* bp, float* Pout) {
   GemmParams P{};
+  P.dbg = conv_epi_dbg();
   P.M = A; P.N = nB * S; P.K = M; P.nk = (M + BK - 1) / BK;
   P.A = reinterpret_cast<const float*>(WpT16); P.a_rs = A;
   P.B = I; P.b_rs = S; P.b_bs = (long)M * S;
@@ -64,6 +72,7 @@ hipError_t conv_att_pre_b16(hipStream_t st, int nB, int M, int S, int A, const f
 hipError_t conv_att_pre(hipStream_t st, int nB, int M, int S, int A, const float* I,
                         const float* WpT, const float* bp, float* Pout, int bf16, int one_per_cu) {
   GemmParams P{};
+  P.dbg = conv_epi_dbg();
   P.M = A; P.N = nB * S; P.K = M; P.nk = (M + BK - 1) / BK;
   P.A = WpT; P.a_rs = A;                // Wp^T [M][A]: reduction-major
   P.B = I; P.b_rs = S; P.b_bs = (long)M * S;

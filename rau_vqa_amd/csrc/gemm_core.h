@@ -70,6 +70,10 @@ __device__ __forceinline__ void put_bf16(uint2* img, int idx, int set_stride, fl
   }
 }
 
+// A/B knob (RAU_CONV_EPI_DIRECT, read by the launcher into GemmParams::dbg bit 2): keep the round-1
+// direct accumulator stores of the flattened-column conv epilogue
+#define rau_conv_epi_direct ((P.dbg & 4) != 0)
+
 // Superset of the arguments any loader/epilogue combination needs.
 struct GemmParams {
   int M, N, K;          // output rows / cols, reduction length (per sample in SC mode)
@@ -760,6 +764,52 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& P, const int bx, con
         }
     }
   } else {
+    // EPI_CONV on maps with S % 4 == 0: the accumulator tile goes through the (idle) staging LDS and
+    // leaves as whole rows -- a thread stores float4s of four consecutive positions, 32 lanes one
+    // 512-byte run of a row -- instead of 128-byte pieces at the 4 S-byte row pitch written by
+    // different waves at different times (measured round 1: 1.37x the algorithmic bytes reached HBM,
+    // all of it partial-line writes).  bf16 modes stage half the tile at a time (their LDS is smaller).
+    if constexpr (EPI == EPI_CONV && BM == 128 && BN == 128) {
+      if (P.S % 4 == 0 && !rau_conv_epi_direct) {
+        constexpr int TP = BN + 4;                               // staged row pitch (floats)
+        constexpr int RP = kStage / TP >= BM ? BM : 64;          // rows per pass
+        static_assert(RP * TP <= kStage, "staging area too small for the epilogue tile");
+        float* T = smem;
+        const int c4 = (tid & 31) * 4;
+        const int n = n0 + c4;
+        const bool nok = n < P.N;                                // N = nB * S is a multiple of 4
+        const int nb = (nok ? n : 0) / P.S, ns = (nok ? n : 0) - nb * P.S;
+        float* crow = P.C + (long)nb * P.c_bs + ns;
+        __syncthreads();
+#pragma unroll 1
+        for (int p0 = 0; p0 < BM; p0 += RP) {
+#pragma unroll
+          for (int i = 0; i < IM; ++i) {
+            const int rb = wm * WM + i * 32;                     // first tile row of this 32x32 block
+            if (rb >= p0 && rb < p0 + RP) {
+#pragma unroll
+              for (int j = 0; j < JN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                  T[(rloc + i * 32 + (r & 3) + 8 * (r >> 2) - p0) * TP + cloc + j * 32] = acc[i][j][r];
+            }
+          }
+          __syncthreads();
+          for (int row = tid >> 5; row < RP; row += 8) {
+            const int m = m0 + p0 + row;
+            if (m < P.M && nok) {
+              float4 v = *reinterpret_cast<const float4*>(T + row * TP + c4);
+              const float bv = P.bias ? P.bias[m] : 0.f;
+              v.x += bv; v.y += bv; v.z += bv; v.w += bv;
+              if (P.act) { v.x = tanh_fast(v.x); v.y = tanh_fast(v.y); v.z = tanh_fast(v.z); v.w = tanh_fast(v.w); }
+              *reinterpret_cast<float4*>(crow + (long)m * P.S) = v;
+            }
+          }
+          __syncthreads();
+        }
+        return;
+      }
+    }
     // Flattened-column epilogues: n -> (sample b, position s).  The per-row bias and
     // the per-(sample,row) vector dj of the few samples a tile's columns span are
     // staged in LDS once, instead of one dependent global load per element.
