@@ -175,6 +175,20 @@ struct LstmStepSide {
 };
 struct LstmStepParams { int n, B, R; LstmStepSide s[2]; };
 hipError_t lstm_step_fused(hipStream_t st, int order, const LstmStepParams& P);
+// The 2-layer encoder's whole wavefront (TL + 1 steps of the same tiles) in one persistent launch with
+// a grid barrier per step (lstm_fused.hip).  Tensors are time-major [t][B][..]; slot 0 of h1/c1/h2/c2
+// holds the zero initial state; G1 holds layer 1's input projection (+ both biases) and receives the
+// activated gates.  flags: >= enc_persist_workgroups(B, R) words, zeroed once; epoch0: a number that
+// grows by at least TL + 1 from launch to launch; *err is set if a barrier timed out.
+struct EncPersistParams {
+  int B, R, TL;
+  float *G1, *G2, *h1, *c1, *tc1, *x2, *h2, *c2, *tc2;
+  const float *Wh1, *Wi2, *Wh2, *bi2, *bh2;
+  const uint32_t* mask; float mscale;
+  unsigned* flags; unsigned epoch0; int nwg; int* err;
+};
+int enc_persist_workgroups(int B, int R);
+hipError_t lstm_enc_persist(hipStream_t st, int order, EncPersistParams Q);
 struct LstmBwdCell {
   const float* gates; const float* c_prev; long cp_rs; const float* tanhc;
   const float* slabA; int nA;     // recurrent dh partials [nB,R]

@@ -128,6 +128,14 @@ struct rau_ctx {
   float* att_part = nullptr;  // [B][chunks][S] partial column sums of the split attention kernels
   bool att_split_env = false; // RAU_ATT_SPLIT: 4-wave row-chunk attention kernels instead of the fused ones
   bool enc_fused_env = false; // RAU_ENC_FUSED: fused GEMM + cell launch per encoder step also in training
+  // persistent encoder forward (lstm_enc_persist): per-workgroup barrier flags, the epoch the next launch
+  // starts from, a device error word (a barrier timed out) copied to pinned memory behind the launch
+  bool enc_persist = false;
+  unsigned* pflags = nullptr;
+  unsigned pepoch = 0;
+  int* perr_d = nullptr;
+  int* perr_h = nullptr;
+  bool persist_used = false;
   float* hopw_h = nullptr;    // pinned staging of the hop weights, 2 slots of H
   int hopw_slot = 0;
   // backward temporaries

@@ -380,6 +380,17 @@ int rau_create(const rau_config* cfg, rau_ctx** out) {
   ctx->att_split_env = std::getenv("RAU_ATT_SPLIT") != nullptr ||
                        (c.B <= 64 && std::getenv("RAU_ATT_FUSED") == nullptr);
   ctx->enc_fused_env = std::getenv("RAU_ENC_FUSED") != nullptr;
+  ctx->enc_persist = std::getenv("RAU_ENC_PERSIST") != nullptr;
+  {
+    float* f = nullptr;
+    CK(dalloc(ctx, &f, (size_t)enc_persist_workgroups(B, Rq) + 1));   // zero-filled
+    ctx->pflags = reinterpret_cast<unsigned*>(f);
+    ctx->perr_d = reinterpret_cast<int*>(f) + enc_persist_workgroups(B, Rq);
+    if (hipHostMalloc(reinterpret_cast<void**>(&ctx->perr_h), sizeof(int), hipHostMallocDefault) != hipSuccess)
+      ctx->perr_h = nullptr;
+    else
+      *ctx->perr_h = 0;
+  }
   CK(dalloc(ctx, &ctx->a, HB * S));
   CK(dalloc(ctx, &ctx->jv, (size_t)B * M));
   CK(dalloc(ctx, &ctx->j, HB * M));
@@ -500,6 +511,7 @@ void rau_destroy(rau_ctx* ctx) {
     if (e) hipEventDestroy(e);
   if (ctx->st3) hipStreamDestroy(ctx->st3);
   if (ctx->st2b) { hipStreamSynchronize(ctx->st2b); hipStreamDestroy(ctx->st2b); }
+  if (ctx->perr_h) hipHostFree(ctx->perr_h);
   if (ctx->evP) hipEventDestroy(ctx->evP);
   if (ctx->evJ) hipEventDestroy(ctx->evJ);
   for (hipEvent_t e : ctx->evF) hipEventDestroy(e);
@@ -1058,7 +1070,21 @@ int rau_forward(rau_ctx* ctx) {
       RUN("enc_i2h_gemm", gflop(rows, 4 * Rq, E), 0,
           gemm_nt(st, rows, 4 * Rq, E, ctx->we, E, ctx->i2h[0].W, E, ctx->G1, 4 * Rq, o));
     }
-    if (ctx->enc_fused_env || ctx->mode == RAU_MODE_EVAL) {
+    if (ctx->enc_persist && !ctx->capturing && ctx->perr_h) {
+      // the whole wavefront in one persistent launch (a captured graph would replay a stale epoch)
+      EncPersistParams q{};
+      q.B = B; q.R = Rq; q.TL = TL;
+      q.G1 = ctx->G1; q.G2 = ctx->G2; q.h1 = ctx->h1; q.c1 = ctx->c1; q.tc1 = ctx->tc1; q.x2 = ctx->x2;
+      q.h2 = ctx->h2; q.c2 = ctx->c2; q.tc2 = ctx->tc2;
+      q.Wh1 = ctx->h2h[0].W; q.Wi2 = ctx->i2h[1].W; q.Wh2 = ctx->h2h[1].W;
+      q.bi2 = ctx->i2h[1].b; q.bh2 = ctx->h2h[1].b;
+      q.mask = m_rnn; q.mscale = sc(RAU_MASK_RNN);
+      q.flags = ctx->pflags; q.epoch0 = ctx->pepoch; q.err = ctx->perr_d;
+      ctx->pepoch += (unsigned)TL + 2;
+      RUN("enc_persist", (double)TL * 3 * gflop(B, 4 * Rq, Rq), 0, lstm_enc_persist(st, GATES_DEEP, q));
+      HIPC(hipMemcpyAsync(ctx->perr_h, ctx->perr_d, sizeof(int), hipMemcpyDeviceToHost, st));
+      ctx->persist_used = true;
+    } else if (ctx->enc_fused_env || ctx->mode == RAU_MODE_EVAL) {
       // one launch per wavefront step: gate GEMM + cell fused (lstm_fused.hip)
       for (int s = 1; s <= TL + 1; ++s) {
         LstmStepParams sp{};
@@ -1652,6 +1678,9 @@ int rau_wait_grads(rau_ctx* ctx, int group, void* hip_stream) {
 int rau_sync(rau_ctx* ctx) {
   NEED(ctx, "null ctx");
   HIPC(hipStreamSynchronize(ctx->st));
+  if (ctx->persist_used && ctx->perr_h && *ctx->perr_h)
+    return fail(RAU_ERR_DEVICE, "persistent encoder: a grid barrier timed out (results of that step are "
+                                "invalid; unset RAU_ENC_PERSIST)");
   return RAU_OK;
 }
 static int d2h(rau_ctx* ctx, void* host, const void* dev, size_t bytes) {
