@@ -178,7 +178,7 @@ hipError_t lstm_step_fused(hipStream_t st, int order, const LstmStepParams& P);
 // The 2-layer encoder's whole wavefront (TL + 1 steps of the same tiles) in one persistent launch with
 // a grid barrier per step (lstm_fused.hip).  Tensors are time-major [t][B][..]; slot 0 of h1/c1/h2/c2
 // holds the zero initial state; G1 holds layer 1's input projection (+ both biases) and receives the
-// activated gates.  flags: >= enc_persist_workgroups(B, R) words, zeroed once; epoch0: a number that
+// activated gates.  flags: >= enc_persist_workgroups(B, R) + 1 words (one per workgroup + the published epoch), zeroed once; epoch0: a number that
 // grows by at least TL + 1 from launch to launch; *err is set if a barrier timed out.
 struct EncPersistParams {
   int B, R, TL;

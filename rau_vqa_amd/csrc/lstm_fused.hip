@@ -316,16 +316,31 @@ __global__ __launch_bounds__(256) void k_enc_persist(const EncPersistParams Q) {
       const unsigned want = Q.epoch0 + (unsigned)s;
       if (threadIdx.x == 0)
         __hip_atomic_store(Q.flags + me, want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      // two levels: workgroup 0 watches every flag and publishes the epoch in one word the others poll
+      // (each poll is an L2-bypassing load: 384 workgroups reading 384 flags each would keep the fabric
+      // busy beside the conv GEMMs)
+      unsigned* go = Q.flags + Q.nwg;
       int spins = 0;
-      for (;;) {
-        bool ok = true;
-        for (int i = threadIdx.x; i < Q.nwg; i += 64)
-          ok &= (int)(__hip_atomic_load(Q.flags + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want) >= 0;
-        if (__all(ok)) break;
-        __builtin_amdgcn_s_sleep(2);
-        if (++spins > kSpinMax) {                // every wave still reaches the end of the kernel
-          if (threadIdx.x == 0) *Q.err = 1;
-          break;
+      if (me == 0) {
+        for (;;) {
+          bool ok = true;
+          for (int i = threadIdx.x; i < Q.nwg; i += 64)
+            ok &= (int)(__hip_atomic_load(Q.flags + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want) >= 0;
+          if (__all(ok)) break;
+          __builtin_amdgcn_s_sleep(2);
+          if (++spins > kSpinMax) {              // every wave still reaches the end of the kernel
+            if (threadIdx.x == 0) *Q.err = 1;
+            break;
+          }
+        }
+        if (threadIdx.x == 0) __hip_atomic_store(go, want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } else {
+        while ((int)(__hip_atomic_load(go, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want) < 0) {
+          __builtin_amdgcn_s_sleep(8);
+          if (++spins > kSpinMax) {
+            if (threadIdx.x == 0) *Q.err = 1;
+            break;
+          }
         }
       }
     }

@@ -383,9 +383,9 @@ int rau_create(const rau_config* cfg, rau_ctx** out) {
   ctx->enc_persist = std::getenv("RAU_ENC_PERSIST") != nullptr;
   {
     float* f = nullptr;
-    CK(dalloc(ctx, &f, (size_t)enc_persist_workgroups(B, Rq) + 1));   // zero-filled
+    CK(dalloc(ctx, &f, (size_t)enc_persist_workgroups(B, Rq) + 2));   // zero-filled: flags, go word, error word
     ctx->pflags = reinterpret_cast<unsigned*>(f);
-    ctx->perr_d = reinterpret_cast<int*>(f) + enc_persist_workgroups(B, Rq);
+    ctx->perr_d = reinterpret_cast<int*>(f) + enc_persist_workgroups(B, Rq) + 1;
     if (hipHostMalloc(reinterpret_cast<void**>(&ctx->perr_h), sizeof(int), hipHostMallocDefault) != hipSuccess)
       ctx->perr_h = nullptr;
     else
