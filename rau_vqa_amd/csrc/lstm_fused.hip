@@ -309,8 +309,9 @@ __global__ __launch_bounds__(256) void k_enc_persist(const EncPersistParams Q) {
     }
     if (active) step_tile<ORDER, true>(P, C, Ws, ut, rt);
     if (s == Q.TL + 1) break;                    // nothing in this launch reads the last step's outputs
-    // ---- grid barrier
+    // ---- grid barrier (at normal wave priority: waiting waves must not crowd out the conv GEMMs' waves)
     __builtin_amdgcn_s_waitcnt(0);               // this wave's stores have been acknowledged
+    __builtin_amdgcn_s_setprio(0);
     __syncthreads();
     if (threadIdx.x < 64) {
       const unsigned want = Q.epoch0 + (unsigned)s;
@@ -345,6 +346,7 @@ __global__ __launch_bounds__(256) void k_enc_persist(const EncPersistParams Q) {
       }
     }
     __syncthreads();
+    RAU_CHAIN_PRIO();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // drop stale h1 / x2 / h2 lines (L2 and L1)
   }
 }
