@@ -91,6 +91,12 @@ hipError_t conv_sample(hipStream_t st, int epi, int nB, int M, int K, int S, con
                        long w_rs, const float* X, long x_bs, float* C, long c_bs,
                        const float* bias, int act, const float* dj, const float* av,
                        const float* Y = nullptr, float* rs = nullptr, int c16 = 0);
+// Wide tiling for 14 x 14 maps (conv_wide.hip, round 3): 64 rows x four whole samples per tile,
+// operands staged by LDS-DMA; epi 0 / 2 as conv_sample's.  nB must be a multiple of 4.
+bool conv_wide_ok(int M, int K, int S, long w_rs);
+hipError_t conv_wide(hipStream_t st, int epi, int nB, int M, int K, int S, const float* Wt, long w_rs,
+                     const float* X, long x_bs, float* C, long c_bs, const float* bias, int act,
+                     const float* dj, const float* av, const float* Y, float* rs, int c16, int per_cu);
 // out[c][r] = in[r][c]  (rows x cols -> cols x rows); used once per step on the two
 // 1x1-conv weights so the forward conv GEMMs get a row-contiguous A operand
 hipError_t transpose2d(hipStream_t st, int rows, int cols, const float* in, float* out,

@@ -1,0 +1,145 @@
+// convbench.hip -- stand-alone check + timing of the wide-tile conv kernels (conv_wide.hip) against
+// the round-2 tilings (gemm_conv.hip / gemm_sample.hip) on random data.  Development tool.
+//   ./convbench [B] [what]      what: fwd | pre | dz | d2048 | all (default)
+// Prints, per shape: bitwise agreement with the old kernel, avg us and TFLOP/s of both.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <vector>
+#include "../rau_vqa_amd/csrc/kernels.h"
+using namespace rau;
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1);} } while (0)
+
+static float* dev_rand(size_t n, float scale = 1.f, bool nonneg = false) {
+  std::vector<float> h(n);
+  for (size_t i = 0; i < n; ++i) {
+    float v = (rand() % 2001) / 1000.f - 1.f;
+    if (nonneg) v = v < 0 ? 0.f : 2.f * v;      // half of the elements dropped, the rest doubled
+    h[i] = scale * v;
+  }
+  float* d; CK(hipMalloc(&d, n * 4)); CK(hipMemcpy(d, h.data(), n * 4, hipMemcpyHostToDevice));
+  return d;
+}
+static double timeit(hipStream_t st, int iters, const std::function<hipError_t()>& f) {
+  hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+  for (int i = 0; i < 3; ++i) CK(f());
+  CK(hipStreamSynchronize(st));
+  CK(hipEventRecord(a, st));
+  for (int i = 0; i < iters; ++i) CK(f());
+  CK(hipEventRecord(b, st));
+  CK(hipEventSynchronize(b));
+  float ms; CK(hipEventElapsedTime(&ms, a, b));
+  return ms * 1e3 / iters;
+}
+static void report(const char* name, double us, double flops) {
+  printf("  %-34s %9.1f us  %7.1f TFLOP/s (%.3f of 157.3)\n", name, us, flops / us / 1e6,
+         flops / us / 1e6 / 157.3);
+  fflush(stdout);
+}
+static void compare(const char* what, const float* a, const float* b, size_t n) {
+  std::vector<float> ha(n), hb(n);
+  CK(hipMemcpy(ha.data(), a, n * 4, hipMemcpyDeviceToHost));
+  CK(hipMemcpy(hb.data(), b, n * 4, hipMemcpyDeviceToHost));
+  size_t nd = 0; double md = 0, mx = 0;
+  for (size_t i = 0; i < n; ++i) {
+    if (memcmp(&ha[i], &hb[i], 4)) ++nd;
+    double d = fabs((double)ha[i] - hb[i]); if (d > md) md = d;
+    if (fabs(hb[i]) > mx) mx = fabs(hb[i]);
+  }
+  printf("  %-34s %zu of %zu words differ, max |diff| %.3g (max |ref| %.3g)%s\n", what, nd, n, md, mx,
+         nd == 0 ? "  BITWISE OK" : (md <= 1e-5 * mx ? "  close" : "  MISMATCH"));
+  fflush(stdout);
+}
+
+int main(int argc, char** argv) {
+  const int B = argc > 1 ? atoi(argv[1]) : 256;
+  const char* what = argc > 2 ? argv[2] : "all";
+  auto want = [&](const char* w) { return !strcmp(what, "all") || !strcmp(what, w); };
+  const int S = 196, M = 512, A = 256;
+  hipStream_t st; CK(hipStreamCreate(&st));
+  srand(1234);
+
+  for (int D : {512, 2048}) {
+    if (D == 512 && !want("fwd")) continue;
+    if (D == 2048 && !want("d2048")) continue;
+    for (int nh : {1, 2}) {
+      const int nB = nh * B;
+      printf("conv_embed_fwd  D=%d  nB=%d (M=%d, tanh)\n", D, nB, M);
+      float* X = dev_rand((size_t)nB * D * S, 0.5f, true);
+      float* WiT = dev_rand((size_t)D * M, 0.08f), *bi = dev_rand(M, 0.08f);
+      float *I0, *I1; CK(hipMalloc(&I0, (size_t)nB * M * S * 4)); CK(hipMalloc(&I1, (size_t)nB * M * S * 4));
+      CK(hipMemset(I0, 0xff, (size_t)nB * M * S * 4)); CK(hipMemset(I1, 0xee, (size_t)nB * M * S * 4));
+      const double fl = 2.0 * M * (double)nB * S * D;
+      CK(conv_embed_fwd(st, nB, D, S, M, X, WiT, bi, I0, 0, 0));
+      CK(conv_wide(st, 0, nB, M, D, S, WiT, M, X, (long)D * S, I1, (long)M * S, bi, 1, nullptr, nullptr, nullptr, nullptr, 0, 2));
+      CK(hipStreamSynchronize(st));
+      compare("wide(2/CU) vs round-2 kernel", I1, I0, (size_t)nB * M * S);
+      CK(hipMemset(I1, 0xee, (size_t)nB * M * S * 4));
+      CK(conv_wide(st, 0, nB, M, D, S, WiT, M, X, (long)D * S, I1, (long)M * S, bi, 1, nullptr, nullptr, nullptr, nullptr, 0, 1));
+      CK(hipStreamSynchronize(st));
+      compare("wide(1/CU) vs round-2 kernel", I1, I0, (size_t)nB * M * S);
+      for (int rep = 0; rep < 2; ++rep) {
+        report("round-2 flattened 128x128", timeit(st, 10, [&] { return conv_embed_fwd(st, nB, D, S, M, X, WiT, bi, I0, 0, 0); }), fl);
+        report("round-2 per-sample 128x208", timeit(st, 10, [&] { return conv_sample(st, 0, nB, M, D, S, WiT, M, X, (long)D * S, I0, (long)M * S, bi, 1, nullptr, nullptr); }), fl);
+        report("wide 64x784, 2 per CU", timeit(st, 10, [&] { return conv_wide(st, 0, nB, M, D, S, WiT, M, X, (long)D * S, I1, (long)M * S, bi, 1, nullptr, nullptr, nullptr, nullptr, 0, 2); }), fl);
+        report("wide 64x784, 1 per CU", timeit(st, 10, [&] { return conv_wide(st, 0, nB, M, D, S, WiT, M, X, (long)D * S, I1, (long)M * S, bi, 1, nullptr, nullptr, nullptr, nullptr, 0, 1); }), fl);
+      }
+      CK(hipFree(X)); CK(hipFree(WiT)); CK(hipFree(bi)); CK(hipFree(I0)); CK(hipFree(I1));
+    }
+  }
+
+  if (want("pre")) {
+    for (int nh : {1, 2}) {
+      const int nB = nh * B;
+      printf("conv_att_pre  nB=%d (A=%d rows, K=%d)\n", nB, A, M);
+      float* I = dev_rand((size_t)nB * M * S, 0.9f);
+      float* WpT = dev_rand((size_t)M * A, 0.08f), *bp = dev_rand(A, 0.08f);
+      float *P0, *P1; CK(hipMalloc(&P0, (size_t)nB * A * S * 4)); CK(hipMalloc(&P1, (size_t)nB * A * S * 4));
+      CK(hipMemset(P0, 0xff, (size_t)nB * A * S * 4)); CK(hipMemset(P1, 0xee, (size_t)nB * A * S * 4));
+      const double fl = 2.0 * A * (double)nB * S * M;
+      CK(conv_att_pre(st, nB, M, S, A, I, WpT, bp, P0, 0, 0));
+      CK(conv_wide(st, 0, nB, A, M, S, WpT, A, I, (long)M * S, P1, (long)A * S, bp, 0, nullptr, nullptr, nullptr, nullptr, 0, 2));
+      CK(hipStreamSynchronize(st));
+      compare("wide vs round-2 kernel", P1, P0, (size_t)nB * A * S);
+      for (int rep = 0; rep < 2; ++rep) {
+        report("round-2 flattened 128x128", timeit(st, 10, [&] { return conv_att_pre(st, nB, M, S, A, I, WpT, bp, P0, 0, 0); }), fl);
+        report("wide 64x784, 2 per CU", timeit(st, 10, [&] { return conv_wide(st, 0, nB, A, M, S, WpT, A, I, (long)M * S, P1, (long)A * S, bp, 0, nullptr, nullptr, nullptr, nullptr, 0, 2); }), fl);
+        report("wide 64x784, 1 per CU", timeit(st, 10, [&] { return conv_wide(st, 0, nB, A, M, S, WpT, A, I, (long)M * S, P1, (long)A * S, bp, 0, nullptr, nullptr, nullptr, nullptr, 0, 1); }), fl);
+      }
+      CK(hipFree(I)); CK(hipFree(WpT)); CK(hipFree(bp)); CK(hipFree(P0)); CK(hipFree(P1));
+    }
+  }
+
+  if (want("dz")) {
+    for (int nh : {1, 2}) {
+      const int nB = nh * B;
+      printf("conv_att_dgrad_dz  nB=%d (M=%d rows, K=%d)\n", nB, M, A);
+      float* dS = dev_rand((size_t)nB * A * S, 0.01f);
+      float* Wp = dev_rand((size_t)A * M, 0.08f);
+      float* dj = dev_rand((size_t)nB * M, 0.01f), *av = dev_rand((size_t)nB * S, 0.01f);
+      float* I = dev_rand((size_t)nB * M * S, 0.9f);
+      float *Z0, *Z1, *r0, *r1;
+      CK(hipMalloc(&Z0, (size_t)nB * M * S * 4)); CK(hipMalloc(&Z1, (size_t)nB * M * S * 4));
+      CK(hipMalloc(&r0, (size_t)nB * M * 4)); CK(hipMalloc(&r1, (size_t)nB * M * 4));
+      CK(hipMemset(Z0, 0xff, (size_t)nB * M * S * 4)); CK(hipMemset(Z1, 0xee, (size_t)nB * M * S * 4));
+      const double fl = 2.0 * M * (double)nB * S * A;
+      CK(conv_sample(st, 2, nB, M, A, S, Wp, M, dS, (long)A * S, Z0, (long)M * S, nullptr, 0, dj, av, I, r0, 0));
+      CK(conv_wide(st, 2, nB, M, A, S, Wp, M, dS, (long)A * S, Z1, (long)M * S, nullptr, 0, dj, av, I, r1, 0, 2));
+      CK(hipStreamSynchronize(st));
+      compare("dZ: wide vs round-2 per-sample", Z1, Z0, (size_t)nB * M * S);
+      compare("row sums", r1, r0, (size_t)nB * M);
+      for (int rep = 0; rep < 2; ++rep) {
+        report("round-2 per-sample 128x208", timeit(st, 10, [&] { return conv_sample(st, 2, nB, M, A, S, Wp, M, dS, (long)A * S, Z0, (long)M * S, nullptr, 0, dj, av, I, r0, 0); }), fl);
+        report("wide 64x784, 2 per CU", timeit(st, 10, [&] { return conv_wide(st, 2, nB, M, A, S, Wp, M, dS, (long)A * S, Z1, (long)M * S, nullptr, 0, dj, av, I, r1, 0, 2); }), fl);
+        report("wide 64x784, 1 per CU", timeit(st, 10, [&] { return conv_wide(st, 2, nB, M, A, S, Wp, M, dS, (long)A * S, Z1, (long)M * S, nullptr, 0, dj, av, I, r1, 0, 1); }), fl);
+      }
+      CK(hipFree(dS)); CK(hipFree(Wp)); CK(hipFree(dj)); CK(hipFree(av)); CK(hipFree(I));
+      CK(hipFree(Z0)); CK(hipFree(Z1)); CK(hipFree(r0)); CK(hipFree(r1));
+    }
+  }
+  printf("done\n");
+  return 0;
+}
