@@ -124,7 +124,9 @@ __global__ __launch_bounds__(256, 2) void k_conv_wide(const WideParams P) {
   const long xstep = (long)WBK * WS * 4, wstep = (long)WBK * P.w_rs * 4;
   auto issue = [&](int n, int stage, const char* xb, const char* wb) {
     const char* base = (n == 6 && slot6_w) ? wb : xb;
-    __builtin_amdgcn_global_load_lds((glb_ptr_t)(base + voff[n]),
+    uint32_t vo = voff[n];
+    asm volatile("" : "+v"(vo));   // keep the per-lane offset 32 bits wide (hipcc otherwise hoists 7 zero-extended pairs)
+    __builtin_amdgcn_global_load_lds((glb_ptr_t)(base + vo),
                                      (lds_ptr_t)(smem + stage * WSTAGE + loff[n]), 16, 0, 0);
   };
 
@@ -159,9 +161,13 @@ __global__ __launch_bounds__(256, 2) void k_conv_wide(const WideParams P) {
   const uint32_t xfrag_b = lds0 + (uint32_t)xfrag * 4, wfrag_b = lds0 + (uint32_t)wfrag * 4;
   // one half-step on (xa, q); its last chunk prefetches chunk 0 of (xa_n, wa_n, q_n).
   // A0: the half-step's chunk 0 sits in fa (else fb).  DMA: issue the loads of K-step t+2.
-  auto half_step = [&](auto start_a, auto dma, auto q_tag, auto qn_tag, uint32_t xa, uint32_t xa_n,
-                       uint32_t wa_n, int st2, const char* xn, const char* wn) {
+  // LAST: the tile's final half-step requests nothing in its last chunk.  (An asm read whose result
+  // nobody uses is not harmless: hipcc sees a dead value, hands its register to the next accumulator
+  // write, and the LDS data lands in it whenever it arrives.)
+  auto half_step = [&](auto start_a, auto dma, auto last, auto q_tag, auto qn_tag, uint32_t xa,
+                       uint32_t xa_n, uint32_t wa_n, int st2, const char* xn, const char* wn) {
     constexpr bool A0 = decltype(start_a)::value, DMA = decltype(dma)::value;
+    constexpr bool LAST = decltype(last)::value;
     constexpr int Q = decltype(q_tag)::value, QN = decltype(qn_tag)::value;
     static_for<7>([&](auto c_tag) {
       constexpr int c = decltype(c_tag)::value;
@@ -171,7 +177,8 @@ __global__ __launch_bounds__(256, 2) void k_conv_wide(const WideParams P) {
       // read i of the next chunk: chunk c + 1 of this half-step, or chunk 0 of the next one
       auto rd = [&](auto i_tag) {
         constexpr int i = decltype(i_tag)::value;
-        if constexpr (c < 6) ds_read_f32<(Q * 4 * WNP + 16 * (7 * (c + 1) + i)) * 4>(fn[i], xa);
+        if constexpr (LAST && c == 6) return;
+        else if constexpr (c < 6) ds_read_f32<(Q * 4 * WNP + 16 * (7 * (c + 1) + i)) * 4>(fn[i], xa);
         else ds_read_f32<(QN * 4 * WNP + 16 * i) * 4>(fn[i], xa_n);
       };
       auto mma = [&](int i) {
@@ -192,16 +199,16 @@ __global__ __launch_bounds__(256, 2) void k_conv_wide(const WideParams P) {
       mma(2);
       __builtin_amdgcn_sched_barrier(0);
       rd(integral_constant<int, 5>{}); rd(integral_constant<int, 6>{});
-      if constexpr (c == 6) ds_read_f32<QN * 4 * WBM * 4>(wnext, wa_n);
+      if constexpr (c == 6 && !LAST) ds_read_f32<QN * 4 * WBM * 4>(wnext, wa_n);
       __builtin_amdgcn_sched_barrier(0);
       mma(3);
       if constexpr (DMA) issue(c, st2, xn, wn);
       mma(4); mma(5); mma(6);
       __builtin_amdgcn_sched_barrier(0);
     });
-    wcur = wnext;
+    if constexpr (!LAST) wcur = wnext;
   };
-  auto kstep = [&](auto dma, int stage) {
+  auto kstep = [&](auto dma, auto last, int stage) {
     int st1 = stage + 1, st2 = stage + 2;
     if (st1 >= WNST) st1 -= WNST;
     if (st2 >= WNST) st2 -= WNST;
@@ -209,10 +216,11 @@ __global__ __launch_bounds__(256, 2) void k_conv_wide(const WideParams P) {
     const uint32_t xa1 = xfrag_b + st1 * (WSTAGE * 4), wa1 = wfrag_b + st1 * (WSTAGE * 4);
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
-    half_step(std::true_type{}, std::false_type{}, I0{}, I1{}, xa, xa, wa, 0, nullptr, nullptr);
+    half_step(std::true_type{}, std::false_type{}, std::false_type{}, I0{}, I1{}, xa, xa, wa, 0, nullptr,
+              nullptr);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    half_step(std::false_type{}, dma, I1{}, I0{}, xa, xa1, wa1, st2, xk + 2 * xstep, wk + 2 * wstep);
+    half_step(std::false_type{}, dma, last, I1{}, I0{}, xa, xa1, wa1, st2, xk + 2 * xstep, wk + 2 * wstep);
     xk += xstep;
     wk += wstep;
   };
@@ -226,13 +234,12 @@ __global__ __launch_bounds__(256, 2) void k_conv_wide(const WideParams P) {
   ds_read_f32<0>(wcur, wfrag_b);
   int stage = 0;
   for (int t = 0; t + 2 < nk; ++t) {
-    kstep(std::true_type{}, stage);
+    kstep(std::true_type{}, std::false_type{}, stage);
     stage = stage + 1 == WNST ? 0 : stage + 1;
   }
-  kstep(std::false_type{}, stage);                    // K-step nk-2: nothing left to load
+  kstep(std::false_type{}, std::false_type{}, stage);   // K-step nk-2: nothing left to load
   stage = stage + 1 == WNST ? 0 : stage + 1;
-  kstep(std::false_type{}, stage);                    // K-step nk-1 (its prefetch reads a stale stage: unused)
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  kstep(std::false_type{}, std::true_type{}, stage);    // K-step nk-1: nothing left to read ahead either
 
   // ---- epilogue, straight from registers: block j, register r = C[m][position 16 j + 4 lq + r]
   const int m = m0 + 16 * w + lr;

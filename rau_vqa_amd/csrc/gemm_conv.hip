@@ -21,6 +21,20 @@ static int conv_epi_dbg() {
   return v;
 }
 
+
+// 14 x 14 maps in exact f32: the wide tiling (conv_wide.hip) takes the samples in groups of four; a
+// remainder of 1-3 samples goes to the tiling `rest` falls back to.  RAU_CONV_WIDE_PER_CU=1|2 (A/B
+// knob): workgroups of the wide kernel per CU.
+static bool wide_on(int which) {   // RAU_CONV_WIDE=<mask>: 1 i_embed forward, 2 ifeatproj forward, 4 attention dgrad
+  static const int mask = [] { const char* e = std::getenv("RAU_CONV_WIDE"); return e ? std::atoi(e) : 7; }();
+  return (mask & which) != 0;
+}
+static int wide_per_cu() {
+  static const int v = [] { const char* e = std::getenv("RAU_CONV_WIDE_PER_CU");
+                            const int x = e ? std::atoi(e) : 0; return x == 1 ? 1 : 2; }();
+  return v;
+}
+
 hipError_t conv_embed_fwd(hipStream_t st, int nB, int D, int S, int M, const float* X,
                           const float* WiT, const float* bi, float* I, int bf16, int one_per_cu) {
   GemmParams P{};
@@ -32,6 +46,14 @@ hipError_t conv_embed_fwd(hipStream_t st, int nB, int D, int S, int M, const flo
   P.C = I; P.c_bs = (long)M * S;
   P.bias = bi;
   P.act = 1;
+  if (!bf16 && wide_on(1) && conv_wide_ok(M, D, S, M) && nB >= 4) {
+    const int n4 = nB & ~3;
+    hipError_t e = conv_wide(st, 0, n4, M, D, S, WiT, M, X, (long)D * S, I, (long)M * S, bi, 1, nullptr,
+                             nullptr, nullptr, nullptr, 0, one_per_cu ? 1 : wide_per_cu());
+    if (e != hipSuccess || n4 == nB) return e;
+    return conv_embed_fwd(st, nB - n4, D, S, M, X + (size_t)n4 * D * S, WiT, bi, I + (size_t)n4 * M * S,
+                          bf16, one_per_cu);
+  }
   if (!bf16 && conv_sample_ok(S, 1))   // 14 x 14 maps: one sample per tile column block (gemm_sample.hip)
     return conv_sample(st, 0, nB, M, D, S, WiT, M, X, (long)D * S, I, (long)M * S, bi, 1, nullptr, nullptr);
   if (bf16 == 2) return launch_gemm<128, 128, BK, SRC_RC, SRC_RC_FLAT, EPI_CONV, 2>(st, P, 1);
@@ -80,6 +102,14 @@ hipError_t conv_att_pre(hipStream_t st, int nB, int M, int S, int A, const float
   P.C = Pout; P.c_bs = (long)A * S;
   P.bias = bp;
   P.act = 0;
+  if (!bf16 && wide_on(2) && conv_wide_ok(A, M, S, A) && nB >= 4) {
+    const int n4 = nB & ~3;
+    hipError_t e = conv_wide(st, 0, n4, A, M, S, WpT, A, I, (long)M * S, Pout, (long)A * S, bp, 0, nullptr,
+                             nullptr, nullptr, nullptr, 0, one_per_cu ? 1 : wide_per_cu());
+    if (e != hipSuccess || n4 == nB) return e;
+    return conv_att_pre(st, nB - n4, M, S, A, I + (size_t)n4 * M * S, WpT, bp, Pout + (size_t)n4 * A * S,
+                        bf16, one_per_cu);
+  }
   if (!bf16 && conv_sample_ok(S, 2))
     return conv_sample(st, 0, nB, A, M, S, WpT, A, I, (long)M * S, Pout, (long)A * S, bp, 0, nullptr, nullptr);
   if (bf16 == 2) return launch_gemm<128, 128, BK, SRC_RC, SRC_RC_FLAT, EPI_CONV, 2>(st, P, 1);
@@ -117,8 +147,19 @@ bool conv_dz_fused_ok(int S, int M, int bf16) {
 hipError_t conv_att_dgrad_dz(hipStream_t st, int nB, int M, int S, int A, const float* dS,
                              const float* Wp, const float* dj, const float* a, const float* I,
                              float* dZ, float* rs, int dz16) {
-  return conv_sample(st, 2, nB, M, A, S, Wp, M, dS, (long)A * S, dZ, (long)M * S, nullptr, 0, dj, a,
-                     I, rs, dz16);
+  int n4 = 0;
+  if (wide_on(4) && conv_wide_ok(M, A, S, M) && nB >= 4) {
+    n4 = nB & ~3;
+    hipError_t e = conv_wide(st, 2, n4, M, A, S, Wp, M, dS, (long)A * S, dZ, (long)M * S, nullptr, 0, dj, a,
+                             I, rs, dz16, wide_per_cu());
+    if (e != hipSuccess || n4 == nB) return e;
+  }
+  // remainder (or all of it): one sample per tile; dZ advances in its stored element size
+  float* dZr = dz16 ? reinterpret_cast<float*>(reinterpret_cast<uint16_t*>(dZ) + (size_t)n4 * M * S)
+                    : dZ + (size_t)n4 * M * S;
+  return conv_sample(st, 2, nB - n4, M, A, S, Wp, M, dS + (size_t)n4 * A * S, (long)A * S, dZr, (long)M * S,
+                     nullptr, 0, dj + (size_t)n4 * M, a + (size_t)n4 * S, I + (size_t)n4 * M * S,
+                     rs + (size_t)n4 * M, dz16);
 }
 
 // dX'[b,d,s] = sum_m Wi[m,d] dZ[b,m,s]: gradient w.r.t. i_embed's (dropped-out) input.  The
