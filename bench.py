@@ -164,6 +164,12 @@ def main():
             raise SystemExit(f"--global-batch {args.global_batch} not divisible by {world} ranks")
         args.batch = args.global_batch // world
 
+    if args.graph:
+        # ROCm 7.2's graph executor spreads a captured graph's branches over its own queues; with its
+        # default the three-stream step replays 1.5-2x slower than the eager calls, with two queues
+        # within 9-13 %.  The runtime reads this at its first HIP call, so it
+        # is set here, for this process only, before torch / librau.so are loaded.
+        os.environ.setdefault("DEBUG_HIP_FORCE_GRAPH_QUEUES", "2")
     import torch  # before librau.so, so both share one HIP runtime
     import torch.distributed as dist
     from rau_vqa_amd import synth

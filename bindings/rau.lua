@@ -69,6 +69,12 @@ int rau_dev_fill(rau_ctx* ctx, float* dst, size_t n, float value);
 int rau_dev_copy(rau_ctx* ctx, float* dst, const float* src, size_t n);
 int rau_dev_axpy(rau_ctx* ctx, float* y, const float* x, size_t n, float alpha);
 int rau_dev_scale(rau_ctx* ctx, float* x, size_t n, float alpha);
+int rau_dev_addcmul(rau_ctx* ctx, float* y, float alpha, const float* x1, const float* x2, size_t n);
+int rau_dev_addcdiv(rau_ctx* ctx, float* y, float alpha, const float* x1, const float* x2, size_t n);
+int rau_dev_sqrt(rau_ctx* ctx, float* x, size_t n);
+int rau_dev_add_scalar(rau_ctx* ctx, float* x, size_t n, float value);
+int rau_dev_adam(rau_ctx* ctx, float* x, const float* dx, float* m, float* v, size_t n, float lr,
+                 float beta1, float beta2, float eps, int32_t t);
 int rau_dev_select_rows(rau_ctx* ctx, float* dst, const float* src, int32_t rows, int32_t cols,
                         const int32_t* key_dev, int32_t value);
 int rau_dev_rowmax(rau_ctx* ctx, const float* x, int32_t rows, int32_t cols, float* max_dev,
@@ -122,7 +128,11 @@ function RAU.new(opt)
   for k, v in pairs(opt) do cfg[0][k] = v end
   local h = ffi.new('rau_ctx*[1]')
   check(C.rau_create(cfg, h))
-  local self = setmetatable({ h = ffi.gc(h[0], C.rau_destroy), cfg = cfg[0] }, RAU)
+  -- `life.alive` is what device-tensor finalizers look at: the collector may run them after the
+  -- context's own finalizer, and rau_destroy has then freed their memory already
+  local life = { alive = true }
+  local self = setmetatable({ h = ffi.gc(h[0], function(p) life.alive = false; C.rau_destroy(p) end),
+                              cfg = cfg[0], life = life, scratch = {} }, RAU)
   return self
 end
 
@@ -202,6 +212,22 @@ function RAU:allreduceGrads() check(C.rau_allreduce_grads(self.h)) end
 local Tensor = {}
 local IntTensor = {}
 local function numel(sz) local n = 1; for _, v in ipairs(sz) do n = n * v end; return n end
+-- Owned device memory is returned to the context when its tensor is collected (or by :free());
+-- the finalizer sits on the pointer cdata, so views (which copy the address, not the cdata) never
+-- free anything.
+local function dev_alloc(rau, n)
+  local p = ffi.new('float*[1]')
+  check(C.rau_dev_alloc(rau.h, n, p))
+  local h, life = rau.h, rau.life
+  return ffi.gc(p[0], function(q) if life.alive then C.rau_dev_free(h, q) end end)
+end
+local function dev_release(t)
+  if t.owned then
+    local q = ffi.gc(t.ptr, nil)
+    t.owned = false
+    if t.rau.life.alive then check(C.rau_dev_free(t.rau.h, ffi.cast('float*', q))) end
+  end
+end
 local function ptr_of(x) if type(x) == 'table' then return x.ptr end; return x end
 
 Tensor.__index = function(t, k)
@@ -216,9 +242,7 @@ function Tensor.wrap(rau, ptr, ...)
 end
 function Tensor.new(rau, ...)                                  -- zero-filled, like torch.zeros
   local sz = { ... }
-  local p = ffi.new('float*[1]')
-  check(C.rau_dev_alloc(rau.h, numel(sz), p))
-  return setmetatable({ rau = rau, ptr = p[0], size = sz, owned = true }, Tensor)
+  return setmetatable({ rau = rau, ptr = dev_alloc(rau, numel(sz)), size = sz, owned = true }, Tensor)
 end
 function Tensor:nElement() return numel(self.size) end
 function Tensor:dim() return #self.size end
@@ -239,12 +263,23 @@ function Tensor:copy(src)                                      -- device tensor 
   return self
 end
 function Tensor:clone() return Tensor.new(self.rau, unpack(self.size)):copy(self) end
-function Tensor:add(a, x)                                      -- :add(x) or :add(alpha, x)
+function Tensor:add(a, x)                                      -- :add(x), :add(alpha, x) or :add(scalar)
+  if x == nil and type(a) == 'number' then
+    check(C.rau_dev_add_scalar(self.rau.h, self.ptr, self:nElement(), a)); return self
+  end
   if x == nil then a, x = 1, a end
   assert(x:nElement() == self:nElement(), 'size mismatch')
   check(C.rau_dev_axpy(self.rau.h, self.ptr, x.ptr, self:nElement(), a)); return self
 end
 function Tensor:mul(a) check(C.rau_dev_scale(self.rau.h, self.ptr, self:nElement(), a)); return self end
+-- what utils/optim_updates.lua's adam() does to its flat vectors (lines 76-86)
+function Tensor:addcmul(a, x1, x2)                             -- self += a * x1 * x2
+  check(C.rau_dev_addcmul(self.rau.h, self.ptr, a, x1.ptr, x2.ptr, self:nElement())); return self
+end
+function Tensor:addcdiv(a, x1, x2)                             -- self += a * x1 / x2
+  check(C.rau_dev_addcdiv(self.rau.h, self.ptr, a, x1.ptr, x2.ptr, self:nElement())); return self
+end
+function Tensor:sqrt() check(C.rau_dev_sqrt(self.rau.h, self.ptr, self:nElement())); return self end
 function Tensor:div(a) return self:mul(1 / a) end
 function Tensor:sum()
   local o = ffi.new('double[1]')
@@ -255,8 +290,17 @@ function Tensor:mean() return self:sum() / self:nElement() end
 function Tensor:max(dim)
   assert(dim == 2 and #self.size == 2, 'only max over dimension 2 of a matrix')
   local r, c = self.size[1], self.size[2]
-  local v = Tensor.new(self.rau, r, 1)
-  local i = IntTensor.new(self.rau, r, 1)
+  -- results live in a ring of four context-owned slots per row count (feval calls this once per
+  -- hop per iteration, SS:488: no allocation on that path); like self.output they stay valid
+  -- until the slot comes round again
+  local ring = self.rau.scratch[r]
+  if not ring then
+    ring = { k = 0 }
+    for s = 1, 4 do ring[s] = { Tensor.new(self.rau, r, 1), IntTensor.new(self.rau, r, 1) } end
+    self.rau.scratch[r] = ring
+  end
+  ring.k = ring.k % 4 + 1
+  local v, i = ring[ring.k][1], ring[ring.k][2]
   check(C.rau_dev_rowmax(self.rau.h, self.ptr, r, c, v.ptr, i.ptr))
   return v, i
 end
@@ -271,14 +315,22 @@ function Tensor:float()                                        -- host copy (tor
   local t = torch.FloatTensor(unpack(self.size))
   check(C.rau_dev_download(self.rau.h, t:data(), self.ptr, self:nElement() * 4)); return t
 end
-function Tensor:free() if self.owned then check(C.rau_dev_free(self.rau.h, self.ptr)); self.owned = false end end
+function Tensor:free() dev_release(self) end
 
 IntTensor.__index = IntTensor
 function IntTensor.new(rau, ...)
   local sz = { ... }
-  local p = ffi.new('float*[1]')
-  check(C.rau_dev_alloc(rau.h, numel(sz), p))                  -- 4-byte elements either way
-  return setmetatable({ rau = rau, ptr = ffi.cast('int32_t*', p[0]), size = sz }, IntTensor)
+  local base = dev_alloc(rau, numel(sz))                       -- 4-byte elements either way
+  -- `base` carries the finalizer; the int32 view of it is what the calls take
+  return setmetatable({ rau = rau, base = base, ptr = ffi.cast('int32_t*', base), size = sz,
+                        owned = true }, IntTensor)
+end
+function IntTensor:free()
+  if self.owned then
+    local t = { rau = self.rau, ptr = self.base, owned = true }
+    self.owned = false
+    dev_release(t)
+  end
 end
 function IntTensor:copy(src)                                   -- host IntTensor -> device
   check(C.rau_dev_upload(self.rau.h, self.ptr, src:data(), numel(self.size) * 4)); return self
@@ -298,16 +350,38 @@ function RAU:ints(host) return IntTensor.new(self, host:nElement()):copy(host) e
 
 -- nn.Module surface completeness: parameters live on the device from the start and the clones
 -- share them by construction, so these are identities (SS:319, 340-346); updateParameters is
--- never called by the reference (updates go through adam on the flat vectors, SS:770-772) and
--- maps to plain SGD on the fused update for hosts that do call it.
+-- never called by the reference (updates go through adam on the flat vectors, SS:770-772); for
+-- hosts that do call it, it is nn.Module's plain SGD step x = x - lr * dx on all three groups.
 function RAU:cuda() return self end
 function RAU:clone() return self end
 function RAU:float() return self end
-function RAU:updateParameters(lr) self:update(0, lr, lr, 0, 0.55, 1e30, 0) end
+function RAU:updateParameters(lr)
+  for _, g in ipairs({ 'embed', 'rnn', 'mult' }) do
+    local p = self:getParameters(g)
+    check(C.rau_dev_axpy(self.h, p.ptr, p.grad, p.n, -lr))
+  end
+end
 -- flat parameter / gradient vectors as device tensors: params, grads = rau:flat('mult')
 function RAU:flat(group)
   local p = self:getParameters(group)
   return Tensor.wrap(self, p.ptr, p.n), Tensor.wrap(self, p.grad, p.n)
+end
+
+-- adam(x, dx, lr, beta1, beta2, epsilon, state): the signature and state fields of
+-- utils/optim_updates.lua:59-87, for x, dx = rau:flat(group) -- so SS:770-772 runs unchanged.
+-- state.m / state.v are device tensors created on first use (x.new(#dx):zero() in the reference),
+-- state.t counts calls; the five tensor statements run as one pass (rau_dev_adam).  No state.tmp:
+-- sqrt(v) + epsilon never leaves registers.
+function RAU.adam(x, dx, lr, beta1, beta2, epsilon, state)
+  beta1, beta2, epsilon = beta1 or 0.9, beta2 or 0.999, epsilon or 1e-8
+  if not state.m then
+    state.t = 0
+    state.m = Tensor.new(x.rau, x:nElement())
+    state.v = Tensor.new(x.rau, x:nElement())
+  end
+  state.t = state.t + 1
+  check(C.rau_dev_adam(x.rau.h, x.ptr, dx.ptr, state.m.ptr, state.v.ptr, x:nElement(), lr, beta1, beta2,
+                       epsilon, state.t))
 end
 
 -- Module-level clones ---------------------------------------------------------

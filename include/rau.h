@@ -190,7 +190,7 @@ int rau_backward(rau_ctx* ctx, const float* hop_w /* [H] host */);
  * Ids in DEVICE tensors (tokens_dev here, labels_dev of rau_criterion_*) cannot be range-checked
  * by the call: the kernels clamp them into [1, V] / [1, K], so a bad id uses a wrong row where
  * the reference's LookupTable / ClassNLLCriterion would raise -- it never faults the GPU.  (The
- * host arrays of rau_set_batch ARE checked and rejected with RAU_ERR_ARG.) */
+ * host arrays of rau_set_batch ARE checked and rejected with RAU_ERR_INVALID.) */
 int rau_embed_forward(rau_ctx* ctx, int t, const int32_t* tokens_dev, float** we /* [B,E] */);
 int rau_embed_backward(rau_ctx* ctx, int t, const int32_t* tokens_dev, const float* d_we);
 
@@ -241,6 +241,17 @@ int rau_dev_fill(rau_ctx* ctx, float* dst, size_t n, float value);
 int rau_dev_copy(rau_ctx* ctx, float* dst, const float* src, size_t n);
 int rau_dev_axpy(rau_ctx* ctx, float* y, const float* x, size_t n, float alpha);   /* y += alpha x */
 int rau_dev_scale(rau_ctx* ctx, float* x, size_t n, float alpha);
+/* The tensor statements of the reference's optimizer call, `adam(x, dx, lr, beta1, beta2, epsilon,
+ * state)` on each flat vector (SS:770-772, utils/optim_updates.lua:59-87): y += alpha x1 x2,
+ * y += alpha x1 / x2, in-place sqrt, x += value -- and the whole function as one pass,
+ * rau_dev_adam: m = beta1 m + (1-beta1) dx; v = beta2 v + (1-beta2) dx^2;
+ * x -= lr sqrt(1-beta2^t)/(1-beta1^t) m / (sqrt(v) + eps), t = state.t after its increment (>= 1). */
+int rau_dev_addcmul(rau_ctx* ctx, float* y, float alpha, const float* x1, const float* x2, size_t n);
+int rau_dev_addcdiv(rau_ctx* ctx, float* y, float alpha, const float* x1, const float* x2, size_t n);
+int rau_dev_sqrt(rau_ctx* ctx, float* x, size_t n);
+int rau_dev_add_scalar(rau_ctx* ctx, float* x, size_t n, float value);
+int rau_dev_adam(rau_ctx* ctx, float* x, const float* dx, float* m, float* v, size_t n, float lr,
+                 float beta1, float beta2, float eps, int32_t t);
 /* dst[k,:] = src[k,:] for the rows k with key_dev[k] == value (SS:455-461, 584-591) */
 int rau_dev_select_rows(rau_ctx* ctx, float* dst, const float* src, int32_t rows, int32_t cols,
                         const int32_t* key_dev, int32_t value);

@@ -10,11 +10,9 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# rau_graph_step: ROCm 7.2's graph executor spreads a captured graph's branches over its own
-# queues; with its default the three-stream step replays 1.5-2x slower than the eager calls, with
-# two queues within 9-13 %.  The runtime reads the variable when it
-# initialises, i.e. at the first HIP call of the process, which comes after this import.
-os.environ.setdefault("DEBUG_HIP_FORCE_GRAPH_QUEUES", "2")
+# Nothing here touches the process environment.  (rau_graph_step replays fastest with the HIP runtime
+# variable DEBUG_HIP_FORCE_GRAPH_QUEUES=2; a host that wants that sets it itself
+# before its first HIP call -- `bench.py --graph` does, for its own process only.)
 # RAU_LIB overrides the library path (A/B runs of two builds on one GPU box)
 LIB_PATH = os.environ.get("RAU_LIB") or os.path.join(_HERE, "librau.so")
 CSRC = os.path.join(_HERE, "csrc")
@@ -97,6 +95,12 @@ _SIGS = {
     "rau_dev_copy": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "rau_dev_axpy": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_float]),
     "rau_dev_scale": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_float]),
+    "rau_dev_addcmul": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "rau_dev_addcdiv": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "rau_dev_sqrt": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "rau_dev_add_scalar": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_float]),
+    "rau_dev_adam": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
+                               C.c_float, C.c_float, C.c_float, C.c_float, C.c_int32]),
     "rau_dev_select_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
                                       C.c_void_p, C.c_int32]),
     "rau_dev_rowmax": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p,

@@ -139,10 +139,9 @@ hipError_t conv_att_dgrad(hipStream_t st, int nB, int M, int S, int A, const flo
 }
 
 bool conv_dz_fused_ok(int S, int M, int bf16) {
-  static const bool off = std::getenv("RAU_DZ_UNFUSED") != nullptr;   // A/B knob
   // bf16 == 1 too: the dgrad then runs on the exact-f32 per-sample kernel (K = A = 256: cheap) and
   // the i_embed weight gradient re-reads one A operand (dZ) instead of two (dI, I) per tile column
-  return !off && bf16 != 2 && M % 4 == 0 && conv_sample_ok(S, 4);
+  return bf16 != 2 && M % 4 == 0 && conv_sample_ok(S, 4);
 }
 hipError_t conv_att_dgrad_dz(hipStream_t st, int nB, int M, int S, int A, const float* dS,
                              const float* Wp, const float* dj, const float* a, const float* I,

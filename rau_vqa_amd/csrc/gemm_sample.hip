@@ -226,9 +226,7 @@ hipError_t conv_sample(hipStream_t st, int epi, int nB, int M, int K, int S, con
                        const float* bias, int act, const float* dj, const float* av,
                        const float* Y, float* rs, int c16) {
   if (!(S % 4 == 0 && S > 176 && S <= SBN) || M % 4 != 0) return hipErrorInvalidValue;
-  static const int rb_env = [] { const char* e = std::getenv("RAU_CONV_SAMPLE_RB");   // A/B knob
-                                 return e ? std::atoi(e) : 2; }();
-  const int rb = rb_env == 1 ? 1 : 2;
+  constexpr int rb = 2;   // 128-row tiles (64-row tiles measured slower in the step)
   SampleParams P{};
   P.M = M; P.K = K; P.S = S; P.nB = nB;
   P.tiles_m = (M + 64 * rb - 1) / (64 * rb);
@@ -239,15 +237,8 @@ hipError_t conv_sample(hipStream_t st, int epi, int nB, int M, int K, int S, con
   P.dj = dj; P.av = av;
   P.Y = Y; P.rs = rs; P.c16 = c16;
   const dim3 grid(P.tiles_m * nB), block(256);
-  // 64-row tiles: 41 KB of static LDS would let three workgroups share a CU (a ragged 2.67
-  // rounds per hop); 16 KB of unused dynamic LDS keeps it at two
-  const int dyn = rb == 1 ? 16 * 1024 : 0;
-#define LAUNCH(E, R) hipLaunchKernelGGL((k_conv_sample<E, R>), grid, block, dyn, st, P)
-  if (rb == 1) {
-    if (epi == 0) LAUNCH(0, 1); else if (epi == 1) LAUNCH(1, 1); else LAUNCH(2, 1);
-  } else {
-    if (epi == 0) LAUNCH(0, 2); else if (epi == 1) LAUNCH(1, 2); else LAUNCH(2, 2);
-  }
+#define LAUNCH(E, R) hipLaunchKernelGGL((k_conv_sample<E, R>), grid, block, 0, st, P)
+  if (epi == 0) LAUNCH(0, 2); else if (epi == 1) LAUNCH(1, 2); else LAUNCH(2, 2);
 #undef LAUNCH
   return hipGetLastError();
 }

@@ -75,14 +75,8 @@ struct rau_ctx {
   hipStream_t st = nullptr;    // chain stream: recurrences, small GEMMs; what callers order against
   hipStream_t st2 = nullptr;   // bulk stream: hop-batched 1x1-conv GEMMs, overlapped with the chain
   hipStream_t st3 = nullptr;   // weight-gradient stream: throughput GEMMs nobody waits for until the end
-  hipStream_t st2b = nullptr;  // second bulk stream (RAU_BULK2): alternate conv launches, so one launch's last
-                               // round of workgroups overlaps the next launch's first
-  hipEvent_t evP = nullptr, evJ = nullptr;   // st2 -> st2b fork (operands ready), st2b -> st2 join
-  int bulk2 = 0;
-  float* slab2b = nullptr;     // split-K slab of the convs launched on st2b
   hipEvent_t evA = nullptr, evD = nullptr, evW = nullptr, evE = nullptr, evW3 = nullptr,
              evM3 = nullptr, evEnd = nullptr, evE1 = nullptr, evHd = nullptr;
-  std::vector<hipEvent_t> evEc;      // encoder weight-gradient chunks
   std::vector<hipEvent_t> evH;       // per hop: forward chain done (the head stream waits on it)
   std::vector<hipEvent_t> evF, evK;  // per hop group: forward bulk done / backward chain done
   // hops per bulk launch (pipelines the bulk GEMMs with the hop loops): gsize[h] = n if hops
@@ -248,7 +242,7 @@ static inline hipEvent_t prof_event(rau_ctx* c) {
       pr_.cls = pc_;                                                                      \
       pr_.a = prof_event(ctx);                                                            \
       pr_.b = prof_event(ctx);                                                            \
-      pr_.sid = (rstream) == ctx->st ? 0 : (rstream) == ctx->st2 ? 1 : (rstream) == ctx->st2b ? 3 : 2; \
+      pr_.sid = (rstream) == ctx->st ? 0 : (rstream) == ctx->st2 ? 1 : 2; \
       hipEventRecord(pr_.a, rstream);                                                     \
     }                                                                                     \
     hipError_t e_ = (expr);                                                               \

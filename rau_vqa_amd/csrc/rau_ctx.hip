@@ -168,23 +168,8 @@ int rau_create(const rau_config* cfg, rau_ctx** out) {
     // path and must not queue behind the bulk GEMMs' workgroups
     int prio_lo = 0, prio_hi = 0;
     hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
-    hipError_t es = hipSuccess;
-    // Optional spatial partition (RAU_CHAIN_CUS=n): the chain stream gets n compute
-    // units to itself, the bulk stream the rest, via per-queue CU masks.
-    const char* env_cus = std::getenv("RAU_CHAIN_CUS");
-    const int chain_cus = env_cus ? std::atoi(env_cus) : 0;
-    const int ncu = prop.multiProcessorCount;
-    if (chain_cus > 0 && chain_cus < ncu) {
-      const int words = (ncu + 31) / 32;
-      std::vector<uint32_t> mc(words, 0u), mb(words, 0u);
-      for (int i = 0; i < ncu; ++i) (i < chain_cus ? mc : mb)[i >> 5] |= 1u << (i & 31);
-      es = hipExtStreamCreateWithCUMask(&ctx->st, words, mc.data());
-      if (es == hipSuccess) es = hipExtStreamCreateWithCUMask(&ctx->st2, words, mb.data());
-    } else {
-      es = hipStreamCreateWithPriority(&ctx->st, hipStreamNonBlocking, prio_hi);
-      if (es == hipSuccess)
-        es = hipStreamCreateWithPriority(&ctx->st2, hipStreamNonBlocking, prio_lo);
-    }
+    hipError_t es = hipStreamCreateWithPriority(&ctx->st, hipStreamNonBlocking, prio_hi);
+    if (es == hipSuccess) es = hipStreamCreateWithPriority(&ctx->st2, hipStreamNonBlocking, prio_lo);
     if (es != hipSuccess) {
       delete ctx;
       return fail(RAU_ERR_DEVICE, "hipStreamCreate: %s", hipGetErrorString(es));
@@ -199,12 +184,6 @@ int rau_create(const rau_config* cfg, rau_ctx** out) {
     int plo = 0, phi = 0;
     hipDeviceGetStreamPriorityRange(&plo, &phi);
     hipStreamCreateWithPriority(&ctx->st3, hipStreamNonBlocking, plo);
-    if (const char* eb = std::getenv("RAU_BULK2")) {   // A/B knob: 1 forward groups alternate, 2 att_i wgrad aside
-      ctx->bulk2 = std::atoi(eb);
-      hipStreamCreateWithPriority(&ctx->st2b, hipStreamNonBlocking, plo);
-      hipEventCreateWithFlags(&ctx->evP, evflags);
-      hipEventCreateWithFlags(&ctx->evJ, evflags);
-    }
   }
   // Default partition: pairs, then the last two hops alone.  The forward phase ends one hop after
   // the last group's GEMMs and the backward bulk work can start one hop into the backward chain
@@ -265,8 +244,6 @@ int rau_create(const rau_config* cfg, rau_ctx** out) {
     hipEventCreateWithFlags(&ctx->evH[i], evflags);
   }
   hipEventCreateWithFlags(&ctx->evHd, evflags);
-  ctx->evEc.resize(8);
-  for (auto& e : ctx->evEc) hipEventCreateWithFlags(&e, evflags);
 
   // S below is the position PITCH of the device tensors; SL the logical number of positions
   // (they differ only for maps like 7x7 = 49 -> 52: pad columns carry zero features, zero
@@ -435,7 +412,6 @@ int rau_create(const rau_config* cfg, rau_ctx** out) {
     const size_t sl2 = std::max(conv_wgrad_slab_floats(H * B, A, M, S),
                                 conv_wgrad_slab_floats(H * B, M, D, S));
     CK(dalloc(ctx, &ctx->slab2, sl2));
-    if (ctx->st2b) CK(dalloc(ctx, &ctx->slab2b, sl2));
     const int rowsH = H * B, rowsT = T * B;
     const int shapes[][3] = {{K, M, rowsH},      {M, R, rowsH},      {4 * R, M, rowsH},
                              {4 * R, R, rowsH},  {M, S, rowsH},      {S, R, rowsH},
@@ -510,15 +486,11 @@ void rau_destroy(rau_ctx* ctx) {
   for (hipEvent_t e : {ctx->evA, ctx->evD, ctx->evW, ctx->evE, ctx->evW3, ctx->evM3, ctx->evEnd, ctx->evE1})
     if (e) hipEventDestroy(e);
   if (ctx->st3) hipStreamDestroy(ctx->st3);
-  if (ctx->st2b) { hipStreamSynchronize(ctx->st2b); hipStreamDestroy(ctx->st2b); }
   if (ctx->perr_h) hipHostFree(ctx->perr_h);
-  if (ctx->evP) hipEventDestroy(ctx->evP);
-  if (ctx->evJ) hipEventDestroy(ctx->evJ);
   for (hipEvent_t e : ctx->evF) hipEventDestroy(e);
   for (hipEvent_t e : ctx->evK) hipEventDestroy(e);
   for (hipEvent_t e : ctx->evH) hipEventDestroy(e);
   if (ctx->evHd) hipEventDestroy(ctx->evHd);
-  for (hipEvent_t e : ctx->evEc) hipEventDestroy(e);
   if (ctx->st2) hipStreamDestroy(ctx->st2);
   if (ctx->st) hipStreamDestroy(ctx->st);
   delete ctx;
@@ -1049,13 +1021,11 @@ int rau_forward(rau_ctx* ctx) {
   // the per-hop half (+u, tanh, score, softmax, context) is att_fwd_fused.
   // Hops are launched in groups of `hop_group` so hop h's chain can start as soon
   // as its group is done while the bulk stream works on the later groups.
-  bool enc_done = false;
   // ---------------- encoder, SS:443-462
   // Layer-1 cell t+1 and layer-2 cell t do not depend on each other, so the two layers
   // advance as a wavefront: per step ONE batched split-K GEMM (h1 W_h2h1^T for layer 1;
   // x2 W_i2h2^T and h2 W_h2h2^T for layer 2; same shapes) and ONE two-cell LSTM kernel
   // that sums the partials -- TL+1 steps of 2 launches instead of 2*TL steps of 2.
-  int enc_rec_step = 0;   // RAU_ENC_FIRST=k: evA is recorded again behind wavefront step k
   auto encoder_forward = [&]() -> int {
   if (TL > 0) {
     const int rows = TL * B;
@@ -1118,7 +1088,6 @@ int rau_forward(rau_ctx* ctx) {
           fl += C2.nsrc * gflop(B, 4 * Rq, Rq);
         }
         RUN("enc_step_fused", fl, 0, lstm_step_fused(st, GATES_DEEP, sp));
-        if (s == enc_rec_step) HIPC(hipEventRecord(ctx->evA, st));
       }
     } else
     for (int s = 1; s <= TL + 1; ++s) {
@@ -1162,7 +1131,6 @@ int rau_forward(rau_ctx* ctx) {
         C2.drop_out = nullptr; C2.mask = nullptr; C2.mask_e0 = 0; C2.mscale = 1.f;
       }
       RUN("lstm_fwd", 0, BRq * 4.0 * 10 * cells.n, lstm_fwd_multi(st, GATES_DEEP, B, Rq, cells));
-      if (s == enc_rec_step) HIPC(hipEventRecord(ctx->evA, st));
     }
   }
   return 0;
@@ -1179,15 +1147,6 @@ int rau_forward(rau_ctx* ctx) {
     hipStream_t sb = ctx->st2;
     HIPC(hipEventRecord(ctx->evA, st));
     HIPC(hipStreamWaitEvent(sb, ctx->evA, 0));
-    // A/B knob: the encoder gets the machine to itself for its first k wavefront steps (k >= T+1: all)
-    static const int enc_first = [] { const char* e = std::getenv("RAU_ENC_FIRST");
-                                      return e ? std::max(1, std::atoi(e)) : 0; }();
-    if (enc_first && TL > 0) {
-      enc_rec_step = std::min(enc_first, TL + 1);
-      if (int rc = encoder_forward()) return rc;
-      HIPC(hipStreamWaitEvent(sb, ctx->evA, 0));
-      enc_done = true;
-    }
     if (int rc = gen_masks(ctx, -1, RAU_MASK_X, sb)) return rc;
     RUNS(sb, "transpose", 0, (double)M * D * 8, transpose2d(sb, M, D, ctx->i_embed.W, ctx->WiT, ctx->WiT16));
     RUNS(sb, "transpose", 0, (double)A * M * 8, transpose2d(sb, A, M, ctx->att_i.W, ctx->WpT, ctx->WpT16));
@@ -1199,17 +1158,7 @@ int rau_forward(rau_ctx* ctx) {
       RUNS(sb, "dropout_features", 0, (double)(H + 1) * B * D * S * 4,
            dropout_features(sb, H, (size_t)B * D * S, ctx->feats, m_x, sc(RAU_MASK_X), ctx->xd, 0, SL,
                             S));
-    static const int cap_hops = [] { const char* e = std::getenv("RAU_FWD_CAP_HOPS");   // A/B knob
-                                     return e ? std::atoi(e) : 0; }();
-    hipStream_t sb0 = sb;
-    if (ctx->st2b) {   // operands (transposed weights, dropped-out maps) are ready for the second bulk stream
-      HIPC(hipEventRecord(ctx->evP, sb0));
-      HIPC(hipStreamWaitEvent(ctx->st2b, ctx->evP, 0));
-    }
-    int gi = 0;
-    for (int h0 = 0; h0 < H; h0 += gsz[h0], ++gi) {
-      sb = (ctx->st2b && (ctx->bulk2 & 1) && (gi & 1)) ? ctx->st2b : sb0;
-      const int cap = !ctx->I_shared && h0 < cap_hops;   // groups that run beside the encoder
+    for (int h0 = 0; h0 < H; h0 += gsz[h0]) {
       const int nBI = ctx->I_shared ? B : gsz[h0] * B;
       const size_t hb = ctx->I_shared ? 0 : (size_t)h0 * B;  // first (hop, sample) row
       const float* xin = m_x ? ctx->xd + hb * D * S : ctx->feats;
@@ -1223,7 +1172,7 @@ int rau_forward(rau_ctx* ctx) {
       else
         RUNS(sb, "conv_embed_fwd", gflop(M, (double)nBI * S, D),
              ((double)nBI * D * S + (double)nBI * M * S) * 4,
-             conv_embed_fwd(sb, nBI, D, S, M, xin, ctx->WiT, ctx->i_embed.b, Ig, ctx->bf16, cap));
+             conv_embed_fwd(sb, nBI, D, S, M, xin, ctx->WiT, ctx->i_embed.b, Ig, ctx->bf16));
       if (x16)
         RUNS(sb, "conv_att_pre", gflop(A, (double)nBI * S, M),
              ((double)nBI * M * S + (double)nBI * A * S) * 4,
@@ -1231,17 +1180,12 @@ int rau_forward(rau_ctx* ctx) {
       else
         RUNS(sb, "conv_att_pre", gflop(A, (double)nBI * S, M),
              ((double)nBI * M * S + (double)nBI * A * S) * 4,
-             conv_att_pre(sb, nBI, M, S, A, Ig, ctx->WpT, ctx->att_i.b, Pg, ctx->bf16, cap));
+             conv_att_pre(sb, nBI, M, S, A, Ig, ctx->WpT, ctx->att_i.b, Pg, ctx->bf16));
       HIPC(hipEventRecord(ctx->evF[h0], sb));
-    }
-    if (ctx->st2b) {   // everything later on the bulk stream is ordered after both
-      HIPC(hipEventRecord(ctx->evJ, ctx->st2b));
-      HIPC(hipStreamWaitEvent(sb0, ctx->evJ, 0));
     }
   }
 
-  if (!enc_done)
-    if (int rc = encoder_forward()) return rc;
+  if (int rc = encoder_forward()) return rc;
   RUN("gather_q", 0, (double)B * Q * 8,
       gather_q(st, B, Rq, TL, ctx->lens_d, ctx->c1, ctx->h1, ctx->c2, ctx->h2, ctx->q));
 
@@ -1418,12 +1362,10 @@ int rau_backward(rau_ctx* ctx, const float* hop_w) {
                conv_att_dgrad(sb, nH, M, S, A, ctx->T + hb * A * S, ctx->att_i.W, ctx->dj + hb * M,
                               ctx->a + hb * S, ctx->dZ + hb * M * S, ctx->bf16));
         {   // RAU_BULK2: the att_i weight gradient (independent of dZ) on the second bulk stream
-          hipStream_t sa = (ctx->st2b && (ctx->bulk2 & 2)) ? ctx->st2b : sb;
-          if (sa != sb) HIPC(hipStreamWaitEvent(sa, ctx->evK[h], 0));
-          RUNS(sa, "conv_att_wgrad", gflop(A, M, (double)nH * S),
+          RUNS(sb, "conv_att_wgrad", gflop(A, M, (double)nH * S),
                ((double)nH * A * S + (double)nH * M * S) * 4,
-               conv_att_wgrad(sa, nH, M, S, A, ctx->T + hb * A * S, ctx->I + hb * M * S,
-                              ctx->att_i.dW, sa != sb ? ctx->slab2b : ctx->slab2, ctx->bf16));
+               conv_att_wgrad(sb, nH, M, S, A, ctx->T + hb * A * S, ctx->I + hb * M * S,
+                              ctx->att_i.dW, ctx->slab2, ctx->bf16));
         }
         if (ctx->xd16 && dzf)
           RUNS(sb, "conv_embed_wgrad", gflop(M, D, (double)nH * S),
@@ -1467,10 +1409,6 @@ int rau_backward(rau_ctx* ctx, const float* hop_w) {
   // row sums of its staged dZ operand)
   {
     hipStream_t sb = ctx->st2;
-    if (ctx->st2b) {
-      HIPC(hipEventRecord(ctx->evJ, ctx->st2b));
-      HIPC(hipStreamWaitEvent(sb, ctx->evJ, 0));
-    }
     HIPC(hipEventRecord(ctx->evD, sb));
   }
   // ---------------- mult-group weight gradients, one GEMM per weight over all hops.
@@ -1530,12 +1468,7 @@ int rau_backward(rau_ctx* ctx, const float* hop_w) {
       RUNS(sw, "wgrad_gemm", fl, 0, gemm_tn_group_acc(sw, pr, np, nr, ctx->slab3, ctx->slab3_floats));
       return 0;
     };
-    // RAU_ENC_CHUNKS=n: n time chunks; chunk boundaries at wavefront steps cut[k] (descending)
-    static const int nchunk_env = [] { const char* e = std::getenv("RAU_ENC_CHUNKS"); const int v = e ? std::atoi(e) : 0;
-                                       return v > 0 ? v : 1; }();
-    const int nchunk = std::max(1, std::min(nchunk_env, std::min(TL, (int)ctx->evEc.size())));
-    int next_cut = nchunk - 1;                 // cuts at u = TL * k / nchunk, k = nchunk-1 .. 1
-    int hi = TL;
+    const int hi = TL;
     for (int u = TL; u >= 0; --u) {
       const float* Ap[3];
       const float* Wp[3];
@@ -1581,13 +1514,6 @@ int rau_backward(rau_ctx* ctx, const float* hop_w) {
         C1.t = t; C1.dq_c = ctx->dq; C1.dq_h = ctx->dq + Rq;
       }
       RUN("lstm_bwd", 0, BRq * 4.0 * 12 * cells.n, lstm_bwd_multi(st, GATES_DEEP, B, Rq, cells));
-      if (next_cut >= 1 && u == (int)((long)TL * next_cut / nchunk) && u < hi) {
-        if (int rc = enc_wgrads(u, hi, ctx->evEc[next_cut])) return rc;
-        hi = u;
-        --next_cut;
-      } else if (next_cut >= 1 && u < (int)((long)TL * next_cut / nchunk)) {
-        --next_cut;
-      }
     }
     {  // gradient w.r.t. the word embeddings' tanh output, all tokens at once
       LINOPTS(o);

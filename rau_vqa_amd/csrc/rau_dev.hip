@@ -8,6 +8,8 @@
 // CUDA box cutorch does that; on an MI355X host there is no cutorch, so the same handful of
 // operations is exported here on plain device pointers, enqueued on the ctx stream like everything
 // else.  bindings/rau.lua wraps them in a tensor-shaped object.
+#include <cmath>
+
 #include "rau_ctx.h"
 
 namespace {
@@ -79,6 +81,44 @@ __global__ void k_count_eq(int n, const int32_t* __restrict__ a, const int32_t* 
   if (threadIdx.x == 0) out[0] = (s[0] + s[1]) + (s[2] + s[3]);
 }
 
+// y += a * x1 * x2   /   y += a * x1 / x2   (torch addcmul / addcdiv, utils/optim_updates.lua:80-87)
+__global__ void k_addcmul(size_t n, float a, const float* __restrict__ x1, const float* __restrict__ x2,
+                          float* __restrict__ y) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n;
+       i += (size_t)gridDim.x * blockDim.x)
+    y[i] += a * x1[i] * x2[i];
+}
+__global__ void k_addcdiv(size_t n, float a, const float* __restrict__ x1, const float* __restrict__ x2,
+                          float* __restrict__ y) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n;
+       i += (size_t)gridDim.x * blockDim.x)
+    y[i] += a * x1[i] / x2[i];
+}
+__global__ void k_sqrt(size_t n, float* __restrict__ x) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n;
+       i += (size_t)gridDim.x * blockDim.x)
+    x[i] = sqrtf(x[i]);
+}
+__global__ void k_add_scalar(size_t n, float v, float* __restrict__ x) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n;
+       i += (size_t)gridDim.x * blockDim.x)
+    x[i] += v;
+}
+// adam(x, dx, ..) of utils/optim_updates.lua:59-87 on one flat vector, its five tensor statements
+// fused into one pass: m = b1 m + (1-b1) dx; v = b2 v + (1-b2) dx^2; x -= step m / (sqrt(v) + eps)
+__global__ void k_adam_vec(size_t n, float b1, float b2, float eps, float step, const float* __restrict__ dx,
+                           float* __restrict__ m, float* __restrict__ v, float* __restrict__ x) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const float g = dx[i];
+    const float mi = m[i] * b1 + (1.f - b1) * g;
+    const float vi = v[i] * b2 + (1.f - b2) * g * g;
+    m[i] = mi;
+    v[i] = vi;
+    x[i] -= step * mi / (sqrtf(vi) + eps);
+  }
+}
+
 inline int blocks_for(size_t n) { return (int)std::min<size_t>((n + 255) / 256, 2048); }
 
 }  // namespace
@@ -119,6 +159,43 @@ int rau_dev_axpy(rau_ctx* ctx, float* y, const float* x, size_t n, float alpha) 
 int rau_dev_scale(rau_ctx* ctx, float* x, size_t n, float alpha) {
   NEED(ctx && (x || !n), "null argument");
   if (n) hipLaunchKernelGGL(k_scale, dim3(blocks_for(n)), dim3(256), 0, ctx->st, n, alpha, x);
+  HIPC(hipGetLastError());
+  return RAU_OK;
+}
+int rau_dev_addcmul(rau_ctx* ctx, float* y, float alpha, const float* x1, const float* x2, size_t n) {
+  NEED(ctx && ((y && x1 && x2) || !n), "null argument");
+  if (n) hipLaunchKernelGGL(k_addcmul, dim3(blocks_for(n)), dim3(256), 0, ctx->st, n, alpha, x1, x2, y);
+  HIPC(hipGetLastError());
+  return RAU_OK;
+}
+int rau_dev_addcdiv(rau_ctx* ctx, float* y, float alpha, const float* x1, const float* x2, size_t n) {
+  NEED(ctx && ((y && x1 && x2) || !n), "null argument");
+  if (n) hipLaunchKernelGGL(k_addcdiv, dim3(blocks_for(n)), dim3(256), 0, ctx->st, n, alpha, x1, x2, y);
+  HIPC(hipGetLastError());
+  return RAU_OK;
+}
+int rau_dev_sqrt(rau_ctx* ctx, float* x, size_t n) {
+  NEED(ctx && (x || !n), "null argument");
+  if (n) hipLaunchKernelGGL(k_sqrt, dim3(blocks_for(n)), dim3(256), 0, ctx->st, n, x);
+  HIPC(hipGetLastError());
+  return RAU_OK;
+}
+int rau_dev_add_scalar(rau_ctx* ctx, float* x, size_t n, float value) {
+  NEED(ctx && (x || !n), "null argument");
+  if (n) hipLaunchKernelGGL(k_add_scalar, dim3(blocks_for(n)), dim3(256), 0, ctx->st, n, value, x);
+  HIPC(hipGetLastError());
+  return RAU_OK;
+}
+int rau_dev_adam(rau_ctx* ctx, float* x, const float* dx, float* m, float* v, size_t n, float lr,
+                 float beta1, float beta2, float eps, int32_t t) {
+  NEED(ctx && ((x && dx && m && v) || !n), "null argument");
+  NEED(t >= 1, "rau_dev_adam: t = %d (the step counter AFTER its increment, >= 1)", t);
+  // step size on the host in double like LuaJIT's numbers (optim_updates.lua:80-83)
+  const double bc1 = 1.0 - std::pow((double)beta1, (double)t), bc2 = 1.0 - std::pow((double)beta2, (double)t);
+  const float step = (float)((double)lr * std::sqrt(bc2) / bc1);
+  if (n)
+    hipLaunchKernelGGL(k_adam_vec, dim3(blocks_for(n)), dim3(256), 0, ctx->st, n, beta1, beta2, eps, step,
+                       dx, m, v, x);
   HIPC(hipGetLastError());
   return RAU_OK;
 }

@@ -184,6 +184,16 @@ class DevTensor:
     def __init__(self, rau, ptr: int, size, owned=False):
         self.rau, self.ptr, self.size, self.owned = rau, int(ptr), tuple(size), owned
 
+    def __del__(self):
+        # owned memory goes back to the context when the tensor is collected (views own nothing);
+        # a context that is already closed has freed it itself
+        try:
+            if self.owned and getattr(self.rau, "_h", None):
+                self.rau._lib.rau_dev_free(self.rau._h, self.ptr)
+        except Exception:
+            pass
+        self.owned = False
+
     @classmethod
     def zeros(cls, rau, *size):
         out = C.c_void_p()
@@ -242,6 +252,25 @@ class DevTensor:
         L.check(self.rau._lib.rau_dev_scale(self.rau._h, self.ptr, self.numel(), float(a)))
         return self
 
+    # the tensor statements of utils/optim_updates.lua:76-86
+    def add_scalar(self, v):
+        L.check(self.rau._lib.rau_dev_add_scalar(self.rau._h, self.ptr, self.numel(), float(v)))
+        return self
+
+    def addcmul(self, a, x1, x2):      # self += a * x1 * x2
+        L.check(self.rau._lib.rau_dev_addcmul(self.rau._h, self.ptr, float(a), x1.ptr, x2.ptr,
+                                              self.numel()))
+        return self
+
+    def addcdiv(self, a, x1, x2):      # self += a * x1 / x2
+        L.check(self.rau._lib.rau_dev_addcdiv(self.rau._h, self.ptr, float(a), x1.ptr, x2.ptr,
+                                              self.numel()))
+        return self
+
+    def sqrt(self):
+        L.check(self.rau._lib.rau_dev_sqrt(self.rau._h, self.ptr, self.numel()))
+        return self
+
     def sum(self):
         out = C.c_double()
         L.check(self.rau._lib.rau_dev_sum(self.rau._h, self.ptr, self.numel(), C.byref(out)))
@@ -250,7 +279,16 @@ class DevTensor:
     def max(self, dim):                # torch.max(t, 2): (values [r,1], 1-based first-max ids [r,1])
         assert dim == 2 and len(self.size) == 2
         r, c = self.size
-        v, i = DevTensor.zeros(self.rau, r, 1), DevTensor.zeros(self.rau, r, 1)
+        # a ring of four context-owned result slots per row count: feval calls this once per hop
+        # per iteration (SS:488), so nothing is allocated on that path; like self.output a result
+        # stays valid until its slot comes round again
+        rings = self.rau.__dict__.setdefault("_max_scratch", {})
+        ring = rings.get(r)
+        if ring is None:
+            ring = rings[r] = {"k": 0, "slots": [(DevTensor.zeros(self.rau, r, 1),
+                                                  DevTensor.zeros(self.rau, r, 1)) for _ in range(4)]}
+        ring["k"] = (ring["k"] + 1) % 4
+        v, i = ring["slots"][ring["k"]]
         L.check(self.rau._lib.rau_dev_rowmax(self.rau._h, self.ptr, r, c, v.ptr, i.ptr))
         i.is_int = True
         return v, i
@@ -285,6 +323,44 @@ class DevTensor:
         if self.owned:
             L.check(self.rau._lib.rau_dev_free(self.rau._h, self.ptr))
             self.owned = False
+
+
+def adam(x, dx, lr, beta1=0.9, beta2=0.999, epsilon=1e-8, state=None):
+    """`adam(x, dx, lr, beta1, beta2, epsilon, state)` of utils/optim_updates.lua:59-87 on one flat
+    device vector (x, dx = rau.flat(group)); state is a dict holding m, v (DevTensors, created on
+    first use) and t -- the Python twin of bindings/rau.lua's RAU.adam, so that SS:770-772 runs
+    unchanged above the C ABI."""
+    if "m" not in state:
+        state["t"] = 0
+        state["m"] = DevTensor.zeros(x.rau, x.numel())
+        state["v"] = DevTensor.zeros(x.rau, x.numel())
+    state["t"] += 1
+    L.check(x.rau._lib.rau_dev_adam(x.rau._h, x.ptr, dx.ptr, state["m"].ptr, state["v"].ptr, x.numel(),
+                                    float(lr), float(beta1), float(beta2), float(epsilon), state["t"]))
+
+
+def adam_statements(x, dx, lr, beta1=0.9, beta2=0.999, epsilon=1e-8, state=None):
+    """The same update written as the reference's five tensor statements, one rau_dev_* call each
+    (what RAU.Tensor's mul / add / addcmul / sqrt / addcdiv give a script that keeps its own adam)."""
+    import math
+    if "m" not in state:
+        state["t"] = 0
+        state["m"] = DevTensor.zeros(x.rau, x.numel())
+        state["v"] = DevTensor.zeros(x.rau, x.numel())
+        state["tmp"] = DevTensor.zeros(x.rau, x.numel())
+    state["m"].mul(beta1).add(1 - beta1, dx)                      # optim_updates.lua:76
+    state["v"].mul(beta2).addcmul(1 - beta2, dx, dx)              # :77
+    state["tmp"].copy(state["v"]).sqrt().add_scalar(epsilon)      # :78
+    state["t"] += 1
+    step = lr * math.sqrt(1 - beta2 ** state["t"]) / (1 - beta1 ** state["t"])
+    x.addcdiv(-step, state["m"], state["tmp"])                    # :86
+
+
+def flat(rau, group):
+    """(params, grads) of a parameter group as DevTensor views (m:getParameters(), SS:322-324)."""
+    w, g, n = C.c_void_p(), C.c_void_p(), C.c_size_t()
+    L.check(rau._lib.rau_params(rau._h, L.GROUPS[group], C.byref(w), C.byref(g), C.byref(n)))
+    return DevTensor.wrap(rau, w.value, n.value), DevTensor.wrap(rau, g.value, n.value)
 
 
 def _cp(t):

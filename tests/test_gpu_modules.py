@@ -307,6 +307,55 @@ def test_device_tensor_ops():
     m.close()
 
 
+def test_reference_adam_on_flat_device_vectors():
+    """SS:770-772 above the C ABI: `adam(x, dx, lr, alpha, beta, epsilon, state)` of
+    utils/optim_updates.lua:59-87 on each group's flat (param, grad) device vectors -- as one fused
+    pass (rau_dev_adam, what bindings/rau.lua's RAU.adam calls) and as the reference's own five
+    tensor statements (mul / add / addcmul / sqrt / add(scalar) / addcdiv, one rau_dev_* call each)
+    -- against the oracle's Adam (noise off, clip off) over three steps; and m:updateParameters'
+    plain SGD.  Also: repeated max() allocates nothing (a ring of context-owned slots)."""
+    from rau_vqa_amd.modules import DevTensor, adam, adam_statements, flat
+    sh = util.shapes(util.SMALL)
+    _, params, _ = util.make_problem(sh)
+    rng = np.random.default_rng(11)
+    for fn in (adam, adam_statements):
+        m = make_model(sh, params, mode="eval")
+        ref = {k: v.astype(np.float64) for k, v in params.items()}
+        mom = {k: (np.zeros(v.size), np.zeros(v.size)) for k, v in params.items()}
+        state = {k: {} for k in params}
+        for t in range(1, 4):
+            grads = {k: (rng.standard_normal(v.size) * 0.01).astype(np.float32) for k, v in params.items()}
+            m.set_grads(grads)
+            for k in ("embed", "rnn", "mult"):
+                lr = 3e-4 if k == "mult" else 3e-3                      # SS:43-46, 770-772
+                x, dx = flat(m, k)
+                fn(x, dx, lr, 0.9, 0.999, 1e-8, state[k])
+                oracle.noise_clip_adam(ref[k], grads[k].astype(np.float64), mom[k][0], mom[k][1], None,
+                                       t - 1, t, lr, eta=0.0, clip=1e30)
+            got = m.get_params()
+            for k in ref:
+                assert util.rel_err(got[k], ref[k]) < 1e-5, (fn.__name__, t, k)
+        assert state["mult"]["t"] == 3
+        m.close()
+    # nn.Module:updateParameters(lr) = x - lr dx on the flat vectors
+    m = make_model(sh, params, mode="eval")
+    grads = {k: (rng.standard_normal(v.size) * 0.01).astype(np.float32) for k, v in params.items()}
+    m.set_grads(grads)
+    for k in ("embed", "rnn", "mult"):
+        x, dx = flat(m, k)
+        x.add(-0.5, dx)
+    got = m.get_params()
+    for k in params:
+        assert np.allclose(got[k], params[k] - 0.5 * grads[k], rtol=1e-6, atol=1e-7), k
+    t = DevTensor.zeros(m, 5, 7).copy(rng.standard_normal((5, 7)).astype(np.float32))
+    seen = set()
+    for _ in range(12):
+        v, i = t.max(2)
+        seen.add((v.ptr, i.ptr))
+    assert len(seen) == 4                                             # four slots, reused
+    m.close()
+
+
 def test_module_level_calls_on_7x7_maps():
     """S = 49 (the scripts' default feature grid, SS:36-37) through the MODULE-level entry points:
     callers see dense [.., 49] tensors, the library re-pitches to 52 internally."""

@@ -70,6 +70,8 @@ def check(sh, seed=123, lens="ragged", mode="train", hop_w=None, scale=None, tor
     assert not bad, f"relative errors above {TOL}: {bad}\nall: {errs}"
     ok, decided, total = util.argmax_margin_ok(ref["logits"], got["argmax"], ref["argmax"])
     assert ok, "argmax mismatch on a decided row"
+    print(f"argmax: {decided} of {total} rows decided at a 1e-5 margin, all equal; "
+          f"{total - decided} undecided")
     return errs
 
 

@@ -60,8 +60,26 @@ def test_surface_the_reference_loops_need():
     for method in ("RAU:training", "RAU:evaluate", "RAU:getParameters", "RAU:cuda", "RAU:clone",
                    "RAU:updateParameters", "RAU:zeroGradParameters", "RAU:forward", "RAU:backward",
                    "Tensor:add", "Tensor:copy", "Tensor:zero", "Tensor:max", "Tensor:sum",
-                   "Tensor:row", "Tensor:selectRows", "Tensor:float", "IntTensor:eqSum"):
+                   "Tensor:row", "Tensor:selectRows", "Tensor:float", "IntTensor:eqSum",
+                   # the tensor statements of utils/optim_updates.lua:76-86, and owned-memory release
+                   "Tensor:mul", "Tensor:addcmul", "Tensor:addcdiv", "Tensor:sqrt", "Tensor:free",
+                   "IntTensor:free"):
         assert re.search(r"function\s+" + re.escape(method) + r"\b", src), method
     assert "Tensor.__newindex" in src and "Tensor.__index" in src    # t[k] and t[k] = row
     for kind in ("embed", "rnn", "multimodal", "criterion"):
         assert f"kind == '{kind}'" in src
+
+
+def test_adam_has_the_reference_signature_and_owned_memory_has_finalizers():
+    """SS:770-772 calls adam(x, dx, lr, alpha, beta, epsilon, state) (utils/optim_updates.lua:59):
+    the shim exports that signature; device memory it allocates carries an ffi.gc finalizer that
+    checks the context is still alive, and max() does not allocate per call."""
+    src = lua_source()
+    assert re.search(r"function\s+RAU\.adam\(x,\s*dx,\s*lr,\s*beta1,\s*beta2,\s*epsilon,\s*state\)", src)
+    code = strip_comments_and_strings(src)
+    assert re.search(r"ffi\.gc\(p\[0\],\s*function\(q\)\s*if\s+life\.alive", code)
+    body = code[code.index("function Tensor:max"):]
+    body = body[:body.index("function Tensor:selectRows")]
+    assert "scratch" in body and "if not ring then" in body          # allocation only when the ring is first built
+    assert body.index("if not ring then") < body.index("Tensor.new") < body.index("ring.k = ring.k % 4 + 1")
+    assert "rau_dev_axpy" in code[code.index("function RAU:updateParameters"):][:400]   # plain SGD

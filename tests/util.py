@@ -46,8 +46,11 @@ def layer_slices(layout):
     return [(n, slice(off, off + r * c)) for n, off, r, c in layout]
 
 
-def argmax_margin_ok(logits_ref, got, ref, margin=1e-3):
-    """Indices must match wherever the reference top-2 margin exceeds `margin`."""
+def argmax_margin_ok(logits_ref, got, ref, margin=1e-5):
+    """Answer indices must be EQUAL wherever the reference decides them: rows whose top-2 margin in the
+    fp64 reference logits exceeds `margin` (relative; 1e-5 = 25x the measured f32 logit error of
+    ~4e-7, the same bar as the 1k-sample tests).  Returns (ok, decided, total); the caller reports
+    total - decided = the rows a 1e-5 tie leaves undecided (0 on every committed seed)."""
     srt = np.sort(logits_ref, axis=-1)
     gap = srt[..., -1] - srt[..., -2]
     decided = gap > margin * np.maximum(1.0, np.abs(srt[..., -1]))
