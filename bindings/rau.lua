@@ -43,6 +43,11 @@ int rau_get_mask(rau_ctx* ctx, int site, uint8_t* keep, size_t n);
 int rau_set_batch(rau_ctx* ctx, const float* feats, const int32_t* tokens,
                   const int32_t* lens, const int32_t* labels);
 int rau_batch_feats(rau_ctx* ctx, float** feats_dev);
+int rau_batch_slot(rau_ctx* ctx, int slot, float** feats_host, int32_t** tokens_host,
+                   int32_t** lens_host, int32_t** labels_host);
+int rau_set_batch_async(rau_ctx* ctx, int slot, const float* feats, const int32_t* tokens,
+                        const int32_t* lens, const int32_t* labels, int has_labels);
+int rau_use_batch(rau_ctx* ctx, int slot);
 int rau_forward(rau_ctx* ctx);
 int rau_backward(rau_ctx* ctx, const float* hop_w);
 int rau_embed_forward(rau_ctx* ctx, int t, const int32_t* tokens_dev, float** we);
@@ -154,6 +159,31 @@ function RAU:reset(seed, lo, hi) check(C.rau_init_uniform(self.h, seed or 123, l
 function RAU:setBatch(feats, x, x_len, y)
   check(C.rau_set_batch(self.h, feats:data(), x:data(), x_len:data(), y and y:data() or nil))
 end
+
+-- Asynchronous, double-buffered upload (slot = 0 | 1): what SS:434-439 does every iteration, moved
+-- behind the loader's prefetch.  rau:batchSlot(slot) returns host tensors OVER the slot's pinned
+-- staging (torch storages on foreign memory: no copy, not owned) for next_batch_feat's worker to
+-- assemble the batch in; rau:setBatchAsync(slot) enqueues the upload of what is in them (pass
+-- tensors to have them copied into the staging first); rau:useBatch(slot) makes it the resident
+-- batch -- the step's streams wait for the copies by an event, the host never does.
+function RAU:batchSlot(slot)
+  local f, x, l, y = ffi.new('float*[1]'), ffi.new('int32_t*[1]'), ffi.new('int32_t*[1]'), ffi.new('int32_t*[1]')
+  check(C.rau_batch_slot(self.h, slot, f, x, l, y))
+  local c = self.cfg
+  local function addr(p) return tonumber(ffi.cast('intptr_t', p)) end
+  return {
+    feats = torch.FloatTensor(torch.FloatStorage(c.B * c.D * c.S, addr(f[0]))):resize(c.B, c.D, c.S),
+    x = torch.IntTensor(torch.IntStorage(c.T * c.B, addr(x[0]))):resize(c.T, c.B),
+    x_len = torch.IntTensor(torch.IntStorage(c.B, addr(l[0]))),
+    y = torch.IntTensor(torch.IntStorage(c.B, addr(y[0]))),
+  }
+end
+function RAU:setBatchAsync(slot, feats, x, x_len, y, has_labels)
+  check(C.rau_set_batch_async(self.h, slot, feats and feats:data() or nil, x and x:data() or nil,
+                              x_len and x_len:data() or nil, y and y:data() or nil,
+                              (has_labels == false) and 0 or 1))
+end
+function RAU:useBatch(slot) check(C.rau_use_batch(self.h, slot)) end
 
 -- forward half of feval (SS:443-520); returns per-hop losses as a Lua table
 function RAU:forward(seed, step)

@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define RAU_ABI_VERSION 3
+#define RAU_ABI_VERSION 4
 
 typedef enum rau_status {
   RAU_OK = 0,
@@ -157,6 +157,30 @@ int rau_set_batch(rau_ctx* ctx, const float* feats, const int32_t* tokens,
                   const int32_t* lens, const int32_t* labels);
 /* device pointer of the resident feature buffer (producer may write it directly) */
 int rau_batch_feats(rau_ctx* ctx, float** feats_dev);
+
+/* ---- asynchronous, double-buffered upload: SS:434-439 behind the loader's prefetch -------------
+ * The reference re-uploads feats / x / x_len / y every iteration (SS:434-439) while its loader's
+ * worker thread assembles the next batch (utils/vqa_prepro_loader.lua:931-958).  Here the ctx owns
+ * TWO batch slots, each with device buffers and PINNED host staging:
+ *   rau_batch_slot(slot)       -> host pointers of the slot's staging (feats [B,D,S], tokens [T,B],
+ *                                 lens [B], labels [B]); the loader assembles the batch in place.
+ *                                 Waits (on the host) until the slot's previous upload has left it.
+ *   rau_set_batch_async(slot, feats, tokens, lens, labels, has_labels)
+ *                              -> checks the ids, builds the token index (host), enqueues the H2D
+ *                                 copies on a dedicated copy stream and returns; no stream is
+ *                                 synchronised.  A NULL pointer = "already in the slot's staging";
+ *                                 a non-NULL one is copied into it first (one host memcpy).
+ *                                 has_labels tells whether in-place labels are present.
+ *   rau_use_batch(slot)        -> the slot becomes the resident batch; the step's streams are ordered
+ *                                 behind its upload by an event, not by a host wait.
+ * Upload batch n+1 into the other slot while step n runs; the copy stream itself waits for the last
+ * step that read the slot being refilled.  rau_set_batch stays the synchronous form (it writes the
+ * current slot). */
+int rau_batch_slot(rau_ctx* ctx, int slot, float** feats_host, int32_t** tokens_host,
+                   int32_t** lens_host, int32_t** labels_host);
+int rau_set_batch_async(rau_ctx* ctx, int slot, const float* feats, const int32_t* tokens,
+                        const int32_t* lens, const int32_t* labels, int has_labels);
+int rau_use_batch(rau_ctx* ctx, int slot);
 
 /* ---- the hot path ------------------------------------------------------------
  * rau_forward : SS:443-520  encoder unroll, length select, H-hop RAU, per-hop

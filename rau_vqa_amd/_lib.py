@@ -71,6 +71,11 @@ _SIGS = {
     "rau_get_mask": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]),
     "rau_set_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "rau_batch_feats": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
+    "rau_batch_slot": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                                C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
+    "rau_set_batch_async": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                     C.c_int]),
+    "rau_use_batch": (C.c_int, [C.c_void_p, C.c_int]),
     "rau_forward": (C.c_int, [C.c_void_p]),
     "rau_backward": (C.c_int, [C.c_void_p, C.c_void_p]),
     # module-level entry points: device pointers in, pointers to ctx-owned slots out

@@ -66,6 +66,24 @@ struct ProfCls {
   double ms = 0, flops = 0, bytes = 0;
 };
 
+// One of the two batch slots of the asynchronous upload path (rau_set_batch_async / rau_use_batch):
+// device buffers, pinned host staging the loader may fill in place, the host-side metadata
+// rau_forward needs, and the two events that order uploads against the steps.
+struct BatchSlot {
+  float* feats = nullptr;                                   // device, [B][D][Sp]
+  int32_t *tokens = nullptr, *lens_d = nullptr, *labels_d = nullptr;
+  int32_t *utok = nullptr, *ustart = nullptr, *upos = nullptr;
+  float* feats_h = nullptr;                                 // pinned host, dense [B][D][S]
+  int32_t *tokens_h = nullptr, *lens_p = nullptr, *labels_h = nullptr;
+  int32_t *utok_h = nullptr, *ustart_h = nullptr, *upos_h = nullptr;
+  std::vector<int32_t> lens;
+  int max_len = 0, nuniq = 0;
+  bool have = false, have_labels = false;
+  hipEvent_t uploaded = nullptr;    // recorded on the copy stream behind the slot's H2D copies
+  hipEvent_t consumed = nullptr;    // recorded on the chain stream when the ctx switches away from the slot
+  bool upload_pending = false, consumed_valid = false;
+};
+
 struct rau_ctx {
   rau_config cfg;
   int Q;
@@ -98,6 +116,12 @@ struct rau_ctx {
   bool have_batch = false, have_labels = false;
   int nuniq = 0;
   int32_t *utok = nullptr, *ustart = nullptr, *upos = nullptr;
+  // asynchronous, double-buffered upload (allocated at the first rau_batch_slot / rau_set_batch_async)
+  BatchSlot slot[2];
+  int cur_slot = 0;
+  bool async_ready = false;
+  hipStream_t stc = nullptr;         // copy stream
+  hipEvent_t hopw_ev[2] = {nullptr, nullptr};   // hop-weight staging slots: H2D copy done
   // dropout
   int mode = RAU_MODE_TRAIN;
   uint32_t* mbits[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};

@@ -487,6 +487,13 @@ void rau_destroy(rau_ctx* ctx) {
     if (e) hipEventDestroy(e);
   if (ctx->st3) hipStreamDestroy(ctx->st3);
   if (ctx->perr_h) hipHostFree(ctx->perr_h);
+  if (ctx->stc) { hipStreamSynchronize(ctx->stc); hipStreamDestroy(ctx->stc); }
+  for (BatchSlot& s : ctx->slot) {
+    if (s.feats_h) hipHostFree(s.feats_h);
+    if (s.uploaded) hipEventDestroy(s.uploaded);
+    if (s.consumed) hipEventDestroy(s.consumed);
+  }
+  for (hipEvent_t e : ctx->hopw_ev) if (e) hipEventDestroy(e);
   for (hipEvent_t e : ctx->evF) hipEventDestroy(e);
   for (hipEvent_t e : ctx->evK) hipEventDestroy(e);
   for (hipEvent_t e : ctx->evH) hipEventDestroy(e);
@@ -633,10 +640,14 @@ int rau_get_mask(rau_ctx* ctx, int site, uint8_t* keep, size_t n) {
 }
 
 // ------------------------------------------------------------------ batch
-int rau_set_batch(rau_ctx* ctx, const float* feats, const int32_t* tokens, const int32_t* lens,
-                  const int32_t* labels) {
-  NEED(ctx && tokens && lens, "null argument");
-  const rau_config& c = ctx->cfg;
+}  // extern "C"
+
+namespace {
+// Host-side half of a batch hand-over: argument checks and the distinct-token index over the live
+// positions (t < lens[b]) that makes the LookupTable gradient a fixed-order gather-sum.
+// utok / ustart / upos must hold T*B, T*B + 1, T*B entries.
+int index_batch(const rau_config& c, const int32_t* tokens, const int32_t* lens, const int32_t* labels,
+                int32_t* utok, int32_t* ustart, int32_t* upos, int* max_len_out, int* nuniq_out) {
   int max_len = 0;
   for (int b = 0; b < c.B; ++b) {
     NEED(lens[b] >= 0 && lens[b] <= c.T, "lens[%d]=%d out of [0,%d]", b, lens[b], c.T);
@@ -647,49 +658,226 @@ int rau_set_batch(rau_ctx* ctx, const float* feats, const int32_t* tokens, const
   if (labels)
     for (int b = 0; b < c.B; ++b)
       NEED(labels[b] >= 1 && labels[b] <= c.K, "labels[%d]=%d out of [1,%d]", b, labels[b], c.K);
-  // distinct-token index over the live positions (t < lens[b]): makes the
-  // LookupTable gradient a fixed-order gather-sum.
   std::vector<std::pair<int32_t, int32_t>> pos;  // (token, position)
   for (int t = 0; t < max_len; ++t)
     for (int b = 0; b < c.B; ++b)
       if (t < lens[b]) pos.push_back({tokens[(size_t)t * c.B + b], t * c.B + b});
   std::sort(pos.begin(), pos.end());
-  std::vector<int32_t> utok, ustart, upos;
+  const size_t TB = (size_t)c.T * c.B;
+  size_t nu = 0;
   for (size_t i = 0; i < pos.size(); ++i) {
     if (i == 0 || pos[i].first != pos[i - 1].first) {
-      utok.push_back(pos[i].first);
-      ustart.push_back((int32_t)i);
+      utok[nu] = pos[i].first;
+      ustart[nu] = (int32_t)i;
+      ++nu;
     }
-    upos.push_back(pos[i].second);
+    upos[i] = pos[i].second;
   }
-  ustart.push_back((int32_t)pos.size());
-  ctx->nuniq = (int)utok.size();
   // pad to the maximum token count: a graph-captured embed_bwd launches T*B blocks, the surplus
   // ones see an empty range
-  utok.resize((size_t)c.T * c.B, 1);
-  ustart.resize((size_t)c.T * c.B + 1, (int32_t)pos.size());
+  for (size_t i = nu; i < TB; ++i) utok[i] = 1;
+  for (size_t i = nu; i <= TB; ++i) ustart[i] = (int32_t)pos.size();
+  for (size_t i = pos.size(); i < TB; ++i) upos[i] = 0;
+  *max_len_out = max_len;
+  *nuniq_out = (int)nu;
+  return RAU_OK;
+}
+
+// H2D copies of one batch into a set of device buffers, enqueued on `s`
+int enqueue_batch(rau_ctx* ctx, hipStream_t s, const BatchSlot& d, const float* feats,
+                  const int32_t* tokens, const int32_t* lens, const int32_t* labels,
+                  const int32_t* utok, const int32_t* ustart, const int32_t* upos) {
+  const rau_config& c = ctx->cfg;
+  const size_t TB = (size_t)c.T * c.B;
   if (feats)   // rows of S positions into rows of Sp (pad columns stay zero)
-    HIPC(hipMemcpy2DAsync(ctx->feats, (size_t)ctx->Sp * sizeof(float), feats,
-                          (size_t)c.S * sizeof(float), (size_t)c.S * sizeof(float),
-                          (size_t)c.B * c.D, hipMemcpyHostToDevice, ctx->st));
-  HIPC(hipMemcpyAsync(ctx->tokens, tokens, (size_t)c.T * c.B * 4, hipMemcpyHostToDevice, ctx->st));
-  HIPC(hipMemcpyAsync(ctx->lens_d, lens, (size_t)c.B * 4, hipMemcpyHostToDevice, ctx->st));
-  if (labels)
-    HIPC(hipMemcpyAsync(ctx->labels_d, labels, (size_t)c.B * 4, hipMemcpyHostToDevice, ctx->st));
-  if (!utok.empty()) {
-    HIPC(hipMemcpyAsync(ctx->utok, utok.data(), utok.size() * 4, hipMemcpyHostToDevice, ctx->st));
-    HIPC(hipMemcpyAsync(ctx->upos, upos.data(), upos.size() * 4, hipMemcpyHostToDevice, ctx->st));
+    HIPC(hipMemcpy2DAsync(d.feats, (size_t)ctx->Sp * sizeof(float), feats, (size_t)c.S * sizeof(float),
+                          (size_t)c.S * sizeof(float), (size_t)c.B * c.D, hipMemcpyHostToDevice, s));
+  HIPC(hipMemcpyAsync(d.tokens, tokens, TB * 4, hipMemcpyHostToDevice, s));
+  HIPC(hipMemcpyAsync(d.lens_d, lens, (size_t)c.B * 4, hipMemcpyHostToDevice, s));
+  if (labels) HIPC(hipMemcpyAsync(d.labels_d, labels, (size_t)c.B * 4, hipMemcpyHostToDevice, s));
+  HIPC(hipMemcpyAsync(d.utok, utok, TB * 4, hipMemcpyHostToDevice, s));
+  HIPC(hipMemcpyAsync(d.upos, upos, TB * 4, hipMemcpyHostToDevice, s));
+  HIPC(hipMemcpyAsync(d.ustart, ustart, (TB + 1) * 4, hipMemcpyHostToDevice, s));
+  return RAU_OK;
+}
+
+void make_current(rau_ctx* ctx, int si) {
+  BatchSlot& s = ctx->slot[si];
+  ctx->cur_slot = si;
+  ctx->feats = s.feats; ctx->tokens = s.tokens; ctx->lens_d = s.lens_d; ctx->labels_d = s.labels_d;
+  ctx->utok = s.utok; ctx->ustart = s.ustart; ctx->upos = s.upos;
+  ctx->lens_h = s.lens;
+  ctx->max_len = s.max_len;
+  ctx->nuniq = s.nuniq;
+  ctx->have_batch = s.have;
+  ctx->have_labels = s.have_labels;
+  ctx->fwd_done = false;
+}
+
+// second set of device buffers, pinned staging for both slots, copy stream, events
+int ensure_async(rau_ctx* ctx) {
+  if (ctx->async_ready) return RAU_OK;
+  const rau_config& c = ctx->cfg;
+  const size_t TB = (size_t)c.T * c.B, nf = (size_t)c.B * c.D * c.S;
+  BatchSlot& s0 = ctx->slot[0];
+  s0.feats = ctx->feats; s0.tokens = ctx->tokens; s0.lens_d = ctx->lens_d; s0.labels_d = ctx->labels_d;
+  s0.utok = ctx->utok; s0.ustart = ctx->ustart; s0.upos = ctx->upos;
+  s0.lens = ctx->lens_h; s0.max_len = ctx->max_len; s0.nuniq = ctx->nuniq;
+  s0.have = ctx->have_batch; s0.have_labels = ctx->have_labels;
+  BatchSlot& s1 = ctx->slot[1];
+  if (int rc = dalloc(ctx, &s1.feats, (size_t)c.B * c.D * ctx->Sp)) return rc;
+  if (int rc = dalloc(ctx, &s1.tokens, TB)) return rc;
+  if (int rc = dalloc(ctx, &s1.lens_d, (size_t)c.B)) return rc;
+  if (int rc = dalloc(ctx, &s1.labels_d, (size_t)c.B)) return rc;
+  if (int rc = dalloc(ctx, &s1.utok, TB)) return rc;
+  if (int rc = dalloc(ctx, &s1.ustart, TB + 1)) return rc;
+  if (int rc = dalloc(ctx, &s1.upos, TB)) return rc;
+  for (BatchSlot& s : ctx->slot) {
+    // one pinned block per slot: feats | tokens | lens | labels | utok | ustart | upos
+    const size_t words = nf + TB + 2 * (size_t)c.B + TB + (TB + 1) + TB;
+    void* h = nullptr;
+    hipError_t e = hipHostMalloc(&h, words * 4, hipHostMallocDefault);
+    if (e != hipSuccess) return fail(RAU_ERR_NOMEM, "hipHostMalloc(batch staging, %zu bytes): %s", words * 4,
+                                     hipGetErrorString(e));
+    s.feats_h = static_cast<float*>(h);
+    s.tokens_h = reinterpret_cast<int32_t*>(s.feats_h + nf);
+    s.lens_p = s.tokens_h + TB;
+    s.labels_h = s.lens_p + c.B;
+    s.utok_h = s.labels_h + c.B;
+    s.ustart_h = s.utok_h + TB;
+    s.upos_h = s.ustart_h + TB + 1;
+    HIPC(hipEventCreateWithFlags(&s.uploaded, hipEventDisableTiming));
+    HIPC(hipEventCreateWithFlags(&s.consumed, hipEventDisableTiming));
   }
-  HIPC(hipMemcpyAsync(ctx->ustart, ustart.data(), ustart.size() * 4, hipMemcpyHostToDevice,
-                      ctx->st));
-  HIPC(hipStreamSynchronize(ctx->st));
+  int plo = 0, phi = 0;
+  hipDeviceGetStreamPriorityRange(&plo, &phi);
+  HIPC(hipStreamCreateWithPriority(&ctx->stc, hipStreamNonBlocking, plo));
+  ctx->async_ready = true;
+  return RAU_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int rau_set_batch(rau_ctx* ctx, const float* feats, const int32_t* tokens, const int32_t* lens,
+                  const int32_t* labels) {
+  NEED(ctx && tokens && lens, "null argument");
+  const rau_config& c = ctx->cfg;
+  const size_t TB = (size_t)c.T * c.B;
+  std::vector<int32_t> utok(TB), ustart(TB + 1), upos(TB);
+  int max_len = 0, nuniq = 0;
+  if (int rc = index_batch(c, tokens, lens, labels, utok.data(), ustart.data(), upos.data(), &max_len, &nuniq))
+    return rc;
+  BatchSlot d;   // the CURRENT device buffers (slot 0 unless rau_use_batch switched)
+  d.feats = ctx->feats; d.tokens = ctx->tokens; d.lens_d = ctx->lens_d; d.labels_d = ctx->labels_d;
+  d.utok = ctx->utok; d.ustart = ctx->ustart; d.upos = ctx->upos;
+  if (ctx->async_ready && ctx->slot[ctx->cur_slot].upload_pending)   // an async upload into the same buffers
+    HIPC(hipStreamWaitEvent(ctx->st, ctx->slot[ctx->cur_slot].uploaded, 0));
+  if (int rc = enqueue_batch(ctx, ctx->st, d, feats, tokens, lens, labels, utok.data(), ustart.data(),
+                             upos.data()))
+    return rc;
+  HIPC(hipStreamSynchronize(ctx->st));   // the caller's (pageable) buffers are free on return
   ctx->lens_h.assign(lens, lens + c.B);
   ctx->max_len = max_len;
+  ctx->nuniq = nuniq;
   ctx->have_batch = true;
   ctx->have_labels = labels != nullptr;
   ctx->fwd_done = false;
+  if (ctx->async_ready) {
+    BatchSlot& s = ctx->slot[ctx->cur_slot];
+    s.lens = ctx->lens_h; s.max_len = max_len; s.nuniq = nuniq;
+    s.have = true; s.have_labels = ctx->have_labels; s.upload_pending = false;
+  }
   return RAU_OK;
 }
+
+int rau_batch_slot(rau_ctx* ctx, int slot, float** feats_host, int32_t** tokens_host,
+                   int32_t** lens_host, int32_t** labels_host) {
+  NEED(ctx, "null ctx");
+  NEED(slot == 0 || slot == 1, "rau_batch_slot: slot %d (0 or 1)", slot);
+  if (int rc = ensure_async(ctx)) return rc;
+  BatchSlot& s = ctx->slot[slot];
+  if (s.upload_pending) {   // the caller is about to overwrite the staging: its last copy must have left
+    HIPC(hipEventSynchronize(s.uploaded));
+    s.upload_pending = false;
+  }
+  if (feats_host) *feats_host = s.feats_h;
+  if (tokens_host) *tokens_host = s.tokens_h;
+  if (lens_host) *lens_host = s.lens_p;
+  if (labels_host) *labels_host = s.labels_h;
+  return RAU_OK;
+}
+
+int rau_set_batch_async(rau_ctx* ctx, int slot, const float* feats, const int32_t* tokens,
+                        const int32_t* lens, const int32_t* labels, int has_labels) {
+  NEED(ctx, "null ctx");
+  NEED(slot == 0 || slot == 1, "rau_set_batch_async: slot %d (0 or 1)", slot);
+  if (int rc = ensure_async(ctx)) return rc;
+  const rau_config& c = ctx->cfg;
+  BatchSlot& s = ctx->slot[slot];
+  if (slot == ctx->cur_slot && ctx->fwd_done)
+    return fail(RAU_ERR_STATE, "rau_set_batch_async: slot %d is the current batch of a forward pass whose "
+                "backward has not run; upload into the other slot", slot);
+  const size_t TB = (size_t)c.T * c.B, nf = (size_t)c.B * c.D * c.S;
+  const bool copies = (feats && feats != s.feats_h) || (tokens && tokens != s.tokens_h) ||
+                      (lens && lens != s.lens_p) || (labels && labels != s.labels_h);
+  if (copies && s.upload_pending) {   // staging still being read by the previous upload of this slot
+    HIPC(hipEventSynchronize(s.uploaded));
+    s.upload_pending = false;
+  }
+  // NULL = the caller has filled the slot's pinned staging in place (rau_batch_slot)
+  if (feats && feats != s.feats_h) std::memcpy(s.feats_h, feats, nf * 4);
+  if (tokens && tokens != s.tokens_h) std::memcpy(s.tokens_h, tokens, TB * 4);
+  if (lens && lens != s.lens_p) std::memcpy(s.lens_p, lens, (size_t)c.B * 4);
+  if (labels && labels != s.labels_h) std::memcpy(s.labels_h, labels, (size_t)c.B * 4);
+  const bool with_labels = labels != nullptr || has_labels != 0;
+  int max_len = 0, nuniq = 0;
+  if (int rc = index_batch(c, s.tokens_h, s.lens_p, with_labels ? s.labels_h : nullptr, s.utok_h, s.ustart_h,
+                           s.upos_h, &max_len, &nuniq))
+    return rc;
+  // device side: the slot's buffers may still be read by the last step that used them
+  if (slot == ctx->cur_slot) {
+    HIPC(hipEventRecord(s.consumed, ctx->st));
+    s.consumed_valid = true;
+  }
+  if (s.consumed_valid) HIPC(hipStreamWaitEvent(ctx->stc, s.consumed, 0));
+  if (int rc = enqueue_batch(ctx, ctx->stc, s, s.feats_h, s.tokens_h, s.lens_p,
+                             with_labels ? s.labels_h : nullptr, s.utok_h, s.ustart_h, s.upos_h))
+    return rc;
+  HIPC(hipEventRecord(s.uploaded, ctx->stc));
+  s.upload_pending = true;
+  s.lens.assign(s.lens_p, s.lens_p + c.B);
+  s.max_len = max_len;
+  s.nuniq = nuniq;
+  s.have = true;
+  s.have_labels = with_labels;
+  if (slot == ctx->cur_slot) {   // re-filled in place: the next forward waits for the copies
+    make_current(ctx, slot);
+    HIPC(hipStreamWaitEvent(ctx->st, s.uploaded, 0));
+  }
+  return RAU_OK;
+}
+
+int rau_use_batch(rau_ctx* ctx, int slot) {
+  NEED(ctx, "null ctx");
+  NEED(slot == 0 || slot == 1, "rau_use_batch: slot %d (0 or 1)", slot);
+  if (int rc = ensure_async(ctx)) return rc;
+  BatchSlot& s = ctx->slot[slot];
+  if (!s.have) return fail(RAU_ERR_STATE, "rau_use_batch: slot %d holds no batch (rau_set_batch_async)", slot);
+  if (slot != ctx->cur_slot) {
+    // everything enqueued so far may still read the slot we are leaving (the forward's bulk work is
+    // joined into the chain stream by its hop events, the backward's by its end-of-step joins)
+    BatchSlot& p = ctx->slot[ctx->cur_slot];
+    HIPC(hipEventRecord(p.consumed, ctx->st));
+    p.consumed_valid = true;
+  }
+  make_current(ctx, slot);
+  // the bulk and weight-gradient streams start each step behind an event of the chain stream,
+  // so ordering the chain stream behind the upload orders all three
+  HIPC(hipStreamWaitEvent(ctx->st, s.uploaded, 0));
+  return RAU_OK;
+}
+
 int rau_batch_feats(rau_ctx* ctx, float** feats_dev) {
   NEED(ctx && feats_dev, "null argument");
   *feats_dev = ctx->feats;
@@ -1247,9 +1435,15 @@ int rau_forward(rau_ctx* ctx) {
 // copy of step n is never overwritten by the host while step n+1's call prepares its own.
 static int upload_hop_weights(rau_ctx* ctx, const float* hop_w) {
   const int H = ctx->cfg.H;
-  float* stage = ctx->hopw_h + (size_t)(ctx->hopw_slot ^= 1) * H;
+  const int sl = (ctx->hopw_slot ^= 1);
+  float* stage = ctx->hopw_h + (size_t)sl * H;
+  // a host that runs two or more steps ahead of the device must not overwrite a staging slot whose
+  // copy has not been read yet: wait for the copy issued from this slot two calls ago
+  if (!ctx->hopw_ev[sl]) HIPC(hipEventCreateWithFlags(&ctx->hopw_ev[sl], hipEventDisableTiming));
+  else HIPC(hipEventSynchronize(ctx->hopw_ev[sl]));
   std::memcpy(stage, hop_w, (size_t)H * sizeof(float));
   HIPC(hipMemcpyAsync(ctx->hopw_d, stage, (size_t)H * sizeof(float), hipMemcpyHostToDevice, ctx->st));
+  if (!ctx->capturing) HIPC(hipEventRecord(ctx->hopw_ev[sl], ctx->st));
   return 0;
 }
 
@@ -1552,6 +1746,7 @@ int rau_graph_step(rau_ctx* ctx, const float* hop_w, int zero_grads_first) {
   uint64_t key = (uint64_t)ctx->mode | ((uint64_t)ctx->max_len << 2) | ((uint64_t)HA << 12) |
                  ((uint64_t)(zero_grads_first != 0) << 22);
   for (int i = 0; i < 5; ++i) key |= (uint64_t)ctx->mexplicit[i] << (24 + i);
+  key |= (uint64_t)ctx->cur_slot << 30;   // the captured kernels hold the batch slot's device pointers
   if (int rc = upload_hop_weights(ctx, hop_w)) return rc;
   hipGraphExec_t exec = nullptr;
   for (auto& g : ctx->graphs)

@@ -62,6 +62,7 @@ class DataClass:
         self.batch_index = 0
         self.batch_order = np.arange(self.n)
         self._job = None          # (key, thread, result holder)
+        self._next_dest = None    # SlotFeeder: where the prefetch worker assembles the next batch
 
     # ---- batch order options, loader.lua:1219-1291
     def set_batch_order_option(self, opt):
@@ -103,8 +104,13 @@ class DataClass:
                 for i, d in zip(idx, dt)]
 
     @staticmethod
-    def _load_feats(paths, D, W, H):
-        out = np.zeros((len(paths), D, W, H), np.float32)
+    def _load_feats(paths, D, W, H, out=None):
+        """Per-image feature files into one [B,D,W,H] array; `out` = a caller-owned destination
+        (the pinned staging of an upload slot: the batch is assembled where the H2D copy reads it)."""
+        if out is None:
+            out = np.zeros((len(paths), D, W, H), np.float32)
+        else:
+            out = out.reshape(len(paths), D, W, H)
         for i, p in enumerate(paths):
             out[i] = t7.load_feature(p, D, W, H).reshape(D, W, H)   # asserts the three sizes
         return out
@@ -112,10 +118,11 @@ class DataClass:
     def _start_prefetch(self, tab_featpaths, D, W, H):
         paths = self._paths(self.batch_index, tab_featpaths)
         holder = {}
+        dest = self._next_dest() if self._next_dest is not None else None
 
         def work():
             try:
-                holder["feats"] = self._load_feats(paths, D, W, H)
+                holder["feats"] = self._load_feats(paths, D, W, H, dest)
             except Exception as e:   # surfaced on the consumer side
                 holder["error"] = e
         th = threading.Thread(target=work, daemon=True)
@@ -207,3 +214,51 @@ def feed(rau, batch):
     labels = a if a.ndim == 1 else None                   # test batches carry MC ids, no labels
     rau.set_batch(feats.reshape(B, D, -1), x, x_len, labels)
     return qids
+
+
+class SlotFeeder:
+    """The loader's prefetch joined to the ctx's two upload slots (rau_batch_slot /
+    rau_set_batch_async / rau_use_batch): what SS:434-439 + vqa_prepro_loader.lua:931-958 do every
+    iteration, without a host copy or a host wait on the step's path.
+
+    The prefetch worker reads the NEXT batch's feature files straight into the pinned staging of
+    the slot the device is not using; ``next()`` (called right after the current step has been
+    enqueued) hands that slot to the copy stream -- the 100 MB transfer runs under the step still
+    executing -- makes it the resident batch for the following step, and points the worker at the
+    slot just left.  Usage::
+
+        feeder = SlotFeeder(rau, data, featdir, D, W, H)      # batch 0 resident on return
+        for it in range(n):
+            rau.forward(); rau.backward(w); ...              # enqueue step `it`
+            qids = feeder.next()                              # batch it+1 resident for the next step
+    """
+
+    def __init__(self, rau, data: DataClass, tab_featpaths, feat_dim, feat_w=1, feat_h=1):
+        self.rau, self.data = rau, data
+        self.args = (tab_featpaths, feat_dim, feat_w, feat_h)
+        self.slot = 0                  # the slot the NEXT batch is assembled in
+        data.opt_prefetch = True
+        data._job = None               # any batch prefetched before now went to ordinary memory
+        data._next_dest = lambda: self.rau.batch_slot(self.slot)["feats"]
+        self.qids = self._advance()    # batch 0: read synchronously (nothing to overlap with yet)
+
+    def _advance(self):
+        d, rau, s = self.data, self.rau, self.slot
+        view = rau.batch_slot(s)                      # (host-waits until the slot's last upload has left)
+        self.slot = s ^ 1                             # the worker started by next_batch_feat fills the other
+        feats, x, x_len, a, qids = d.next_batch_feat(*self.args)
+        if not np.shares_memory(feats, view["feats"]):   # first batch / a re-drawn order: not prefetched in place
+            view["feats"][...] = feats.reshape(view["feats"].shape)
+        view["tokens"][...] = x
+        view["lens"][...] = x_len
+        labels = a.ndim == 1                          # test batches carry MC ids, no labels
+        if labels:
+            view["labels"][...] = a
+        rau.set_batch_async(s, has_labels=labels)     # staging filled in place: no host copy
+        rau.use_batch(s)
+        return qids
+
+    def next(self):
+        """Upload the prefetched batch and make it resident; returns its question ids."""
+        self.qids = self._advance()
+        return self.qids

@@ -200,6 +200,42 @@ class RAU:
         L.check(self._lib.rau_set_batch(self._h, feats.ctypes.data, tokens.ctypes.data,
                                         lens.ctypes.data, lp))
 
+    # asynchronous, double-buffered upload (rau_batch_slot / rau_set_batch_async / rau_use_batch)
+    def batch_slot(self, slot):
+        """numpy views of slot's PINNED staging: {feats [B,D,S], tokens [T,B], lens [B], labels [B]}.
+        A loader fills them in place; set_batch_async(slot) then uploads without a host copy."""
+        c = self.cfg
+        p = [C.c_void_p() for _ in range(4)]
+        L.check(self._lib.rau_batch_slot(self._h, slot, *[C.byref(x) for x in p]))
+
+        def view(ptr, n, ct, dt, shape):
+            return np.frombuffer((ct * n).from_address(ptr.value), dtype=dt).reshape(shape)
+        return {"feats": view(p[0], c.B * c.D * c.S, C.c_float, np.float32, (c.B, c.D, c.S)),
+                "tokens": view(p[1], c.T * c.B, C.c_int32, np.int32, (c.T, c.B)),
+                "lens": view(p[2], c.B, C.c_int32, np.int32, (c.B,)),
+                "labels": view(p[3], c.B, C.c_int32, np.int32, (c.B,))}
+
+    def set_batch_async(self, slot, feats=None, tokens=None, lens=None, labels=None, has_labels=True):
+        """Enqueue the upload of a batch into `slot` on the copy stream and return.  Arrays left None
+        are taken from the slot's staging (filled in place through batch_slot)."""
+        c = self.cfg
+
+        def ptr(a, dt, n):
+            if a is None:
+                return None, None
+            a = np.ascontiguousarray(a, dt)
+            if a.size != n:
+                raise ValueError("batch shapes do not match the config")
+            return a.ctypes.data, a
+        fp, fk = ptr(feats, np.float32, c.B * c.D * c.S)
+        tp, tk = ptr(tokens, np.int32, c.T * c.B)
+        lp, lk = ptr(lens, np.int32, c.B)
+        yp, yk = ptr(labels, np.int32, c.B)
+        L.check(self._lib.rau_set_batch_async(self._h, slot, fp, tp, lp, yp, int(bool(has_labels))))
+
+    def use_batch(self, slot):
+        L.check(self._lib.rau_use_batch(self._h, slot))
+
     def forward(self):
         L.check(self._lib.rau_forward(self._h))
 

@@ -105,3 +105,53 @@ def test_prefetch_returns_the_same_batches(dataset):
         xa, xb = a.next_batch_feat(fdir, D, W, H), b.next_batch_feat(fdir, D, W, H)
         for u, w in zip(xa, xb):
             np.testing.assert_array_equal(u, w)
+
+
+class _FakeRau:
+    """Records what SlotFeeder does to the two upload slots (the device half is tested on the GPU in
+    tests/test_gpu_async_batch.py)."""
+
+    def __init__(self, B):
+        self.slots = [{"feats": np.zeros((B, D, W * H), np.float32), "tokens": np.zeros((T, B), np.int32),
+                       "lens": np.zeros(B, np.int32), "labels": np.zeros(B, np.int32)} for _ in range(2)]
+        self.log, self.uploaded = [], [None, None]
+
+    def batch_slot(self, s):
+        return self.slots[s]
+
+    def set_batch_async(self, s, has_labels=True):
+        self.log.append(("upload", s))
+        self.uploaded[s] = {k: v.copy() for k, v in self.slots[s].items()}
+        self.uploaded[s]["has_labels"] = has_labels
+
+    def use_batch(self, s):
+        self.log.append(("use", s))
+        self.current = self.uploaded[s]
+
+
+def test_slot_feeder_alternates_slots_and_prefetches_in_place(dataset):
+    """SlotFeeder = next_batch_feat's prefetch + the ctx's two pinned upload slots: batches arrive
+    in the loader's order, alternate between the slots, and from the second batch on the worker
+    has assembled the features directly in the slot's staging (no copy on the consumer side)."""
+    root, fdir, q, lens, feats = dataset
+    B = 4
+    ref = loader.load_data(str(root), batch_size=B).train_data
+    v = loader.load_data(str(root), batch_size=B)
+    rau = _FakeRau(B)
+    feeder = loader.SlotFeeder(rau, v.train_data, fdir, D, W, H)
+    for it in range(9):                                   # runs over the epoch wrap (23 examples / 4)
+        f, x, xl, a, qid = ref.next_batch_feat(fdir, D, W, H)
+        cur = rau.current
+        np.testing.assert_array_equal(cur["feats"], f.reshape(B, D, -1))
+        np.testing.assert_array_equal(cur["tokens"], x)
+        np.testing.assert_array_equal(cur["lens"], xl)
+        np.testing.assert_array_equal(cur["labels"], a)
+        np.testing.assert_array_equal(feeder.qids, qid)
+        assert rau.log[-2:] == [("upload", it & 1), ("use", it & 1)]
+        if it < 8:
+            feeder.next()
+    # test split: multiple-choice ids instead of labels
+    rau2 = _FakeRau(3)
+    v2 = loader.load_data(str(root), batch_size=4, test_batch_size=3)
+    loader.SlotFeeder(rau2, v2.test_data, fdir, D, W, H)
+    assert rau2.current["has_labels"] is False
