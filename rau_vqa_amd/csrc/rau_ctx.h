@@ -127,7 +127,8 @@ struct rau_ctx {
   uint32_t* mbits[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   size_t mcount[5] = {0, 0, 0, 0, 0};
   bool mexplicit[5] = {false, false, false, false, false};
-  float mp[5];
+  float mp[5];        // drop probability of the device's Philox masks: p quantised to 1/256
+  float mp_exact[5];  // the configured p: scale 1/(1-p) of caller-supplied masks (nn.Dropout's)
   uint64_t seed = 0;
   uint32_t step = 0;
   // encoder activations
@@ -195,6 +196,13 @@ struct rau_ctx {
   std::vector<ProfRec> precs;
   std::vector<hipEvent_t> evpool;
 };
+
+// Effective drop probability of a mask site.  Masks the device draws itself (Philox, 8-bit draws)
+// drop with p quantised to 1/256 and scale by 1/(1-pq), so that E[mask * scale] = 1 exactly;
+// caller-supplied masks (rau_set_mask) are nn.Dropout's: scale 1/(1-p) with the configured p.
+inline float mask_p(const rau_ctx* ctx, int site) {
+  return ctx->mexplicit[site] ? ctx->mp_exact[site] : ctx->mp[site];
+}
 
 template <typename Tp>
 static int dalloc(rau_ctx* c, Tp** p, size_t count) {

@@ -153,6 +153,7 @@ int rau_create(const rau_config* cfg, rau_ctx** out) {
       return fail(RAU_ERR_INVALID, "rau_create: dropout p=%f rounds to 1 at 1/256 resolution", ps[i]);
     }
     ctx->mp[i] = pq;
+    ctx->mp_exact[i] = ps[i];
   }
   *out = nullptr;
 #define CK(x)                \
@@ -985,7 +986,7 @@ int hop_forward_head(rau_ctx* ctx, hipStream_t s, float* ws, size_t reg, int h0,
   const rau_config& c = ctx->cfg;
   const int B = c.B, M = c.M, R = c.R, K = c.K;
   const bool tr = ctx->mode == RAU_MODE_TRAIN;
-  const uint32_t* m_mf = (tr && ctx->mp[RAU_MASK_MF] > 0.f) ? ctx->mbits[RAU_MASK_MF] : nullptr;
+  const uint32_t* m_mf = (tr && mask_p(ctx, RAU_MASK_MF) > 0.f) ? ctx->mbits[RAU_MASK_MF] : nullptr;
   auto gflop = [](double m, double n, double k) { return 2.0 * m * n * k; };
   const size_t BM_ = (size_t)B * M, BR_ = (size_t)B * R;
   const int rows = nh * B;
@@ -1002,7 +1003,7 @@ int hop_forward_head(rau_ctx* ctx, hipStream_t s, float* ws, size_t reg, int h0,
     o.add_rs = M;
     o.emask = m_mf;
     o.emask_e0 = (size_t)h0 * BM_;
-    o.emscale = 1.f / (1.f - ctx->mp[RAU_MASK_MF]);
+    o.emscale = 1.f / (1.f - mask_p(ctx, RAU_MASK_MF));
     RUNS(s, "head_gemm", gflop(rows, M, R), 0,
          gemm_nt(s, rows, M, R, hnew, R, ctx->lstm_out.W, R, mfh, M, o));
   }
@@ -1046,8 +1047,8 @@ int hop_backward(rau_ctx* ctx, int h, const float* cp, const float* Ih, const Ho
   const int B = c.B, S = ctx->Sp, SL = c.S, M = c.M, A = c.A, R = c.R, K = c.K;
   hipStream_t st = ctx->st;
   const bool tr = ctx->mode == RAU_MODE_TRAIN;
-  const uint32_t* m_mf = (tr && ctx->mp[RAU_MASK_MF] > 0.f) ? ctx->mbits[RAU_MASK_MF] : nullptr;
-  auto sc = [&](int site) { return 1.f / (1.f - ctx->mp[site]); };
+  const uint32_t* m_mf = (tr && mask_p(ctx, RAU_MASK_MF) > 0.f) ? ctx->mbits[RAU_MASK_MF] : nullptr;
+  auto sc = [&](int site) { return 1.f / (1.f - mask_p(ctx, site)); };
   auto gflop = [](double m, double n, double k) { return 2.0 * m * n * k; };
   const size_t BM_ = (size_t)B * M, BS_ = (size_t)B * S, BR_ = (size_t)B * R;
   const float* qf = ctx->qf + (size_t)h * BM_;
@@ -1192,9 +1193,9 @@ int rau_forward(rau_ctx* ctx) {
   if (int rc = gen_masks(ctx, RAU_MASK_X)) return rc;
   const bool tr = ctx->mode == RAU_MODE_TRAIN;
   auto mk = [&](int site) -> const uint32_t* {
-    return (tr && ctx->mp[site] > 0.f) ? ctx->mbits[site] : nullptr;
+    return (tr && mask_p(ctx, site) > 0.f) ? ctx->mbits[site] : nullptr;
   };
-  auto sc = [&](int site) { return 1.f / (1.f - ctx->mp[site]); };
+  auto sc = [&](int site) { return 1.f / (1.f - mask_p(ctx, site)); };
   const uint32_t *m_we = mk(RAU_MASK_WE), *m_rnn = mk(RAU_MASK_RNN), *m_q = mk(RAU_MASK_Q),
                  *m_x = mk(RAU_MASK_X);
   const size_t BRq = (size_t)B * Rq;
@@ -1468,9 +1469,9 @@ int rau_backward(rau_ctx* ctx, const float* hop_w) {
   hipStream_t st = ctx->st;
   const bool tr = ctx->mode == RAU_MODE_TRAIN;
   auto mk = [&](int site) -> const uint32_t* {
-    return (tr && ctx->mp[site] > 0.f) ? ctx->mbits[site] : nullptr;
+    return (tr && mask_p(ctx, site) > 0.f) ? ctx->mbits[site] : nullptr;
   };
-  auto sc = [&](int site) { return 1.f / (1.f - ctx->mp[site]); };
+  auto sc = [&](int site) { return 1.f / (1.f - mask_p(ctx, site)); };
   const uint32_t *m_we = mk(RAU_MASK_WE), *m_rnn = mk(RAU_MASK_RNN), *m_q = mk(RAU_MASK_Q);
   auto gflop = [](double m, double n, double k) { return 2.0 * m * n * k; };
   const size_t BM_ = (size_t)B * M, BS_ = (size_t)B * S, BR_ = (size_t)B * R;
@@ -1808,6 +1809,8 @@ static int d2h(rau_ctx* ctx, void* host, const void* dev, size_t bytes) {
   NEED(ctx && host, "null argument");
   HIPC(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, ctx->st));
   HIPC(hipStreamSynchronize(ctx->st));
+  if (ctx->persist_used && ctx->perr_h && *ctx->perr_h)   // same check as rau_sync: never hand back such results as OK
+    return fail(RAU_ERR_DEVICE, "persistent encoder: a grid barrier timed out (results of that step are invalid)");
   return RAU_OK;
 }
 int rau_get_losses(rau_ctx* ctx, float* losses) {

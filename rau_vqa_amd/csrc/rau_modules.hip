@@ -60,9 +60,9 @@ struct Masks {
 Masks masks_of(rau_ctx* ctx) {
   const bool tr = ctx->mode == RAU_MODE_TRAIN;
   auto mk = [&](int site) -> const uint32_t* {
-    return (tr && ctx->mp[site] > 0.f) ? ctx->mbits[site] : nullptr;
+    return (tr && mask_p(ctx, site) > 0.f) ? ctx->mbits[site] : nullptr;
   };
-  auto sc = [&](int site) { return 1.f / (1.f - ctx->mp[site]); };
+  auto sc = [&](int site) { return 1.f / (1.f - mask_p(ctx, site)); };
   return Masks{mk(RAU_MASK_WE), mk(RAU_MASK_RNN), mk(RAU_MASK_Q), mk(RAU_MASK_X), mk(RAU_MASK_MF),
                sc(RAU_MASK_WE), sc(RAU_MASK_RNN), sc(RAU_MASK_Q), sc(RAU_MASK_X), sc(RAU_MASK_MF)};
 }

@@ -158,3 +158,13 @@ def test_multfeat_wider_than_every_recurrent_width():
     dims = dict(B=18, T=6, V=25, E=20, Rq=4, D=136, S=4, M=128, A=20, R=8, K=32, H=4)
     check(util.shapes(dims), scale=0.3, mode="eval")
     check(util.shapes(dims), scale=0.3, mode="train")
+
+
+def test_explicit_masks_use_the_configured_p_not_its_1_256_quantisation():
+    """Caller-supplied masks are nn.Dropout's: kept elements are scaled by 1/(1-p) with the
+    CONFIGURED p (the device's own Philox masks quantise p to 1/256 and scale by that value, which
+    is exact for the reference's 0.5).  p = 0.3 is not a multiple of 1/256 (0.3008 after rounding:
+    a 0.1 % scale error before round 3), p = 0.001 rounds to 0 (the masks were ignored)."""
+    for p in (0.3, 0.001):
+        sh = util.shapes(util.SMALL, p_we=p, p_rnn=p, p_q=p, p_x=p, p_mf=p)
+        check(sh, scale=0.5)
