@@ -226,6 +226,37 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+
+    def h2d_leg():
+        """Fresh inputs every step (what SS:434-439 does): the batch goes through the two pinned slots
+        of the asynchronous upload, batch i+1 uploading while step i runs.  Not the metric (its timed
+        region starts with the inputs resident); reported beside it.  Every rank runs it (the steps
+        carry the gradient collective)."""
+        if args.graph:
+            return None
+        for sl in (0, 1):
+            v = m.batch_slot(sl)
+            b2 = batch if sl == 0 else synth.make_batch(cfg.B, cfg.T, cfg.V, cfg.D, cfg.S, cfg.K,
+                                                        seed=977 + rank, lens="full")
+            for k in ("feats", "tokens", "lens", "labels"):
+                v[k][...] = np.asarray(b2[k]).reshape(v[k].shape)
+        m.set_batch_async(0)
+        for i in range(3):
+            m.use_batch(i & 1)
+            m.set_batch_async((i + 1) & 1)
+            step(3000 + i)
+        fence()
+        t3 = time.perf_counter()
+        nh2d = 10
+        for i in range(nh2d):
+            m.use_batch((i + 1) & 1)
+            m.set_batch_async(i & 1)          # next batch: B*D*S*4 bytes over PCIe under this step
+            step(3100 + i)
+        fence()
+        ms = (time.perf_counter() - t3) / nh2d * 1e3
+        m.set_batch(**batch)
+        return ms
+
     for i in range(args.warmup):
         step(i)
     fence()
@@ -311,32 +342,10 @@ def main():
             m.update(step_t=i)
         fence()
         extra["step_incl_update_ms"] = (time.perf_counter() - t1) / 5 * 1e3
-        # fresh inputs every step (what SS:434-439 does): the batch goes through the two pinned slots
-        # of the asynchronous upload, batch i+1 uploading while step i runs; not the metric (its
-        # timed region starts with the inputs resident), reported beside it
-        if not args.graph:
-            for sl in (0, 1):
-                v = m.batch_slot(sl)
-                b2 = batch if sl == 0 else synth.make_batch(cfg.B, cfg.T, cfg.V, cfg.D, cfg.S, cfg.K,
-                                                            seed=977 + rank, lens="full")
-                for k in ("feats", "tokens", "lens", "labels"):
-                    v[k][...] = np.asarray(b2[k]).reshape(v[k].shape)
-            m.set_batch_async(0)
-            for i in range(3):
-                m.use_batch(i & 1)
-                m.set_batch_async((i + 1) & 1)
-                step(3000 + i)
-            fence()
-            t3 = time.perf_counter()
-            nh2d = 10
-            for i in range(nh2d):
-                m.use_batch((i + 1) & 1)
-                m.set_batch_async(i & 1)          # next batch: 103 MB over PCIe under this step
-                step(3100 + i)
-            fence()
-            extra["step_incl_h2d_ms"] = (time.perf_counter() - t3) / nh2d * 1e3
+        h2d_ms = h2d_leg()
+        if h2d_ms is not None:
+            extra["step_incl_h2d_ms"] = h2d_ms
             extra["h2d_bytes_per_step"] = int(cfg.B * cfg.D * cfg.S * 4)
-            m.set_batch(**batch)
         # inference (predict_result, SS:633-705: evaluate mode, forward only, i_embed / ifeatproj
         # hoisted out of the hop loop), reported separately
         m.evaluate()
@@ -361,6 +370,7 @@ def main():
             step(2000 + i)
             m.update(step_t=i)
         fence()
+        h2d_leg()
         m.evaluate()
         for i in range(2):
             m.forward()

@@ -26,12 +26,12 @@ static int conv_epi_dbg() {
 // remainder of 1-3 samples goes to the tiling `rest` falls back to.  RAU_CONV_WIDE_PER_CU=1|2 (A/B
 // knob): workgroups of the wide kernel per CU.
 static bool wide_on(int which) {   // RAU_CONV_WIDE=<mask>: 1 i_embed forward, 2 ifeatproj forward, 4 attention dgrad
-  static const int mask = [] { const char* e = std::getenv("RAU_CONV_WIDE"); return e ? std::atoi(e) : 7; }();
+  static const int mask = [] { const char* e = std::getenv("RAU_CONV_WIDE"); return e ? std::atoi(e) : 3; }();
   return (mask & which) != 0;
 }
 static int wide_per_cu() {
   static const int v = [] { const char* e = std::getenv("RAU_CONV_WIDE_PER_CU");
-                            const int x = e ? std::atoi(e) : 0; return x == 1 ? 1 : 2; }();
+                            const int x = e ? std::atoi(e) : 0; return x == 2 ? 2 : 1; }();
   return v;
 }
 

@@ -690,7 +690,9 @@ int enqueue_batch(rau_ctx* ctx, hipStream_t s, const BatchSlot& d, const float* 
                   const int32_t* utok, const int32_t* ustart, const int32_t* upos) {
   const rau_config& c = ctx->cfg;
   const size_t TB = (size_t)c.T * c.B;
-  if (feats)   // rows of S positions into rows of Sp (pad columns stay zero)
+  if (feats && ctx->Sp == c.S)   // dense on both sides: one linear copy (a DMA-engine transfer, no blit kernel)
+    HIPC(hipMemcpyAsync(d.feats, feats, (size_t)c.B * c.D * c.S * sizeof(float), hipMemcpyHostToDevice, s));
+  else if (feats)   // rows of S positions into rows of Sp (pad columns stay zero)
     HIPC(hipMemcpy2DAsync(d.feats, (size_t)ctx->Sp * sizeof(float), feats, (size_t)c.S * sizeof(float),
                           (size_t)c.S * sizeof(float), (size_t)c.B * c.D, hipMemcpyHostToDevice, s));
   HIPC(hipMemcpyAsync(d.tokens, tokens, TB * 4, hipMemcpyHostToDevice, s));

@@ -118,7 +118,7 @@ def test_slot_feeder_on_device_equals_synchronous_feed(dataset):   # noqa: F811
     from rau_vqa_amd import loader
     root, fdir, q, lens, feats = dataset
     B = 4
-    dims = dict(B=B, T=LT, V=9, E=8, Rq=8, D=LD, S=LW * LH, M=8, A=8, R=8, K=10, H=2)
+    dims = dict(B=B, T=LT, V=9, E=8, Rq=8, D=LD, S=LW * LH, M=8, A=8, R=8, K=12, H=2)
     hop_w = np.full(2, 2.0, np.float32)
     m = make(dims)
     ref = loader.load_data(str(root), batch_size=B).train_data
