@@ -150,6 +150,8 @@ struct rau_ctx {
   // persistent encoder forward (lstm_enc_persist): per-workgroup barrier flags, the epoch the next launch
   // starts from, a device error word (a barrier timed out) copied to pinned memory behind the launch
   bool enc_persist = false;
+  bool enc_ws = false;          // weight-stationary persistent encoder forward (enc_ws.hip)
+  unsigned* ws_cnt = nullptr;   // its 16 progress counters
   unsigned* pflags = nullptr;
   unsigned pepoch = 0;
   int* perr_d = nullptr;

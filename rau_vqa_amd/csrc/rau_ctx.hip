@@ -360,6 +360,16 @@ int rau_create(const rau_config* cfg, rau_ctx** out) {
   ctx->enc_fused_env = std::getenv("RAU_ENC_FUSED") != nullptr;
   ctx->enc_persist = std::getenv("RAU_ENC_PERSIST") != nullptr;
   {
+    // Weight-stationary persistent encoder (enc_ws.hip): chosen by shape, never by the environment in
+    // normal use -- contexts of up to 64 samples (the strong-scaling shards of configs[3]) are bound
+    // by the recurrence's launches.  RAU_ENC_WS=0|1 is the A/B override.
+    const char* e = std::getenv("RAU_ENC_WS");
+    ctx->enc_ws = enc_ws_ok(B, Rq) && (e ? std::atoi(e) != 0 : B <= 64);
+    float* f = nullptr;
+    CK(dalloc(ctx, &f, 16));
+    ctx->ws_cnt = reinterpret_cast<unsigned*>(f);
+  }
+  {
     float* f = nullptr;
     CK(dalloc(ctx, &f, (size_t)enc_persist_workgroups(B, Rq) + 2));   // zero-filled: flags, go word, error word
     ctx->pflags = reinterpret_cast<unsigned*>(f);
@@ -1231,7 +1241,20 @@ int rau_forward(rau_ctx* ctx) {
       RUN("enc_i2h_gemm", gflop(rows, 4 * Rq, E), 0,
           gemm_nt(st, rows, 4 * Rq, E, ctx->we, E, ctx->i2h[0].W, E, ctx->G1, 4 * Rq, o));
     }
-    if (ctx->enc_persist && !ctx->capturing && ctx->perr_h) {
+    if (ctx->enc_ws && ctx->perr_h) {
+      // both layers, all tokens: one launch, weights resident in registers (enc_ws.hip)
+      EncWsParams q{};
+      q.B = B; q.R = Rq; q.TL = TL;
+      q.G1 = ctx->G1; q.G2 = ctx->G2; q.h1 = ctx->h1; q.c1 = ctx->c1; q.tc1 = ctx->tc1; q.x2 = ctx->x2;
+      q.h2 = ctx->h2; q.c2 = ctx->c2; q.tc2 = ctx->tc2;
+      q.Wh1 = ctx->h2h[0].W; q.Wi2 = ctx->i2h[1].W; q.Wh2 = ctx->h2h[1].W;
+      q.bi2 = ctx->i2h[1].b; q.bh2 = ctx->h2h[1].b;
+      q.mask = m_rnn; q.mscale = sc(RAU_MASK_RNN);
+      q.cnt = ctx->ws_cnt; q.err = ctx->perr_d;
+      RUN("enc_ws", (double)TL * 3 * gflop(B, 4 * Rq, Rq), 0, enc_ws_forward(st, GATES_DEEP, q));
+      HIPC(hipMemcpyAsync(ctx->perr_h, ctx->perr_d, sizeof(int), hipMemcpyDeviceToHost, st));
+      ctx->persist_used = true;
+    } else if (ctx->enc_persist && !ctx->capturing && ctx->perr_h) {
       // the whole wavefront in one persistent launch (a captured graph would replay a stale epoch)
       EncPersistParams q{};
       q.B = B; q.R = Rq; q.TL = TL;

@@ -1,0 +1,63 @@
+"""Weight-stationary persistent encoder forward (csrc/enc_ws.hip): model/DeepLSTM.lua:29-65 unrolled
+by SS:448-462 as ONE launch -- recurrent weights in registers, per-(layer, sample half) progress
+counters instead of launches or grid barriers.  Selected by shape (contexts of up to 64 samples at
+the reference's hidden width 512); RAU_ENC_WS=1 forces it for larger batches.  Same bar as every
+other path: 1e-4 max-norm relative against the fp64 oracle on every output and every gradient (the
+backward reads the gates / cell states this kernel saves), and no barrier time-out reported."""
+import numpy as np
+import pytest
+
+from tests import util
+from tests.test_gpu_parity import check
+
+pytestmark = pytest.mark.gpu
+
+BASE = dict(T=26, V=300, E=200, Rq=512, D=64, S=196, M=64, A=32, R=64, K=40, H=2)
+
+
+@pytest.mark.parametrize("B", [16, 32, 48, 64])
+def test_weight_stationary_encoder_is_the_default_up_to_64_samples(B):
+    """B = 16 / 48: one sample part (1 / 3 blocks of 16); 32 / 64: two sample halves."""
+    check(util.shapes(dict(BASE, B=B)), scale=None, torch_oracle=True)
+
+
+def test_weight_stationary_encoder_eval_mode_and_short_questions():
+    check(util.shapes(dict(BASE, B=32, T=5)), scale=None, mode="eval", torch_oracle=True)
+    check(util.shapes(dict(BASE, B=32, T=1)), scale=None, torch_oracle=True)
+
+
+@pytest.mark.parametrize("B", [96, 256])
+def test_weight_stationary_encoder_forced_at_larger_batches(monkeypatch, B):
+    monkeypatch.setenv("RAU_ENC_WS", "1")
+    check(util.shapes(dict(BASE, B=B, T=12)), scale=None, torch_oracle=True)
+
+
+def test_weight_stationary_encoder_is_deterministic_and_matches_the_launch_per_step_path(monkeypatch):
+    """Same seeded step three times (a hand-off race would show as a run that differs), then the
+    same step on the launch-per-step encoder (RAU_ENC_WS=0): equal within f32 summation-order noise."""
+    from rau_vqa_amd import synth
+    from rau_vqa_amd.model import RAU, Config
+    dims = dict(BASE, B=64, T=26)
+
+    def run(n):
+        m = RAU(Config(**dims))
+        m.init_uniform(seed=3)
+        m.set_batch(**synth.make_batch(64, 26, 300, 64, 196, 40, seed=4, lens="ragged"))
+        m.training()
+        outs = []
+        for _ in range(n):
+            m.set_dropout_seed(9, 2)
+            m.zero_grads()
+            m.forward()
+            q = m.question_state()
+            m.backward(np.full(2, 2.0, np.float32))
+            outs.append((q, m.get_grads()["rnn"]))
+        m.close()
+        return outs
+
+    a = run(3)
+    for q, g in a[1:]:
+        assert np.array_equal(q, a[0][0]) and np.array_equal(g, a[0][1])
+    monkeypatch.setenv("RAU_ENC_WS", "0")
+    (q0, g0), = run(1)
+    assert util.rel_err(a[0][0], q0) < 1e-5 and util.rel_err(a[0][1], g0) < 1e-5
