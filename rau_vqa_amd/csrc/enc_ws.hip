@@ -45,7 +45,8 @@ constexpr int ESTAGE = 2 * ESLOT;     // a stage = two slots (33792 bytes)
 constexpr int EOUTG = 16 * 64;        // activated gates of a 16-sample block: [sample][gate][16 units]
 constexpr int EOUTV = 16 * 16;        // h | x2 | c | tanh c: [sample][16 units]
 constexpr int EHAND = 2 * 4 * 64;     // kind B: partial sums of the h2-half waves, [tile][reg][lane]
-constexpr int ESMEM = 2 * ESTAGE + EOUTG + 4 * EOUTV + EHAND;   // 19456 floats = 77824 bytes
+constexpr int EOUT = EOUTG + 4 * EOUTV;   // one block's output tile (2048 floats)
+constexpr int ESMEM = 2 * ESTAGE + EOUT + EHAND;   // 19456 floats = 77824 bytes: fits a CU beside one wide conv tile
 constexpr int kWsSpinMax = 1 << 22;
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -123,9 +124,8 @@ __device__ __forceinline__ void enc_ws_body(const EncWsParams& Q, const int wg, 
   float bias = 0.f;
   if (KIND_B) bias = Q.bi2[qslot * ER + U0 + uw + u] + Q.bh2[qslot * ER + U0 + uw + u];
 
-  float* outg = smem + 2 * ESTAGE;
-  float* outv = outg + EOUTG;           // h, x2, c, tanh c
-  float* hand = outv + 4 * EOUTV;
+  float* outg = smem + 2 * ESTAGE;      // [gates | h | x2 | c | tanh c]
+  float* hand = outg + EOUT;
   unsigned* cnt1 = Q.cnt + part;        // layer-1 cells done, this sample half
   unsigned* cnt2 = Q.cnt + 8 + part;    // layer-2 cells done
   const unsigned nA = ER / 16, nB = ER / 8;   // workgroups per (layer, sample half)
@@ -137,13 +137,15 @@ __device__ __forceinline__ void enc_ws_body(const EncWsParams& Q, const int wg, 
       const int rr = 8 * w + i, slot = rr >> 4, r = rr & 15;
       const float* src = (slot ? src1 + k1 : src0 + k0) + (size_t)(row0 + r) * ER + 4 * l;
       __builtin_amdgcn_global_load_lds((glb_ptr_t)src,
-                                       (lds_ptr_t)(smem + buf * ESTAGE + slot * ESLOT + r * EPITCH), 16, 0, 0);
+                                       (lds_ptr_t)(smem + buf * ESTAGE + slot * ESLOT + r * EPITCH), 16, 0, 16 /* sc1 */);
     }
   };
 
 #pragma unroll 1
   for (int t = 1; t <= Q.TL; ++t) {
-    // ---- dependencies of cell t of this layer
+    // ---- dependencies of cell t of this layer.  No acquire behind the poll: every h / x2 row is
+    // written once per launch, at an address no CU has read in this launch, with write-through
+    // (sc1) stores, and is read below by sc1 loads (LDS-DMA, L1-bypassing) only.
     if (tid == 0) {
       if (!KIND_B) {
         if (t > 1) wait_counter(cnt1, nA * (unsigned)(t - 1), Q.err);       // h1[t-1]
@@ -151,8 +153,6 @@ __device__ __forceinline__ void enc_ws_body(const EncWsParams& Q, const int wg, 
         wait_counter(cnt1, nA * (unsigned)t, Q.err);                         // x2[t]
         if (t > 1) wait_counter(cnt2, nB * (unsigned)(t - 1), Q.err);       // h2[t-1]
       }
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __syncthreads();
     const float* h1p = Q.h1 + (size_t)(t - 1) * BR;      // h1[t-1]
@@ -171,9 +171,35 @@ __device__ __forceinline__ void enc_ws_body(const EncWsParams& Q, const int wg, 
       if (!KIND_B) issue_stage(s & 1, h1p, h1p, 0, EKC, b0 + 16 * s);
       else issue_stage(s & 1, x2t, h2p, EKC * (s & 1), EKC * (s & 1), b0 + 16 * (s >> 1));
     };
+    // a finished block's outputs leave in 16-byte pieces of 4 consecutive units, one block LATE: its
+    // stores are issued in front of the next block's MFMAs, so that the wait for a stage (which is
+    // a wait for everything this wave has in flight) finds them long done
+    auto flush = [&](int sb) {
+      const float* og = outg;
+      const float* ov = og + EOUTG;
+      const int bs = b0 + 16 * sb;
+      constexpr int NU4 = KIND_B ? 2 : 4;                 // 16-byte pieces per sample row of the workgroup
+      const int sg = tid >> 4, qq = (tid >> 2) & 3, u4 = tid & 3;
+      if (u4 < NU4) {
+        const int gs = qq == 0 ? GS::I : qq == 1 ? GS::F : qq == 2 ? GS::O : GS::G;
+        const float4 v = *reinterpret_cast<const float4*>(og + (sg * 4 + qq) * 16 + 4 * u4);
+        *reinterpret_cast<float4*>(gates + (size_t)(bs + sg) * 4 * ER + gs * ER + U0 + 4 * u4) = v;
+      }
+      const int arr = tid >> 6, idx = tid & 63, s2 = idx >> 2, v4 = idx & 3;
+      if (v4 < NU4 && !(KIND_B && arr == 1)) {
+        const float4 v = *reinterpret_cast<const float4*>(ov + arr * EOUTV + s2 * 16 + 4 * v4);
+        const size_t e = (size_t)(bs + s2) * ER + U0 + 4 * v4;
+        if (arr == 0) { store_sc1(h_out + e, v.x, v.y); store_sc1(h_out + e + 2, v.z, v.w); }
+        else if (arr == 1) { store_sc1(x2_out + e, v.x, v.y); store_sc1(x2_out + e + 2, v.z, v.w); }
+        else if (arr == 2) *reinterpret_cast<float4*>(c_out + e) = v;
+        else *reinterpret_cast<float4*>(tc_out + e) = v;
+      }
+    };
     const int nst = KIND_B ? 2 * nsb : nsb;
     issue(0);
     f32x4 acc0, acc1;
+    const uint32_t lds0 = (uint32_t)(size_t)(lds_ptr_t)smem;
+    const uint32_t afrag = lds0 + (uint32_t)(col * EPITCH + 4 * g) * 4;   // row = sample `col` of the block
 #pragma unroll 1
     for (int sb = 0; sb < nsb; ++sb) {
       const int bs = b0 + 16 * sb;                        // first sample of the block
@@ -212,14 +238,13 @@ __device__ __forceinline__ void enc_ws_body(const EncWsParams& Q, const int wg, 
           __builtin_amdgcn_sched_barrier(0);
         });
       };
-      const uint32_t lds0 = (uint32_t)(size_t)(lds_ptr_t)smem;
-      const uint32_t afrag = lds0 + (uint32_t)(col * EPITCH + 4 * g) * 4;   // row = sample `col` of the block
       using I0 = std::integral_constant<int, 0>;
       using I16 = std::integral_constant<int, 16>;
       if (!KIND_B) {
         const int s = sb;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of stage s has landed
-        __syncthreads();                                   // everyone's has; stage s-1 and the out tiles are free
+        __syncthreads();                                   // everyone's has; stage s-1 and block sb-1's out tile are done
+        if (sb > 0) flush(sb - 1);
         if (s + 1 < nst) issue(s + 1);
         const uint32_t st = afrag + (uint32_t)((s & 1) * ESTAGE) * 4;
         mma_slot(I0{}, st);
@@ -230,6 +255,7 @@ __device__ __forceinline__ void enc_ws_body(const EncWsParams& Q, const int wg, 
           const int s = 2 * sb + c;
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
           __syncthreads();
+          if (c == 0 && sb > 0) flush(sb - 1);
           if (s + 1 < nst) issue(s + 1);
           const uint32_t st = afrag + (uint32_t)((s & 1) * ESTAGE + half * ESLOT) * 4;
           if (c == 0) mma_slot(I0{}, st); else mma_slot(I16{}, st);
@@ -248,15 +274,19 @@ __device__ __forceinline__ void enc_ws_body(const EncWsParams& Q, const int wg, 
           for (int r = 0; r < 4; ++r) acc[r] += hand[((w >> 1) * 4 + r) * 64 + l];
         }
         cell = !half;
+      } else {
+        __syncthreads();   // every wave has long read block sb-1's tile (flush sits in front of the MFMAs)
       }
       if (cell) {
         // lane (unit u, gate q) holds that gate's pre-activation for samples 4 g + r of the block
+        float* og = outg;
+        float* ov = og + EOUTG;
         float act[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const float x = acc[r] + pre[r];
           act[r] = q == 3 ? tanh_fast(x) : sigmoidf_(x);
-          outg[((4 * g + r) * 4 + q) * 16 + uw + u] = act[r];
+          og[((4 * g + r) * 4 + q) * 16 + uw + u] = act[r];
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -267,42 +297,25 @@ __device__ __forceinline__ void enc_ws_body(const EncWsParams& Q, const int wg, 
           const float hn = go * tc;
           if (q == 0) {
             const int o = (4 * g + r) * 16 + uw + u;
-            outv[o] = hn;
-            outv[2 * EOUTV + o] = cn;
-            outv[3 * EOUTV + o] = tc;
+            ov[o] = hn;
+            ov[2 * EOUTV + o] = cn;
+            ov[3 * EOUTV + o] = tc;
             if (!KIND_B) {
               float xv = hn;
               if (Q.mask) {
                 const size_t e = (size_t)(t - 1) * BR + (size_t)(bs + 4 * g + r) * ER + U0 + uw + u;
                 xv = mask_bit(Q.mask, e) ? hn * Q.mscale : 0.f;
               }
-              outv[EOUTV + o] = xv;
+              ov[EOUTV + o] = xv;
             }
           }
         }
       }
-      __syncthreads();
-      // ---- the block's outputs leave in 16-byte pieces of 4 consecutive units
-      {
-        constexpr int NU4 = KIND_B ? 2 : 4;               // 16-byte pieces per sample row of the workgroup
-        const int s = tid >> 4, qq = (tid >> 2) & 3, u4 = tid & 3;
-        if (u4 < NU4) {
-          const int gs = qq == 0 ? GS::I : qq == 1 ? GS::F : qq == 2 ? GS::O : GS::G;
-          const float4 v = *reinterpret_cast<const float4*>(outg + (s * 4 + qq) * 16 + 4 * u4);
-          *reinterpret_cast<float4*>(gates + (size_t)(bs + s) * 4 * ER + gs * ER + U0 + 4 * u4) = v;
-        }
-        const int arr = tid >> 6, idx = tid & 63, s2 = idx >> 2, v4 = idx & 3;
-        if (v4 < NU4 && !(KIND_B && arr == 1)) {
-          const float4 v = *reinterpret_cast<const float4*>(outv + arr * EOUTV + s2 * 16 + 4 * v4);
-          const size_t e = (size_t)(bs + s2) * ER + U0 + 4 * v4;
-          if (arr == 0) { store_sc1(h_out + e, v.x, v.y); store_sc1(h_out + e + 2, v.z, v.w); }
-          else if (arr == 1) { store_sc1(x2_out + e, v.x, v.y); store_sc1(x2_out + e + 2, v.z, v.w); }
-          else if (arr == 2) *reinterpret_cast<float4*>(c_out + e) = v;
-          else *reinterpret_cast<float4*>(tc_out + e) = v;
-        }
-      }
     }
-    // ---- publish: every storing wave drains, then ONE lane counts the workgroup in
+    // ---- the last block's outputs, then publish: every storing wave drains, ONE lane counts the
+    // workgroup in
+    __syncthreads();
+    flush(nsb - 1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) __hip_atomic_fetch_add(KIND_B ? cnt2 : cnt1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -29,10 +29,10 @@ static bool wide_on(int which) {   // RAU_CONV_WIDE=<mask>: 1 i_embed forward, 2
   static const int mask = [] { const char* e = std::getenv("RAU_CONV_WIDE"); return e ? std::atoi(e) : 3; }();
   return (mask & which) != 0;
 }
-static int wide_per_cu() {
-  static const int v = [] { const char* e = std::getenv("RAU_CONV_WIDE_PER_CU");
-                            const int x = e ? std::atoi(e) : 0; return x == 2 ? 2 : 1; }();
-  return v;
+static int wide_per_cu(int which) {   // RAU_CONV_WIDE_PER_CU=<f><d>: workgroups per CU of the forward convs / the dgrad
+  static const int v = [] { const char* e = std::getenv("RAU_CONV_WIDE_PER_CU"); return e ? std::atoi(e) : 12; }();
+  const int d = which == 4 ? v % 10 : (v >= 10 ? v / 10 : v);
+  return d == 2 ? 2 : 1;
 }
 
 hipError_t conv_embed_fwd(hipStream_t st, int nB, int D, int S, int M, const float* X,
@@ -49,7 +49,7 @@ hipError_t conv_embed_fwd(hipStream_t st, int nB, int D, int S, int M, const flo
   if (!bf16 && wide_on(1) && conv_wide_ok(M, D, S, M) && nB >= 4) {
     const int n4 = nB & ~3;
     hipError_t e = conv_wide(st, 0, n4, M, D, S, WiT, M, X, (long)D * S, I, (long)M * S, bi, 1, nullptr,
-                             nullptr, nullptr, nullptr, 0, one_per_cu ? 1 : wide_per_cu());
+                             nullptr, nullptr, nullptr, 0, one_per_cu ? 1 : wide_per_cu(1));
     if (e != hipSuccess || n4 == nB) return e;
     return conv_embed_fwd(st, nB - n4, D, S, M, X + (size_t)n4 * D * S, WiT, bi, I + (size_t)n4 * M * S,
                           bf16, one_per_cu);
@@ -105,7 +105,7 @@ hipError_t conv_att_pre(hipStream_t st, int nB, int M, int S, int A, const float
   if (!bf16 && wide_on(2) && conv_wide_ok(A, M, S, A) && nB >= 4) {
     const int n4 = nB & ~3;
     hipError_t e = conv_wide(st, 0, n4, A, M, S, WpT, A, I, (long)M * S, Pout, (long)A * S, bp, 0, nullptr,
-                             nullptr, nullptr, nullptr, 0, one_per_cu ? 1 : wide_per_cu());
+                             nullptr, nullptr, nullptr, 0, one_per_cu ? 1 : wide_per_cu(2));
     if (e != hipSuccess || n4 == nB) return e;
     return conv_att_pre(st, nB - n4, M, S, A, I + (size_t)n4 * M * S, WpT, bp, Pout + (size_t)n4 * A * S,
                         bf16, one_per_cu);
@@ -150,7 +150,7 @@ hipError_t conv_att_dgrad_dz(hipStream_t st, int nB, int M, int S, int A, const 
   if (wide_on(4) && conv_wide_ok(M, A, S, M) && nB >= 4) {
     n4 = nB & ~3;
     hipError_t e = conv_wide(st, 2, n4, M, A, S, Wp, M, dS, (long)A * S, dZ, (long)M * S, nullptr, 0, dj, a,
-                             I, rs, dz16, wide_per_cu());
+                             I, rs, dz16, wide_per_cu(4));
     if (e != hipSuccess || n4 == nB) return e;
   }
   // remainder (or all of it): one sample per tile; dZ advances in its stored element size

@@ -368,16 +368,16 @@ hipError_t lstm_bwd_multi(hipStream_t st, int order, int nB, int R, const LstmBw
 // Wave w owns rows w, w+NW, ...; lane l owns the float4 column groups l, l+64, ...
 // Cross-wave sums go through LDS and are added in wave order (deterministic).
 // waves per sample: 16 streams a sample fastest when the kernel has the GPU to itself, but a
-// 16-wave workgroup needs 4 x its VGPRs per SIMD and cannot start next to two resident
-// bulk-GEMM workgroups (2 x 144..168 of 512 VGPRs): it then waits for a bulk tile to retire.
-// Measured in the overlapped step: forward 0.94 ms with 16 waves vs 1.14 with 8; backward 1.00 ms
-// with 8 vs 1.07-1.25 with 16 (it runs next to the 160-VGPR weight-gradient GEMMs) -- but the
-// backward phase is throughput-bound, the step does not move (11.2-11.3 ms either way), so both
-// stay at 16.  RAU_ATT_WAVES_FWD / RAU_ATT_WAVES_BWD (4, 8 or 16) override.
+// 16-wave workgroup needs 4 x its VGPRs per SIMD.  Round 3: the forward convs beside it are the
+// wide tiles at ONE workgroup per CU (255 VGPRs on every SIMD), so what is left for the recurrence's
+// kernels is 257 VGPRs per SIMD: the forward kernel's 4 x 102 do not fit and its workgroups waited
+// for conv tiles (130 us each) to retire -- 117-265 us per launch in the step against 52 alone.
+// With 8 waves (2 x 104) it starts at once: 10.02 -> 9.78 ms per step.  The backward kernel (48
+// VGPRs) fits either way and stays at 16.  RAU_ATT_WAVES_FWD / RAU_ATT_WAVES_BWD (4, 8 or 16) override.
 static int att_waves(bool bwd) {
   static const int v[2] = {
       [] { const char* e = std::getenv("RAU_ATT_WAVES_FWD"); const int n = e ? std::atoi(e) : 0;
-           return (n == 4 || n == 8 || n == 16) ? n : 16; }(),
+           return (n == 4 || n == 8 || n == 16) ? n : 8; }(),
       [] { const char* e = std::getenv("RAU_ATT_WAVES_BWD"); const int n = e ? std::atoi(e) : 0;
            return (n == 4 || n == 8 || n == 16) ? n : 16; }()};
   return v[bwd ? 1 : 0];
