@@ -526,11 +526,197 @@ __global__ __launch_bounds__(NW * 64) void k_att_fwd_fused(
     }
   }
 }
+// ---- the same forward pass with its two row streams (P and I, 200 + 400 KB per sample at the
+// reference's sizes) brought in by LDS-DMA (round 3).  The register-staged kernel above keeps
+// kAttLoads rows per wave in flight in VGPRs: 25-50 KB per compute unit, which beside a resident
+// conv tile (memory latency of several microseconds) bounds it at ~140 us per launch in the step
+// against 52 us alone -- and more rows in flight means more registers, i.e. a workgroup that no
+// longer fits next to the conv tile at all.  Here every wave owns a private ring of D row slots in
+// LDS: `global_load_lds` fills slot (i + D) % D while row i is consumed, no staging registers, no
+// barrier (nobody else reads a wave's ring), ~48 VGPRs per wave.  Per-row scalars (u[k], ws[k]) sit
+// in one register per lane and are broadcast with v_readlane; results (jv) likewise collect in a
+// lane each and leave in one store at the end: no other memory instruction inside the streaming
+// loops, so the only vmcnt traffic is the ring's and the counted waits are exact.
+// The LDS reads of the ring are inline asm: hipcc would wait vmcnt(0) -- draining the ring -- in
+// front of every LDS read it can see while a DMA is in flight.
+typedef __attribute__((address_space(3))) void* att_lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* att_glb_ptr_t;
+
+template <int NW, int D>
+__global__ __launch_bounds__(NW * 64) void k_att_fwd_dma(
+    int M, int A, int S, const float* __restrict__ P, const float* __restrict__ u,
+    const float* __restrict__ ws, const float* __restrict__ bs, const float* __restrict__ zm,
+    const float* __restrict__ I, const float* __restrict__ qf, float* __restrict__ a,
+    float* __restrict__ jv, AttPartials ap) {
+  RAU_CHAIN_PRIO();
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* red = sm;                     // [NW][S]
+  float* as = sm + NW * S;             // [S]
+  float* sc = as + S;                  // [2*NW] block scalars
+  float* us = sc + 2 * NW;             // [A]
+  float* zs = us + A;                  // [S]
+  float* ring = zs + S;                // [NW][D][S] (+ slack: lanes past S/4 read beyond a slot)
+  const int b = blockIdx.x, tid = threadIdx.x, l = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int S4 = S >> 2;
+  const float* Pb = P + (size_t)b * A * S;
+  const float* ub = u + (size_t)b * A;
+  if (ap.u_ns) {
+    for (int k = tid; k < A; k += NW * 64) {
+      float v = ap.u_bias[k];
+      for (int sp = 0; sp < ap.u_ns; ++sp) v += u[((size_t)sp * gridDim.x + b) * A + k];
+      us[k] = v;
+    }
+  }
+  const int SL = ap.SL > 0 ? ap.SL : S;   // logical positions; [SL, S) are pad columns
+  if (ap.z_ns) {
+    for (int s = tid; s < SL; s += NW * 64) {
+      float v = ap.z_bias[s];
+      for (int sp = 0; sp < ap.z_ns; ++sp) v += zm[((size_t)sp * gridDim.x + b) * SL + s];
+      zs[s] = v;
+    }
+  }
+  if (ap.u_ns || ap.z_ns) __syncthreads();
+  if (ap.u_out)
+    for (int k = tid; k < A; k += NW * 64) ap.u_out[(size_t)b * A + k] = ap.u_ns ? us[k] : ub[k];
+
+  float* myring = ring + (size_t)w * D * S;
+  const uint32_t ring_b = (uint32_t)(size_t)(att_lds_ptr_t)myring + (uint32_t)l * 16;
+  const bool lane_on = l < S4;
+  // row i of this wave = row w + NW * i of the tile at `base`; its slot is i % D
+  auto dma_row = [&](const float* base, int i) {
+    if (lane_on)
+      __builtin_amdgcn_global_load_lds((att_glb_ptr_t)(base + (size_t)(w + NW * i) * S + 4 * l),
+                                       (att_lds_ptr_t)(myring + (i % D) * S), 16, 0, 0);
+  };
+  auto ring_read = [&](int i) {
+    float4 v;
+    asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(ring_b + (uint32_t)((i % D) * S) * 4) : "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return v;
+  };
+
+  // ---- phase 1: e[s] = sum_k ws[k] tanh(P[k,s] + u[k]); lane j holds (u, ws) of the wave's row j
+  {
+    const int nrows = w < A ? (A - w + NW - 1) / NW : 0;
+    float urow = 0.f, wrow = 0.f;
+    if (l < nrows) {
+      const int k = w + NW * l;
+      urow = ap.u_ns ? us[k] : ub[k];
+      wrow = ws[k];
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // nothing of the above counts below
+    for (int i = 0; i < D && i < nrows; ++i) dma_row(Pb, i);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 1
+    for (int i = 0; i < nrows; ++i) {
+      // rows i+1 .. i+D-1 may still be in flight (fewer at the tail)
+      if (i + D <= nrows) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(D - 1) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const float4 p = ring_read(i);
+      if (i + D < nrows) dma_row(Pb, i + D);       // the slot just read is free again
+      const float uk = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, urow), i));
+      const float wk = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wrow), i));
+      if (lane_on) {
+        acc.x += wk * tanh_fast(p.x + uk); acc.y += wk * tanh_fast(p.y + uk);
+        acc.z += wk * tanh_fast(p.z + uk); acc.w += wk * tanh_fast(p.w + uk);
+      }
+    }
+    if (lane_on) reinterpret_cast<float4*>(red + (size_t)w * S)[l] = acc;
+  }
+  __syncthreads();
+  // ---- phase 2: a = softmax(e + bs + zm)   (as in k_att_fwd_fused)
+  float mx = -INFINITY;
+  for (int s = tid; s < S; s += (NW * 64)) {
+    float z = -INFINITY;
+    if (s < SL) {
+      const float zmv = ap.z_ns ? zs[s] : zm[(size_t)b * S + s];
+      z = block_sum_ordered<NW>(red, S, s) + bs[0] + zmv;
+    }
+    as[s] = z;
+    mx = fmaxf(mx, z);
+  }
+  mx = wave_max(mx);
+  if (l == 0) sc[w] = mx;
+  __syncthreads();
+  mx = sc[0];
+#pragma unroll
+  for (int i = 1; i < NW; ++i) mx = fmaxf(mx, sc[i]);
+  float den = 0.f;
+  for (int s = tid; s < S; s += (NW * 64)) {
+    const float ex = expf(as[s] - mx);
+    as[s] = ex;
+    den += ex;
+  }
+  den = wave_sum(den);
+  if (l == 0) sc[NW + w] = den;
+  __syncthreads();
+  den = sc[NW];
+#pragma unroll
+  for (int i = 1; i < NW; ++i) den += sc[NW + i];
+  const float inv = 1.f / den;
+  for (int s = tid; s < S; s += (NW * 64)) {
+    const float v = as[s] * inv;
+    as[s] = v;
+    a[(size_t)b * S + s] = v;
+  }
+  __syncthreads();
+  // ---- phase 3: jv[m] = qf[m] + sum_s I[m,s] a[s]; lane j collects the wave's row j
+  {
+    const float* Ib = I + (size_t)b * M * S;
+    const int nrows = w < M ? (M - w + NW - 1) / NW : 0;
+    float4 av = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (lane_on) av = reinterpret_cast<const float4*>(as)[l];
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    for (int i = 0; i < D && i < nrows; ++i) dma_row(Ib, i);
+    float res = 0.f;
+#pragma unroll 1
+    for (int i = 0; i < nrows; ++i) {
+      if (i + D <= nrows) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(D - 1) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const float4 x = ring_read(i);
+      if (i + D < nrows) dma_row(Ib, i + D);
+      float part = lane_on ? (x.x * av.x + x.y * av.y) + (x.z * av.z + x.w * av.w) : 0.f;
+      part = wave_sum(part);
+      if (l == i) res = part;
+    }
+    if (l < nrows) {
+      const size_t e = (size_t)b * M + w + NW * l;
+      jv[e] = res + qf[e];
+    }
+  }
+}
+
 hipError_t att_fwd_fused(hipStream_t st, int nB, int M, int A, int S, const float* P,
                          const float* u, const float* ws, const float* bs, const float* zm,
                          const float* I, const float* qf, float* T, float* a, float* jv,
                          const AttPartials& ap) {
   const int nw = att_waves(false);
+  // 14 x 14 (and any S % 4 == 0, S <= 256) maps on the step path (tanh(P + u) not kept): the LDS-DMA kernel
+  static const bool dma_off = std::getenv("RAU_ATT_DMA_OFF") != nullptr;   // A/B knob
+  if (!dma_off && !T && S % 4 == 0 && S <= 256 && A <= 64 * 8 && M <= 64 * 8 && (nw == 8 || nw == 16)) {
+    constexpr int kD8 = 8, kD16 = 4;
+    const int d = nw == 8 ? kD8 : kD16;
+    const size_t ldsd = ((size_t)(nw + 2) * S + 2 * nw + A + (size_t)nw * d * S + 256) * sizeof(float);
+    static bool attr = false;
+    if (!attr) {
+      hipFuncSetAttribute(reinterpret_cast<const void*>(k_att_fwd_dma<8, kD8>),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+      hipFuncSetAttribute(reinterpret_cast<const void*>(k_att_fwd_dma<16, kD16>),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+      attr = true;
+    }
+    if (ldsd <= 96 * 1024) {
+      if (nw == 8)
+        hipLaunchKernelGGL((k_att_fwd_dma<8, kD8>), dim3(nB), dim3(512), ldsd, st, M, A, S, P, u, ws, bs, zm, I,
+                           qf, a, jv, ap);
+      else
+        hipLaunchKernelGGL((k_att_fwd_dma<16, kD16>), dim3(nB), dim3(1024), ldsd, st, M, A, S, P, u, ws, bs, zm,
+                           I, qf, a, jv, ap);
+      return hipGetLastError();
+    }
+  }
   const size_t lds = ((size_t)(nw + 2) * S + 2 * nw + A) * sizeof(float);
 #define ATT_FWD(NW_) hipLaunchKernelGGL(k_att_fwd_fused<NW_>, dim3(nB), dim3(NW_ * 64), lds, st, M, A, \
                                         S, P, u, ws, bs, zm, I, qf, T, a, jv, ap)
