@@ -299,7 +299,7 @@ def main():
         # FETCH_SIZE doubled per the gfx950 correction) when one exists for this kernel and shape
         traffic, traffic_src = None, None
         shape = (args.batch, args.D, args.dtype)
-        for rnd in ("r02", "r01"):
+        for rnd in ("r03", "r02", "r01"):
             tag = {(256, 512, "f32"): rnd, (256, 2048, "bf16"): rnd + "_bf16"}.get(shape)
             pmc = os.path.join(ROOT, "profiles", f"{tag}_pmc_{dom_name}.json")
             if tag and os.path.exists(pmc):

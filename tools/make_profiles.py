@@ -45,8 +45,10 @@ def classify(rows):
     names = [short(r["Kernel_Name"]) for r in rows]
     grids = [int(r["Grid_Size"]) // 256 for r in rows]
     out = [None] * len(rows)
+    # round 3: the forward convs run on the wide tiling (conv_wide.hip, k_conv_wide<0>); the
+    # flattened-column kernel only takes what the wide one does not (other map sizes, remainders)
     fwd = "gemm_kernel<128, 128, 32, 1, 2, 2, 0>"
-    fwd_idx = [i for i, n in enumerate(names) if n == fwd]
+    fwd_idx = [i for i, n in enumerate(names) if n == fwd or n.startswith("k_conv_wide<0>")]
     for pos, i in enumerate(fwd_idx):
         g = grids[i]
         # in stream order every conv_embed_fwd launch is followed by its conv_att_pre launch
@@ -69,8 +71,8 @@ def classify(rows):
         for pos, i in enumerate(plain):
             out[i] = ("conv_att_wgrad" if pos % 2 == 0 else "conv_embed_wgrad", None)
     for i, n in enumerate(names):
-        if n.startswith("k_conv_sample<1>") or n.startswith("k_conv_sample<2>") or \
-                n == "gemm_kernel<128, 128, 32, 1, 2, 3, 0>":
+        if n.startswith("k_conv_sample<1") or n.startswith("k_conv_sample<2") or \
+                n.startswith("k_conv_wide<2>") or n == "gemm_kernel<128, 128, 32, 1, 2, 3, 0>":
             out[i] = ("conv_att_dgrad", None)
     return out
 
@@ -108,7 +110,7 @@ alg_per_hop = {
 }
 # workgroups per hop where the grid scales with the hops of a launch (else: 1.6 hops per launch
 # on average with hop groups 2,2,2,1,1)
-wg_per_hop = {"conv_embed_fwd": 1568, "conv_att_pre": 784, "conv_att_dgrad": 1024}
+wg_per_hop = {"conv_embed_fwd": 512, "conv_att_pre": 256, "conv_att_dgrad": 1024}   # wide tiles: (M/64) x (B/4) per hop
 pmc_json = {}
 for cls, by_wg in traffic.items():
     launches = []
