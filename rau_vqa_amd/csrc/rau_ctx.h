@@ -150,7 +150,8 @@ struct rau_ctx {
   // persistent encoder forward (lstm_enc_persist): per-workgroup barrier flags, the epoch the next launch
   // starts from, a device error word (a barrier timed out) copied to pinned memory behind the launch
   bool enc_persist = false;
-  bool enc_ws = false;          // weight-stationary persistent encoder forward (enc_ws.hip)
+  bool enc_ws = false;          // weight-stationary persistent encoder forward (enc_ws.hip): evaluate mode
+  bool enc_ws_train = false;    // ... and in training steps
   unsigned* ws_cnt = nullptr;   // its 16 progress counters
   unsigned* pflags = nullptr;
   unsigned pepoch = 0;

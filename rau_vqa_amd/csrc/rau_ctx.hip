@@ -364,6 +364,11 @@ int rau_create(const rau_config* cfg, rau_ctx** out) {
     // normal use -- contexts of up to 64 samples (the strong-scaling shards of configs[3]) are bound
     // by the recurrence's launches.  RAU_ENC_WS=0|1 is the A/B override.
     const char* e = std::getenv("RAU_ENC_WS");
+    // measured in the step (MS weights, same box): B = 16 / 32 / 64 -> 3.00 / 3.49 / 4.46 ms with it,
+    // 3.16 / 3.52 / 4.26 without; evaluate-mode forward 14.3 / 26.8 / 45.9 k vs 10.8 / 20.8 / 40.4 k QA/s.
+    // Every workgroup reads all h rows of its sample half each step, so the traffic grows with B while
+    // the weights it avoids re-reading do not: training contexts up to 32 samples, inference up to 64.
+    ctx->enc_ws_train = enc_ws_ok(B, Rq) && (e ? std::atoi(e) != 0 : B <= 32);
     ctx->enc_ws = enc_ws_ok(B, Rq) && (e ? std::atoi(e) != 0 : B <= 64);
     float* f = nullptr;
     CK(dalloc(ctx, &f, 16));
@@ -1241,7 +1246,7 @@ int rau_forward(rau_ctx* ctx) {
       RUN("enc_i2h_gemm", gflop(rows, 4 * Rq, E), 0,
           gemm_nt(st, rows, 4 * Rq, E, ctx->we, E, ctx->i2h[0].W, E, ctx->G1, 4 * Rq, o));
     }
-    if (ctx->enc_ws && ctx->perr_h) {
+    if ((ctx->mode == RAU_MODE_EVAL ? ctx->enc_ws : ctx->enc_ws_train) && ctx->perr_h) {
       // both layers, all tokens: one launch, weights resident in registers (enc_ws.hip)
       EncWsParams q{};
       q.B = B; q.R = Rq; q.TL = TL;

@@ -1,7 +1,7 @@
 """Weight-stationary persistent encoder forward (csrc/enc_ws.hip): model/DeepLSTM.lua:29-65 unrolled
 by SS:448-462 as ONE launch -- recurrent weights in registers, per-(layer, sample half) progress
-counters instead of launches or grid barriers.  Selected by shape (contexts of up to 64 samples at
-the reference's hidden width 512); RAU_ENC_WS=1 forces it for larger batches.  Same bar as every
+counters instead of launches or grid barriers.  Selected by shape at the reference's hidden width 512
+(training contexts of up to 32 samples, evaluate-mode contexts of up to 64); RAU_ENC_WS=1 forces it.  Same bar as every
 other path: 1e-4 max-norm relative against the fp64 oracle on every output and every gradient (the
 backward reads the gates / cell states this kernel saves), and no barrier time-out reported."""
 import numpy as np
@@ -16,9 +16,17 @@ BASE = dict(T=26, V=300, E=200, Rq=512, D=64, S=196, M=64, A=32, R=64, K=40, H=2
 
 
 @pytest.mark.parametrize("B", [16, 32, 48, 64])
-def test_weight_stationary_encoder_is_the_default_up_to_64_samples(B):
-    """B = 16 / 48: one sample part (1 / 3 blocks of 16); 32 / 64: two sample halves."""
+def test_weight_stationary_encoder_training_steps(monkeypatch, B):
+    """B = 16 / 48: one sample part (1 / 3 blocks of 16); 32 / 64: two sample halves.  Default in
+    training up to 32 samples; forced here for every size."""
+    monkeypatch.setenv("RAU_ENC_WS", "1")
     check(util.shapes(dict(BASE, B=B)), scale=None, torch_oracle=True)
+
+
+def test_weight_stationary_encoder_default_selection():
+    """No environment: training contexts up to 32 samples and evaluate-mode contexts up to 64 take it."""
+    check(util.shapes(dict(BASE, B=32, T=9)), scale=None, torch_oracle=True)
+    check(util.shapes(dict(BASE, B=64, T=9)), scale=None, mode="eval", torch_oracle=True)
 
 
 def test_weight_stationary_encoder_eval_mode_and_short_questions():
@@ -38,6 +46,7 @@ def test_weight_stationary_encoder_is_deterministic_and_matches_the_launch_per_s
     from rau_vqa_amd import synth
     from rau_vqa_amd.model import RAU, Config
     dims = dict(BASE, B=64, T=26)
+    monkeypatch.setenv("RAU_ENC_WS", "1")
 
     def run(n):
         m = RAU(Config(**dims))

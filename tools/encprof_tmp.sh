@@ -1,12 +1,12 @@
 cd /root/repo
-for B in 64 256; do
+for B in 16 32 64; do
 for ws in 1 0; do
-RAU_ENC_WS=$ws python3 bench.py --batch $B --variant MS --steps 10 --warmup 3 --no-cpu-baseline 2>/dev/null | python3 -c "
+RAU_ENC_WS=$ws python3 bench.py --batch $B --variant MS --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | python3 -c "
 import sys, json
 for l in sys.stdin:
     l = l.strip()
     if l.startswith('{'):
         d = json.loads(l); k = d['kernel_classes_ms_per_step']
-        print('B=$B ws=$ws ms_per_step %.3f' % d['ms_per_step'], {n: k[n] for n in k if n.startswith('enc') or n.startswith('lstm_fwd') or n == 'embed_fwd'}, 'inference', round(d['inference_qa_per_s']))
+        print('B=$B ws=$ws ms_per_step %.3f' % d['ms_per_step'], {n: k[n] for n in k if n.startswith('enc_ws') or n.startswith('lstm_fwd') or n == 'enc_h2h_gemm'}, 'inference', round(d['inference_qa_per_s']))
 "
 done; done
