@@ -302,8 +302,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_wide(const WideParams P) {
 // at least two K-steps, 16-byte aligned rows.  Sample counts that are not a multiple of 4 are the
 // caller's to split (conv_wide handles the multiple-of-4 part only).
 bool conv_wide_ok(int M, int K, int S, long w_rs) {
-  static const bool off = std::getenv("RAU_CONV_WIDE_OFF") != nullptr;   // A/B knob
-  return !off && S == WS && M % WBM == 0 && K % WBK == 0 && K >= 2 * WBK && w_rs % 4 == 0;
+  return S == WS && M % WBM == 0 && K % WBK == 0 && K >= 2 * WBK && w_rs % 4 == 0;
 }
 
 // epi 0: C = act(acc + bias[m]);  epi 2: C = (acc + dj[b,m] a[b,s]) (1 - Y[b,m,s]^2), rs[b,m] = sum_s C.

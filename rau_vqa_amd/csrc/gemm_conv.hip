@@ -16,10 +16,6 @@ constexpr int BK = 32;
 // 16-byte LDS writes and full-line global reads, ~10% faster than the k-contiguous
 // loader), B = X' [b][d][s] (position contiguous; dropout already applied by
 // dropout_features).  nB may be a group of hops.
-static int conv_epi_dbg() {
-  static const int v = std::getenv("RAU_CONV_EPI_DIRECT") ? 4 : 0;   // A/B knob, see gemm_core.h
-  return v;
-}
 
 
 // 14 x 14 maps in exact f32: the wide tiling (conv_wide.hip) takes the samples in groups of four; a
@@ -38,7 +34,6 @@ static int wide_per_cu(int which) {   // RAU_CONV_WIDE_PER_CU=<f><d>: workgroups
 hipError_t conv_embed_fwd(hipStream_t st, int nB, int D, int S, int M, const float* X,
                           const float* WiT, const float* bi, float* I, int bf16, int one_per_cu) {
   GemmParams P{};
-  P.dbg = conv_epi_dbg();
   P.M = M; P.N = nB * S; P.K = D; P.nk = (D + BK - 1) / BK;
   P.A = WiT; P.a_rs = M;
   P.B = X; P.b_rs = S; P.b_bs = (long)D * S;
@@ -64,7 +59,6 @@ hipError_t conv_embed_fwd(hipStream_t st, int nB, int D, int S, int M, const flo
 hipError_t conv_embed_fwd_b16(hipStream_t st, int nB, int D, int S, int M, const void* X16,
                               const void* WiT16, const float* bi, float* I) {
   GemmParams P{};
-  P.dbg = conv_epi_dbg();
   P.M = M; P.N = nB * S; P.K = D; P.nk = (D + BK - 1) / BK;
   P.A = reinterpret_cast<const float*>(WiT16); P.a_rs = M;
   P.B = reinterpret_cast<const float*>(X16); P.b_rs = S; P.b_bs = (long)D * S;   // in bf16 elements
@@ -77,7 +71,6 @@ hipError_t conv_embed_fwd_b16(hipStream_t st, int nB, int D, int S, int M, const
 hipError_t conv_att_pre_b16(hipStream_t st, int nB, int M, int S, int A, const float* I,
                             const void* WpT16, const float* bp, float* Pout) {
   GemmParams P{};
-  P.dbg = conv_epi_dbg();
   P.M = A; P.N = nB * S; P.K = M; P.nk = (M + BK - 1) / BK;
   P.A = reinterpret_cast<const float*>(WpT16); P.a_rs = A;
   P.B = I; P.b_rs = S; P.b_bs = (long)M * S;
@@ -94,7 +87,6 @@ hipError_t conv_att_pre_b16(hipStream_t st, int nB, int M, int S, int A, const f
 hipError_t conv_att_pre(hipStream_t st, int nB, int M, int S, int A, const float* I,
                         const float* WpT, const float* bp, float* Pout, int bf16, int one_per_cu) {
   GemmParams P{};
-  P.dbg = conv_epi_dbg();
   P.M = A; P.N = nB * S; P.K = M; P.nk = (M + BK - 1) / BK;
   P.A = WpT; P.a_rs = A;                // Wp^T [M][A]: reduction-major
   P.B = I; P.b_rs = S; P.b_bs = (long)M * S;
@@ -181,11 +173,7 @@ hipError_t conv_embed_dgrad(hipStream_t st, int nB, int D, int S, int M, const f
 
 static int conv_wgrad_splits(int nB, int rowsA, int rowsB) {
   const int tiles = ((rowsA + 127) / 128) * ((rowsB + 127) / 128);
-  static const int target = [] {  // tuning knob: workgroups a conv weight-gradient launch aims for
-    const char* e = std::getenv("RAU_WGRAD_WGS");
-    const int v = e ? std::atoi(e) : 0;
-    return v > 0 ? v : 512;   // = one resident wave of workgroups (2 per CU x 256 CUs)
-  }();
+  constexpr int target = 512;   // = one resident wave of workgroups (2 per CU x 256 CUs)
   int s = target / tiles;
   if (s > nB) s = nB;
   if (s < 1) s = 1;
@@ -213,12 +201,7 @@ static hipError_t conv_wgrad(hipStream_t st, GemmParams P, int nB, int S, float*
   P.nk_per_split = spb * P.cps;
   const int splits = (P.nk + P.nk_per_split - 1) / P.nk_per_split;
   P.rs_out = drow ? slab + (size_t)splits * P.M * P.N : nullptr;
-  static const bool xcd_off = std::getenv("RAU_WGRAD_NOXCD") != nullptr;   // A/B knob
-  if (xcd_off) {
-    dim3 grid(P.tiles_m * P.tiles_n, 1, splits);
-    hipLaunchKernelGGL((gemm_kernel<128, 128, BKT, ASRC, BSRC, EPI_SLAB, DT>), grid, dim3(256), 0,
-                       st, P);
-  } else {   // a split's tiles share an XCD (and its L2 copy of the split's samples)
+  {   // a split's tiles share an XCD (and its L2 copy of the split's samples)
     dim3 grid(8 * ((splits + 7) / 8) * P.tiles_m * P.tiles_n);
     hipLaunchKernelGGL((gemm_split_xcd_kernel<128, 128, BKT, ASRC, BSRC, EPI_SLAB, DT>), grid,
                        dim3(256), 0, st, P, splits);

@@ -70,9 +70,6 @@ __device__ __forceinline__ void put_bf16(uint2* img, int idx, int set_stride, fl
   }
 }
 
-// A/B knob (RAU_CONV_EPI_DIRECT, read by the launcher into GemmParams::dbg bit 2): keep the round-1
-// direct accumulator stores of the flattened-column conv epilogue
-#define rau_conv_epi_direct ((P.dbg & 4) != 0)
 
 // Superset of the arguments any loader/epilogue combination needs.
 struct GemmParams {
@@ -770,7 +767,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& P, const int bx, con
     // different waves at different times (measured round 1: 1.37x the algorithmic bytes reached HBM,
     // all of it partial-line writes).  bf16 modes stage half the tile at a time (their LDS is smaller).
     if constexpr (EPI == EPI_CONV && BM == 128 && BN == 128) {
-      if (P.S % 4 == 0 && !rau_conv_epi_direct) {
+      if (P.S % 4 == 0) {
         constexpr int TP = BN + 4;                               // staged row pitch (floats)
         constexpr int RP = kStage / TP >= BM ? BM : 64;          // rows per pass
         static_assert(RP * TP <= kStage, "staging area too small for the epilogue tile");

@@ -41,11 +41,7 @@ static int skinny_splits(int M, int N, int K, const LinOpts& o) {
   if (!o.slab) return 1;
   const int tiles = ((M + 63) / 64) * ((N + 63) / 64);
   const int nk = (K + BKS - 1) / BKS;
-  static const int target = [] {  // tuning knob: workgroups a skinny launch aims for
-    const char* e = std::getenv("RAU_SKINNY_WGS");
-    const int v = e ? std::atoi(e) : 0;
-    return v > 0 ? v : 160;
-  }();
+  constexpr int target = 160;   // workgroups a skinny launch aims for (64 .. 200 measured equal)
   int s = (target + tiles - 1) / tiles;
   if (s > nk / 2) s = nk / 2;
   if (s < 1) s = 1;
@@ -168,11 +164,7 @@ hipError_t gemm_nt_hetero_deferred(hipStream_t st, int nb, int M, int K, const f
 static int tn_splits(int M, int N, int K) {
   const int tiles = ((M + 127) / 128) * ((N + 127) / 128);
   const int nk = (K + BK - 1) / BK;
-  static const int target = [] {  // tuning knob: workgroups a Linear weight-gradient launch aims for
-    const char* e = std::getenv("RAU_TN_WGS");
-    const int v = e ? std::atoi(e) : 0;
-    return v > 0 ? v : 512;
-  }();
+  constexpr int target = 512;   // workgroups a Linear weight-gradient launch aims for
   int s = target / tiles;
   if (s > nk / 8) s = nk / 8;
   if (s < 1) s = 1;
@@ -220,10 +212,7 @@ static int group_splits(const TnProblem* pr, int np, int K) {
   int tiles = 0;
   for (int i = 0; i < np; ++i) tiles += ((pr[i].M + 127) / 128) * ((pr[i].N + 127) / 128);
   const int nk = (K + BK - 1) / BK;
-  static const int target = [] {   // RAU_GROUP_WGS=n: fixed workgroup target instead of the fit below
-    const char* e = std::getenv("RAU_GROUP_WGS");
-    return e ? std::atoi(e) : 0;
-  }();
+  constexpr int target = 0;   // 0: K split fitted to whole rounds of the resident workgroups (below)
   const int smax = std::max(1, nk / 16);
   int s = 1;
   if (target > 0) {

@@ -186,13 +186,6 @@ hipError_t lstm_step_fused(hipStream_t st, int order, const LstmStepParams& P);
 // holds the zero initial state; G1 holds layer 1's input projection (+ both biases) and receives the
 // activated gates.  flags: >= enc_persist_workgroups(B, R) + 1 words (one per workgroup + the published epoch), zeroed once; epoch0: a number that
 // grows by at least TL + 1 from launch to launch; *err is set if a barrier timed out.
-struct EncPersistParams {
-  int B, R, TL;
-  float *G1, *G2, *h1, *c1, *tc1, *x2, *h2, *c2, *tc2;
-  const float *Wh1, *Wi2, *Wh2, *bi2, *bh2;
-  const uint32_t* mask; float mscale;
-  unsigned* flags; unsigned epoch0; int nwg; int* err;
-};
 // Weight-stationary persistent encoder forward (enc_ws.hip, round 3): all T token steps of both
 // layers in one launch, recurrent weights held in registers, per-(layer, sample half) counters
 // instead of a grid barrier.  cnt: 16 words (zeroed by the launcher), err: device error word.
@@ -206,8 +199,6 @@ struct EncWsParams {
 bool enc_ws_ok(int B, int R);
 int enc_ws_workgroups(int B);
 hipError_t enc_ws_forward(hipStream_t st, int order, EncWsParams Q);
-int enc_persist_workgroups(int B, int R);
-hipError_t lstm_enc_persist(hipStream_t st, int order, EncPersistParams Q);
 struct LstmBwdCell {
   const float* gates; const float* c_prev; long cp_rs; const float* tanhc;
   const float* slabA; int nA;     // recurrent dh partials [nB,R]

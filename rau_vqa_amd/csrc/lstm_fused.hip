@@ -249,125 +249,7 @@ __global__ __launch_bounds__(256) void k_lstm_step_fused(const LstmStepParams P)
   step_tile<ORDER, false>(P, C, Ws, ut, rt);
 }
 
-// ---------------------------------------------------------------------------------------------
-// Persistent encoder forward: the whole 2-layer wavefront (T + 1 steps) in ONE launch.
-// blockIdx.y = 0: the layer-1 cells (one source, 64-row tiles), 1: the layer-2 cells (two sources,
-// 32-row tiles); a workgroup keeps its (unit tile, row tile) for every step and meets all others at
-// a grid barrier after each.  What crosses workgroups between steps is h1, x2 = dropout(h1) and h2:
-// written with agent-scope stores (step_tile<COH>), waited for (s_waitcnt) before the workgroup
-// arrives, and read after an agent-scope acquire (`buffer_inv sc1`: the XCD's L2 and the CU's L1
-// drop what they hold of other agents' data), so the A-operand loads stay ordinary cached loads.
-// Barrier: one flag per workgroup (no read-modify-write on a shared line), epoch numbers instead
-// of resets, BOUNDED spinning -- if the grid cannot be co-resident long enough the kernel sets
-// *err and runs to its end with wrong numbers rather than hanging the device (the host checks).
-// Measured (tools/gbar.hip): 4-5 us per barrier of this kind against 8 us launch-to-launch.
-constexpr int kSpinMax = 1 << 21;
-
-template <int ORDER>
-__global__ __launch_bounds__(256) void k_enc_persist(const EncPersistParams Q) {
-  RAU_CHAIN_PRIO();
-  const int side = blockIdx.y;
-  const int rows_per_wg = side ? 32 : 64;
-  const int tiles_u = (Q.R + 15) / 16;
-  const int ut = blockIdx.x % tiles_u, rt = blockIdx.x / tiles_u;
-  if (rt * rows_per_wg >= Q.B) return;           // not counted in nwg
-  const int n0 = tiles_u * ((Q.B + 63) / 64);    // participating layer-1 workgroups come first
-  const int me = side ? n0 + (int)blockIdx.x : (int)blockIdx.x;
-  __shared__ __attribute__((aligned(16))) float Ws[2 * FBK * FLD];
-  const size_t BR = (size_t)Q.B * Q.R, G4 = BR * 4;
-  LstmStepParams P{};
-  P.n = 1; P.B = Q.B; P.R = Q.R;
-  LstmStepSide& C = P.s[0];
-#pragma unroll 1
-  for (int s = 1; s <= Q.TL + 1; ++s) {
-    bool active;
-    if (side == 0) {      // layer-1 cell t = s: G1[t] + h1[t-1] W_h2h1^T  (h1[0] = 0)
-      active = s <= Q.TL;
-      C.nsrc = 1;
-      C.A[0] = Q.h1 + (size_t)(s - 1) * BR; C.W[0] = Q.Wh1; C.K[0] = Q.R;
-      C.A[1] = nullptr; C.W[1] = nullptr; C.K[1] = 0;
-      C.pre = Q.G1 + (size_t)(s - 1) * G4; C.b1 = nullptr; C.b2 = nullptr;
-      C.gates = Q.G1 + (size_t)(s - 1) * G4;
-      C.c_prev = Q.c1 + (size_t)(s - 1) * BR;
-      C.c = Q.c1 + (size_t)s * BR; C.h = Q.h1 + (size_t)s * BR;
-      C.tanhc = Q.tc1 + (size_t)(s - 1) * BR;
-      C.drop_out = Q.x2 + (size_t)(s - 1) * BR;
-      C.mask = Q.mask; C.mask_e0 = (size_t)(s - 1) * BR; C.mscale = Q.mscale;
-    } else {              // layer-2 cell t = s - 1: b + x2[t] W_i2h2^T + h2[t-1] W_h2h2^T  (h2[0] = 0)
-      const int t = s - 1;
-      active = s >= 2;
-      const int tt = active ? t : 1;
-      C.nsrc = 2;
-      C.A[0] = Q.x2 + (size_t)(tt - 1) * BR; C.W[0] = Q.Wi2; C.K[0] = Q.R;
-      C.A[1] = Q.h2 + (size_t)(tt - 1) * BR; C.W[1] = Q.Wh2; C.K[1] = Q.R;
-      C.pre = nullptr; C.b1 = Q.bi2; C.b2 = Q.bh2;
-      C.gates = Q.G2 + (size_t)(tt - 1) * G4;
-      C.c_prev = Q.c2 + (size_t)(tt - 1) * BR;
-      C.c = Q.c2 + (size_t)tt * BR; C.h = Q.h2 + (size_t)tt * BR;
-      C.tanhc = Q.tc2 + (size_t)(tt - 1) * BR;
-      C.drop_out = nullptr; C.mask = nullptr; C.mask_e0 = 0; C.mscale = 1.f;
-    }
-    if (active) step_tile<ORDER, true>(P, C, Ws, ut, rt);
-    if (s == Q.TL + 1) break;                    // nothing in this launch reads the last step's outputs
-    // ---- grid barrier (at normal wave priority: waiting waves must not crowd out the conv GEMMs' waves)
-    __builtin_amdgcn_s_waitcnt(0);               // this wave's stores have been acknowledged
-    __builtin_amdgcn_s_setprio(0);
-    __syncthreads();
-    if (threadIdx.x < 64) {
-      const unsigned want = Q.epoch0 + (unsigned)s;
-      if (threadIdx.x == 0)
-        __hip_atomic_store(Q.flags + me, want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      // two levels: workgroup 0 watches every flag and publishes the epoch in one word the others poll
-      // (each poll is an L2-bypassing load: 384 workgroups reading 384 flags each would keep the fabric
-      // busy beside the conv GEMMs)
-      unsigned* go = Q.flags + Q.nwg;
-      int spins = 0;
-      if (me == 0) {
-        for (;;) {
-          bool ok = true;
-          for (int i = threadIdx.x; i < Q.nwg; i += 64)
-            ok &= (int)(__hip_atomic_load(Q.flags + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want) >= 0;
-          if (__all(ok)) break;
-          __builtin_amdgcn_s_sleep(2);
-          if (++spins > kSpinMax) {              // every wave still reaches the end of the kernel
-            if (threadIdx.x == 0) *Q.err = 1;
-            break;
-          }
-        }
-        if (threadIdx.x == 0) __hip_atomic_store(go, want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      } else {
-        while ((int)(__hip_atomic_load(go, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want) < 0) {
-          __builtin_amdgcn_s_sleep(8);
-          if (++spins > kSpinMax) {
-            if (threadIdx.x == 0) *Q.err = 1;
-            break;
-          }
-        }
-      }
-    }
-    __syncthreads();
-    RAU_CHAIN_PRIO();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // drop stale h1 / x2 / h2 lines (L2 and L1)
-  }
-}
-
 }  // namespace
-
-int enc_persist_workgroups(int B, int R) {
-  const int tiles_u = (R + 15) / 16;
-  return tiles_u * ((B + 63) / 64) + tiles_u * ((B + 31) / 32);
-}
-hipError_t lstm_enc_persist(hipStream_t st, int order, EncPersistParams Q) {
-  if (Q.R % 4 != 0 || Q.TL < 1 || !Q.flags || !Q.err) return hipErrorInvalidValue;
-  const int tiles_u = (Q.R + 15) / 16;
-  Q.nwg = enc_persist_workgroups(Q.B, Q.R);
-  const dim3 grid(tiles_u * ((Q.B + 31) / 32), 2), block(256);
-  if (order == GATES_ATT)
-    hipLaunchKernelGGL(k_enc_persist<GATES_ATT>, grid, block, 0, st, Q);
-  else
-    hipLaunchKernelGGL(k_enc_persist<GATES_DEEP>, grid, block, 0, st, Q);
-  return hipGetLastError();
-}
 
 hipError_t lstm_step_fused(
 hipStream_t st, int order, const LstmStepParams& P) {

@@ -146,15 +146,10 @@ struct rau_ctx {
   int32_t* argmax_d;
   float* att_part = nullptr;  // [B][chunks][S] partial column sums of the split attention kernels
   bool att_split_env = false; // RAU_ATT_SPLIT: 4-wave row-chunk attention kernels instead of the fused ones
-  bool enc_fused_env = false; // RAU_ENC_FUSED: fused GEMM + cell launch per encoder step also in training
-  // persistent encoder forward (lstm_enc_persist): per-workgroup barrier flags, the epoch the next launch
-  // starts from, a device error word (a barrier timed out) copied to pinned memory behind the launch
-  bool enc_persist = false;
+  // persistent encoder forward (enc_ws.hip): device error word (a bounded spin gave up), copied to pinned memory behind the launch
   bool enc_ws = false;          // weight-stationary persistent encoder forward (enc_ws.hip): evaluate mode
   bool enc_ws_train = false;    // ... and in training steps
   unsigned* ws_cnt = nullptr;   // its 16 progress counters
-  unsigned* pflags = nullptr;
-  unsigned pepoch = 0;
   int* perr_d = nullptr;
   int* perr_h = nullptr;
   bool persist_used = false;

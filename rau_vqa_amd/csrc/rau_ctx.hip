@@ -351,14 +351,12 @@ int rau_create(const rau_config* cfg, rau_ctx** out) {
   // Same-box A/B (B=256, D=512, ms/step): fused 16-wave attention + split-K encoder 10.54-10.59,
   // split attention + fused encoder step 10.92-10.95, round-1 library 10.75-10.82.  The split
   // attention kernels and the fused LSTM step are faster ALONE (no bulk GEMM beside them): the
-  // evaluate-mode forward uses the fused LSTM step; RAU_ATT_SPLIT / RAU_ENC_FUSED force them.
+  // evaluate-mode forward uses the fused LSTM step; RAU_ATT_SPLIT forces the split attention kernels.
   // Small batches (one 16-wave workgroup per sample leaves most CUs idle): B = 32 / 64 / 128 fused
   // 3.83 / 4.57 / 6.06 ms, split in 8 row chunks 3.63 / 4.39 / 6.05 ms -> split up to B = 64
   // (RAU_ATT_FUSED keeps the fused kernels).
   ctx->att_split_env = std::getenv("RAU_ATT_SPLIT") != nullptr ||
                        (c.B <= 64 && std::getenv("RAU_ATT_FUSED") == nullptr);
-  ctx->enc_fused_env = std::getenv("RAU_ENC_FUSED") != nullptr;
-  ctx->enc_persist = std::getenv("RAU_ENC_PERSIST") != nullptr;
   {
     // Weight-stationary persistent encoder (enc_ws.hip): chosen by shape, never by the environment in
     // normal use -- contexts of up to 64 samples (the strong-scaling shards of configs[3]) are bound
@@ -376,9 +374,8 @@ int rau_create(const rau_config* cfg, rau_ctx** out) {
   }
   {
     float* f = nullptr;
-    CK(dalloc(ctx, &f, (size_t)enc_persist_workgroups(B, Rq) + 2));   // zero-filled: flags, go word, error word
-    ctx->pflags = reinterpret_cast<unsigned*>(f);
-    ctx->perr_d = reinterpret_cast<int*>(f) + enc_persist_workgroups(B, Rq) + 1;
+    CK(dalloc(ctx, &f, 4));   // device error word of the persistent encoder (a bounded spin gave up)
+    ctx->perr_d = reinterpret_cast<int*>(f);
     if (hipHostMalloc(reinterpret_cast<void**>(&ctx->perr_h), sizeof(int), hipHostMallocDefault) != hipSuccess)
       ctx->perr_h = nullptr;
     else
@@ -1259,21 +1256,7 @@ int rau_forward(rau_ctx* ctx) {
       RUN("enc_ws", (double)TL * 3 * gflop(B, 4 * Rq, Rq), 0, enc_ws_forward(st, GATES_DEEP, q));
       HIPC(hipMemcpyAsync(ctx->perr_h, ctx->perr_d, sizeof(int), hipMemcpyDeviceToHost, st));
       ctx->persist_used = true;
-    } else if (ctx->enc_persist && !ctx->capturing && ctx->perr_h) {
-      // the whole wavefront in one persistent launch (a captured graph would replay a stale epoch)
-      EncPersistParams q{};
-      q.B = B; q.R = Rq; q.TL = TL;
-      q.G1 = ctx->G1; q.G2 = ctx->G2; q.h1 = ctx->h1; q.c1 = ctx->c1; q.tc1 = ctx->tc1; q.x2 = ctx->x2;
-      q.h2 = ctx->h2; q.c2 = ctx->c2; q.tc2 = ctx->tc2;
-      q.Wh1 = ctx->h2h[0].W; q.Wi2 = ctx->i2h[1].W; q.Wh2 = ctx->h2h[1].W;
-      q.bi2 = ctx->i2h[1].b; q.bh2 = ctx->h2h[1].b;
-      q.mask = m_rnn; q.mscale = sc(RAU_MASK_RNN);
-      q.flags = ctx->pflags; q.epoch0 = ctx->pepoch; q.err = ctx->perr_d;
-      ctx->pepoch += (unsigned)TL + 2;
-      RUN("enc_persist", (double)TL * 3 * gflop(B, 4 * Rq, Rq), 0, lstm_enc_persist(st, GATES_DEEP, q));
-      HIPC(hipMemcpyAsync(ctx->perr_h, ctx->perr_d, sizeof(int), hipMemcpyDeviceToHost, st));
-      ctx->persist_used = true;
-    } else if (ctx->enc_fused_env || ctx->mode == RAU_MODE_EVAL) {
+    } else if (ctx->mode == RAU_MODE_EVAL) {
       // one launch per wavefront step: gate GEMM + cell fused (lstm_fused.hip)
       for (int s = 1; s <= TL + 1; ++s) {
         LstmStepParams sp{};
@@ -1831,8 +1814,8 @@ int rau_sync(rau_ctx* ctx) {
   NEED(ctx, "null ctx");
   HIPC(hipStreamSynchronize(ctx->st));
   if (ctx->persist_used && ctx->perr_h && *ctx->perr_h)
-    return fail(RAU_ERR_DEVICE, "persistent encoder: a grid barrier timed out (results of that step are "
-                                "invalid; unset RAU_ENC_PERSIST)");
+    return fail(RAU_ERR_DEVICE, "persistent encoder: a bounded wait on another workgroup's progress counter gave up "
+                                "(results of that step are invalid; RAU_ENC_WS=0 selects the launch-per-step path)");
   return RAU_OK;
 }
 static int d2h(rau_ctx* ctx, void* host, const void* dev, size_t bytes) {
@@ -1840,7 +1823,7 @@ static int d2h(rau_ctx* ctx, void* host, const void* dev, size_t bytes) {
   HIPC(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, ctx->st));
   HIPC(hipStreamSynchronize(ctx->st));
   if (ctx->persist_used && ctx->perr_h && *ctx->perr_h)   // same check as rau_sync: never hand back such results as OK
-    return fail(RAU_ERR_DEVICE, "persistent encoder: a grid barrier timed out (results of that step are invalid)");
+    return fail(RAU_ERR_DEVICE, "persistent encoder: a bounded wait gave up (results of that step are invalid)");
   return RAU_OK;
 }
 int rau_get_losses(rau_ctx* ctx, float* losses) {

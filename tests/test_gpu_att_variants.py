@@ -32,20 +32,3 @@ def test_split_attention_kernels_above_64_samples(monkeypatch, chunks):
 
 def test_default_family_at_80_samples_is_the_fused_one_and_agrees():
     check(util.shapes(WIDE), scale=0.3, torch_oracle=True)
-
-
-@pytest.mark.parametrize("dims,scale,mode", [(util.SMALL, 0.5, "train"), (util.MEDIUM, 0.2, "train"),
-                                             (util.SMALL, 0.5, "eval")])
-def test_persistent_encoder_forward(monkeypatch, dims, scale, mode):
-    """RAU_ENC_PERSIST: the encoder's whole two-layer wavefront as ONE persistent launch with a grid
-    barrier per step (lstm_fused.hip, k_enc_persist) -- off by default because it measured slower than
-    the two launches per step it replaces; same parity bar, and rau_sync must not
-    report a barrier time-out."""
-    monkeypatch.setenv("RAU_ENC_PERSIST", "1")
-    check(util.shapes(dims), scale=scale, mode=mode)
-
-
-def test_persistent_encoder_at_real_widths(monkeypatch):
-    monkeypatch.setenv("RAU_ENC_PERSIST", "1")
-    dims = dict(B=70, T=26, V=300, E=200, Rq=512, D=64, S=196, M=64, A=32, R=64, K=40, H=2)
-    check(util.shapes(dims), scale=None, torch_oracle=True)

@@ -1,0 +1,36 @@
+"""Every A/B environment variable librau.so still reads keeps the parity bar:
+each setting runs tests/knob_check.py -- train and evaluate mode against the fp64 oracle, 1e-4 -- in
+its own process, because most of them are read once per process."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+KNOBS = [
+    ({}, 72), ({}, 24),                                     # defaults on both sides of the 64-sample switch
+    ({"RAU_CONV_WIDE": "0"}, 72),                           # round-2 tilings everywhere
+    ({"RAU_CONV_WIDE": "7"}, 72),                           # + the attention dgrad on the wide tiling
+    ({"RAU_CONV_WIDE": "7", "RAU_CONV_WIDE_PER_CU": "22"}, 72),
+    ({"RAU_CONV_WIDE": "0", "RAU_CONV_SAMPLE": "15"}, 72),  # per-sample tiling for all four convs
+    ({"RAU_CONV_WIDE": "0", "RAU_CONV_SAMPLE": "0"}, 72),   # flattened-column tiling for all
+    ({"RAU_HOP_GROUPS": "1,3", "RAU_BWD_GROUPS": "2,2"}, 72),
+    ({"RAU_ATT_WAVES_FWD": "16", "RAU_ATT_WAVES_BWD": "8"}, 72),
+    ({"RAU_ATT_WAVES_FWD": "4", "RAU_ATT_WAVES_BWD": "4"}, 72),
+    ({"RAU_ATT_DMA_OFF": "1"}, 72),
+    ({"RAU_ATT_SPLIT": "1", "RAU_ATT_CHUNKS": "4"}, 72),
+    ({"RAU_ATT_FUSED": "1"}, 24),
+    ({"RAU_ENC_WS": "0"}, 24),
+]
+
+
+@pytest.mark.parametrize("env,batch", KNOBS, ids=[" ".join(f"{k}={v}" for k, v in e.items()) + f" B={b}"
+                                                  for e, b in KNOBS])
+def test_knob_setting_keeps_parity(env, batch):
+    e = dict(os.environ, **env)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "knob_check.py"), str(batch)],
+                         env=e, cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
