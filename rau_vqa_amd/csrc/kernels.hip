@@ -848,12 +848,174 @@ __global__ __launch_bounds__(NW * 64) void k_att_bwd_fused(
     }
   }
 }
+// ---- the backward pass on the LDS-DMA structure of k_att_fwd_dma (round 3): I rows (phase 1) and
+// P rows (phase 3) arrive in per-wave rings of D slots.  Phase 3 also STORES a row of dS per
+// iteration (in place over P), so a wave's vmcnt sequence is DMA, store, DMA, store, ...: with one
+// of each per iteration -- the tail keeps issuing (unused) loads of its last row so the pattern
+// never changes -- row i has landed once at most 2 D - 2 younger operations are outstanding (D - 1
+// while the ring's first lap is still in flight; waiting for a smaller count is always safe).
+// Only the recompute form (Psrc != nullptr: the forward kept P, not tanh(P + u)) is built this way.
+template <int NW, int D>
+__global__ __launch_bounds__(NW * 64) void k_att_bwd_dma(
+    int M, int A, int S, const float* __restrict__ I, const float* __restrict__ dj,
+    const float* __restrict__ a, const float* __restrict__ da_lin, const float* __restrict__ ws,
+    float* __restrict__ T, float* __restrict__ dz, float* __restrict__ du, float* __restrict__ dwsp,
+    const float* __restrict__ Psrc, const float* __restrict__ u, int da_ns, int SL, int nB,
+    const float* __restrict__ da_add) {
+  RAU_CHAIN_PRIO();
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* red = sm;                     // [NW][S]
+  float* dzs = sm + NW * S;            // [S]
+  float* sc = dzs + S;                 // [NW]
+  float* ring = sc + NW;               // [NW][D][S] (+ slack)
+  const int b = blockIdx.x, tid = threadIdx.x, l = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int S4 = S >> 2;
+  const bool lane_on = l < S4;
+  float* myring = ring + (size_t)w * D * S;
+  const uint32_t ring_b = (uint32_t)(size_t)(att_lds_ptr_t)myring + (uint32_t)l * 16;
+  auto dma_row = [&](const float* base, int i, int row) {   // row `row` of the wave into slot i % D
+    if (lane_on)
+      __builtin_amdgcn_global_load_lds((att_glb_ptr_t)(base + (size_t)(w + NW * row) * S + 4 * l),
+                                       (att_lds_ptr_t)(myring + (i % D) * S), 16, 0, 0);
+  };
+  auto ring_read = [&](int i) {
+    float4 v;
+    asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(ring_b + (uint32_t)((i % D) * S) * 4) : "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return v;
+  };
+  auto lane_val = [&](float v, int i) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), i));
+  };
+  // ---- phase 1: da[s] = da_lin[s] + sum_m dj[m] I[m,s]
+  {
+    const float* Ib = I + (size_t)b * M * S;
+    const int nrows = w < M ? (M - w + NW - 1) / NW : 0;
+    float drow = 0.f;
+    if (l < nrows) drow = dj[(size_t)b * M + w + NW * l];
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    for (int i = 0; i < D && i < nrows; ++i) dma_row(Ib, i, i);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 1
+    for (int i = 0; i < nrows; ++i) {
+      if (i + D <= nrows) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(D - 1) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const float4 x = ring_read(i);
+      if (i + D < nrows) dma_row(Ib, i + D, i + D);
+      const float d = lane_val(drow, i);
+      acc.x += d * x.x; acc.y += d * x.y; acc.z += d * x.z; acc.w += d * x.w;
+    }
+    if (lane_on) reinterpret_cast<float4*>(red + (size_t)w * S)[l] = acc;
+  }
+  __syncthreads();
+  // ---- phase 2: dz = a * (da - sum_s a da)   (as in k_att_bwd_fused)
+  float dot = 0.f;
+  for (int s = tid; s < S; s += (NW * 64)) {
+    float d;
+    if (da_ns > 0) {
+      d = 0.f;
+      if (s < SL) {
+        for (int sp = 0; sp < da_ns; ++sp) d += da_lin[((size_t)sp * nB + b) * SL + s];
+        if (da_add) d += da_add[(size_t)b * S + s];
+      }
+    } else {
+      d = da_lin[(size_t)b * S + s];
+    }
+    d += block_sum_ordered<NW>(red, S, s);
+    dzs[s] = d;
+    dot += a[(size_t)b * S + s] * d;
+  }
+  dot = wave_sum(dot);
+  if (l == 0) sc[w] = dot;
+  __syncthreads();
+  dot = sc[0];
+#pragma unroll
+  for (int i = 1; i < NW; ++i) dot += sc[i];
+  for (int s = tid; s < S; s += (NW * 64)) {
+    const float v = a[(size_t)b * S + s] * (dzs[s] - dot);
+    dzs[s] = v;
+    dz[(size_t)b * S + s] = v;
+  }
+  __syncthreads();
+  // ---- phase 3: dS = dz ws (1 - tanh(P + u)^2) in place over P; du[k] = sum_s dS; dwsp[k] = sum_s dz T
+  {
+    float* Tb = T + (size_t)b * A * S;
+    const float* Pb = Psrc + (size_t)b * A * S;
+    const int nrows = w < A ? (A - w + NW - 1) / NW : 0;
+    float urow = 0.f, wrow = 0.f;
+    if (l < nrows) {
+      urow = u[(size_t)b * A + w + NW * l];
+      wrow = ws[w + NW * l];
+    }
+    float4 d4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (lane_on) d4 = reinterpret_cast<const float4*>(dzs)[l];
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    if (nrows > 0)
+      for (int i = 0; i < D; ++i) dma_row(Pb, i, i < nrows ? i : nrows - 1);
+    float r1 = 0.f, r2 = 0.f;
+#pragma unroll 1
+    for (int i = 0; i < nrows; ++i) {
+      if (i >= D - 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * D - 2) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(D - 1) : "memory");
+      float4 t = ring_read(i);
+      dma_row(Pb, i + D, i + D < nrows ? i + D : nrows - 1);   // one load per iteration, always
+      const float uk = lane_val(urow, i), wk = lane_val(wrow, i);
+      float s1 = 0.f, s2 = 0.f;
+      float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (lane_on) {
+        t.x = tanh_fast(t.x + uk); t.y = tanh_fast(t.y + uk);
+        t.z = tanh_fast(t.z + uk); t.w = tanh_fast(t.w + uk);
+        o.x = d4.x * wk * (1.f - t.x * t.x);
+        o.y = d4.y * wk * (1.f - t.y * t.y);
+        o.z = d4.z * wk * (1.f - t.z * t.z);
+        o.w = d4.w * wk * (1.f - t.w * t.w);
+        s1 = (o.x + o.y) + (o.z + o.w);
+        s2 = d4.x * t.x + d4.y * t.y + d4.z * t.z + d4.w * t.w;
+      }
+      // one store per iteration, always (its lanes past S/4 are masked off)
+      if (lane_on) reinterpret_cast<float4*>(Tb + (size_t)(w + NW * i) * S)[l] = o;
+      s1 = wave_sum(s1);
+      s2 = wave_sum(s2);
+      if (l == i) { r1 = s1; r2 = s2; }
+    }
+    if (l < nrows) {
+      du[(size_t)b * A + w + NW * l] = r1;
+      dwsp[(size_t)b * A + w + NW * l] = r2;
+    }
+  }
+}
+
 hipError_t att_bwd_fused(hipStream_t st, int nB, int M, int A, int S, const float* I,
                          const float* dj, const float* a, const float* da_lin,
                          const float* ws, float* T_to_dS, float* dz, float* du, float* dwsp,
                          const float* Psrc, const float* u, int da_ns, int SL,
                          const float* da_add) {
   const int nw = att_waves(true);
+  static const bool dma_off = std::getenv("RAU_ATT_DMA_OFF") != nullptr;   // A/B knob
+  if (!dma_off && Psrc && u && S % 4 == 0 && S <= 256 && A <= 64 * 8 && M <= 64 * 8 && (nw == 8 || nw == 16)) {
+    constexpr int kD8 = 8, kD16 = 4;
+    const int d = nw == 8 ? kD8 : kD16;
+    const size_t ldsd = ((size_t)(nw + 1) * S + nw + (size_t)nw * d * S + 256) * sizeof(float);
+    static bool attr = false;
+    if (!attr) {
+      hipFuncSetAttribute(reinterpret_cast<const void*>(k_att_bwd_dma<8, kD8>),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+      hipFuncSetAttribute(reinterpret_cast<const void*>(k_att_bwd_dma<16, kD16>),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+      attr = true;
+    }
+    if (ldsd <= 96 * 1024) {
+      if (nw == 8)
+        hipLaunchKernelGGL((k_att_bwd_dma<8, kD8>), dim3(nB), dim3(512), ldsd, st, M, A, S, I, dj, a, da_lin, ws,
+                           T_to_dS, dz, du, dwsp, Psrc, u, da_ns, SL, nB, da_add);
+      else
+        hipLaunchKernelGGL((k_att_bwd_dma<16, kD16>), dim3(nB), dim3(1024), ldsd, st, M, A, S, I, dj, a, da_lin,
+                           ws, T_to_dS, dz, du, dwsp, Psrc, u, da_ns, SL, nB, da_add);
+      return hipGetLastError();
+    }
+  }
   const size_t lds = ((size_t)(nw + 1) * S + nw) * sizeof(float);
 #define ATT_BWD(NW_) hipLaunchKernelGGL(k_att_bwd_fused<NW_>, dim3(nB), dim3(NW_ * 64), lds, st, M, A, \
                                         S, I, dj, a, da_lin, ws, T_to_dS, dz, du, dwsp, Psrc, u, \
