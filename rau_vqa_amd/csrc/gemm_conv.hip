@@ -215,6 +215,8 @@ static hipError_t conv_wgrad(hipStream_t st, GemmParams P, int nB, int S, float*
 template <int ASRC>
 static hipError_t conv_wgrad_any(hipStream_t st, const GemmParams& P, int nB, int S, float* dW,
                                  float* slab, int bf16, float* drow = nullptr) {
+  if (!bf16 && ASRC == SRC_SC && !drow && wgrad_dma_ok(P.M, P.N, S))   // exact f32, plain operands
+    return wgrad_dma(st, nB, P.M, P.N, S, P.A, P.a_bs, P.B, P.b_bs, dW, slab, conv_wgrad_splits(nB, P.M, P.N));
   // bf16 MFMA steps are 16 deep: 32-wide chunks, the last one of a 196-position map zero-filled
   if (bf16 == 2) return conv_wgrad<32, ASRC, 2>(st, P, nB, S, dW, slab, drow);
   if (bf16) return conv_wgrad<32, ASRC, 1>(st, P, nB, S, dW, slab, drow);

@@ -119,6 +119,11 @@ hipError_t conv_embed_dgrad(hipStream_t st, int nB, int D, int S, int M, const f
 // dWp[k,m] += sum_{b,s} dS[b,k,s] I[b,m,s]   and, with dZ = dI (1 - I^2),
 // dWi[m,d] += sum_{b,s} dZ[b,m,s] X'[b,d,s]
 size_t conv_wgrad_slab_floats(int nB, int rowsA, int rowsB, int S);
+// the same products with both operands staged by LDS-DMA (wgrad_dma.hip, round 3): 14 x 14 maps,
+// row counts multiples of 128, plain operands (dZ already final)
+bool wgrad_dma_ok(int ra, int rb, int S);
+hipError_t wgrad_dma(hipStream_t st, int nB, int ra, int rb, int S, const float* A, long a_bs,
+                     const float* B, long b_bs, float* dW, float* slab, int splits);
 hipError_t conv_att_wgrad(hipStream_t st, int nB, int M, int S, int A, const float* dS,
                           const float* I, float* dWp, float* slab, int bf16 = 0);
 hipError_t conv_embed_wgrad(hipStream_t st, int nB, int D, int S, int M, const float* dI,

@@ -21,6 +21,7 @@ KNOBS = [
     ({"RAU_ATT_WAVES_FWD": "16", "RAU_ATT_WAVES_BWD": "8"}, 72),
     ({"RAU_ATT_WAVES_FWD": "4", "RAU_ATT_WAVES_BWD": "4"}, 72),
     ({"RAU_ATT_DMA_OFF": "1"}, 72),
+    ({"RAU_WGRAD_DMA_OFF": "1"}, 72),
     ({"RAU_ATT_SPLIT": "1", "RAU_ATT_CHUNKS": "4"}, 72),
     ({"RAU_ATT_FUSED": "1"}, 24),
     ({"RAU_ENC_WS": "0"}, 24),

@@ -8,6 +8,7 @@
 #include <cstring>
 #include <functional>
 #include <vector>
+#include <cmath>
 #include "../rau_vqa_amd/csrc/kernels.h"
 using namespace rau;
 
@@ -138,6 +139,51 @@ int main(int argc, char** argv) {
       }
       CK(hipFree(dS)); CK(hipFree(Wp)); CK(hipFree(dj)); CK(hipFree(av)); CK(hipFree(I));
       CK(hipFree(Z0)); CK(hipFree(Z1)); CK(hipFree(r0)); CK(hipFree(r1));
+    }
+  }
+  if (want("wgrad")) {
+    // conv weight gradients: conv_att_wgrad (dWp [A][M]) and conv_embed_wgrad with dZ final (dWi [M][D]);
+    // set RAU_WGRAD_DMA_OFF=1 to time the round-2 register-staged kernel instead of wgrad_dma.hip
+    {   // correctness against a host reference in double, 8 samples
+      const int nb = 8, D = 512;
+      std::vector<float> hA((size_t)nb * M * S), hB((size_t)nb * D * S);
+      for (auto& v : hA) v = 0.01f * ((rand() % 2001) / 1000.f - 1.f);
+      for (auto& v : hB) v = (rand() % 2001) / 1000.f - 1.f;
+      float *dA, *dB, *dW, *slab;
+      CK(hipMalloc(&dA, hA.size() * 4)); CK(hipMalloc(&dB, hB.size() * 4));
+      CK(hipMemcpy(dA, hA.data(), hA.size() * 4, hipMemcpyHostToDevice));
+      CK(hipMemcpy(dB, hB.data(), hB.size() * 4, hipMemcpyHostToDevice));
+      CK(hipMalloc(&dW, (size_t)M * D * 4)); CK(hipMemset(dW, 0, (size_t)M * D * 4));
+      CK(hipMalloc(&slab, conv_wgrad_slab_floats(nb, M, D, S) * 4));
+      CK(conv_embed_wgrad(st, nb, D, S, M, dA, nullptr, dB, dW, slab, 0, nullptr, 1));
+      CK(hipStreamSynchronize(st));
+      std::vector<float> hW((size_t)M * D);
+      CK(hipMemcpy(hW.data(), dW, hW.size() * 4, hipMemcpyDeviceToHost));
+      double md = 0, mx = 0;
+      for (int m = 0; m < M; m += 7)
+        for (int d = 0; d < D; d += 5) {
+          double v = 0;
+          for (int b = 0; b < nb; ++b)
+            for (int s2 = 0; s2 < S; ++s2) v += (double)hA[((size_t)b * M + m) * S + s2] * hB[((size_t)b * D + d) * S + s2];
+          md = fmax(md, fabs(v - hW[(size_t)m * D + d])); mx = fmax(mx, fabs(v));
+        }
+      printf("conv_embed_wgrad nB=8 vs host double: max |diff| %.3g (max |ref| %.3g)\n", md, mx);
+      CK(hipFree(dA)); CK(hipFree(dB)); CK(hipFree(dW)); CK(hipFree(slab));
+    }
+    for (int nh : {1, 2}) {
+      const int nB = nh * B, D = 512;
+      float* dS = dev_rand((size_t)nB * A * S, 0.01f), *I = dev_rand((size_t)nB * M * S, 0.9f);
+      float* dZ = dev_rand((size_t)nB * M * S, 0.01f), *X = dev_rand((size_t)nB * D * S, 0.5f, true);
+      float *dWp, *dWi, *slab;
+      CK(hipMalloc(&dWp, (size_t)A * M * 4)); CK(hipMalloc(&dWi, (size_t)M * D * 4));
+      size_t sl = conv_wgrad_slab_floats(nB, M, D, S); if (conv_wgrad_slab_floats(nB, A, M, S) > sl) sl = conv_wgrad_slab_floats(nB, A, M, S);
+      CK(hipMalloc(&slab, sl * 4));
+      printf("conv weight gradients  nB=%d\n", nB);
+      for (int rep = 0; rep < 2; ++rep) {
+        report("conv_att_wgrad (256 x 512)", timeit(st, 10, [&] { return conv_att_wgrad(st, nB, M, S, A, dS, I, dWp, slab, 0); }), 2.0 * A * M * (double)nB * S);
+        report("conv_embed_wgrad (512 x 512)", timeit(st, 10, [&] { return conv_embed_wgrad(st, nB, D, S, M, dZ, nullptr, X, dWi, slab, 0, nullptr, 1); }), 2.0 * M * D * (double)nB * S);
+      }
+      CK(hipFree(dS)); CK(hipFree(I)); CK(hipFree(dZ)); CK(hipFree(X)); CK(hipFree(dWp)); CK(hipFree(dWi)); CK(hipFree(slab));
     }
   }
   printf("done\n");
