@@ -356,7 +356,19 @@ def main():
         for i in range(10):
             m.forward()
         fence()
-        extra["inference_qa_per_s"] = cfg.B * 10 / (time.perf_counter() - t2)
+        inf_s = (time.perf_counter() - t2) / 10
+        extra["inference_qa_per_s"] = cfg.B / inf_s
+        # the evaluate-mode forward is HBM-bound by construction: i_embed / ifeatproj run
+        # once, each hop streams I [M,S] and P [A,S] of every sample once.  Algorithmic bytes per batch:
+        # X read + I, P written once, then H x (I + P) read, f32.
+        inf_bytes = 4.0 * cfg.B * cfg.S * (cfg.D + cfg.M + cfg.A + cfg.H * (cfg.M + cfg.A))
+        extra["inference"] = {"qa_per_s": cfg.B / inf_s, "ms_per_batch": inf_s * 1e3,
+                              "roofline": {"bound": "hbm", "achieved": inf_bytes / inf_s / 1e9,
+                                           "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                           "frac": inf_bytes / inf_s / 1e9 / HBM_PEAK_GBS,
+                                           "algorithmic_bytes_per_batch": inf_bytes},
+                              "note": "whole evaluate-mode forward (encoder + conv once + 8 hops), wall time over "
+                                      "10 batches; the hop chain's ~60 dependent launches bound it, not HBM"}
         m.training()
         if world == 1 and not args.no_cpu_baseline:
             extra["cpu_baseline"] = cpu_baseline(cfgd)

@@ -232,7 +232,7 @@ hipError_t wgrad_dma(hipStream_t st, int nB, int ra, int rb, int S, const float*
   P.splits = (nB + P.spb - 1) / P.spb;
   P.A = A; P.a_bs = a_bs; P.B = B; P.b_bs = b_bs; P.slab = slab;
   const dim3 grid(8 * ((P.splits + 7) / 8) * P.tiles_a * P.tiles_b), block(256);
-  hipLaunchKernelGGL(k_wgrad_dma, grid, block, 0, st, P);
+  hipLaunchKernelGGL(k_wgrad_dma, grid, block, 0, st, P);   // two per CU (one per CU measured 10.23 vs 9.70 ms/step)
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   return splitk_reduce_acc(st, (size_t)ra * rb, P.splits, slab, (size_t)ra * rb, dW);
