@@ -48,9 +48,18 @@ def rnn_specs(sh):
             ("l2_i2h", 4 * sh.Rq, sh.Rq), ("l2_h2h", 4 * sh.Rq, sh.Rq)]
 
 
+_NUDGE = 0.0   # see step(bf16_nudge=...)
+
+
 def _rb(x):
-    """Round to bfloat16 (RNE, via float32 like the device's staging path) and back."""
-    return x.detach().to(torch.float32).to(torch.bfloat16).to(x.dtype)
+    """Round to bfloat16 (RNE, via float32 like the device's staging path) and back.  With _NUDGE = eta
+    the value is scaled by (1 + eta) first: an operand further than eta (relative) from a bf16 rounding
+    boundary rounds to the same bf16 value as before, one closer than that flips to its neighbour --
+    exactly the operands whose rounding the device's own f32 error (~3e-7) can decide differently."""
+    v = x.detach().to(torch.float32)
+    if _NUDGE:
+        v = v * (1.0 + _NUDGE)
+    return v.to(torch.bfloat16).to(x.dtype)
 
 
 class _Conv1x1BF16(torch.autograd.Function):
@@ -160,8 +169,19 @@ def multimodal(sh, P, q, feats4d, prev_c, prev_h, mq, mx, mmf, bf16=False):
 
 
 def step(sh, params, feats, tokens, lens, labels, masks=None, hop_w=None,
-         backward=True, dtype=torch.float64, bf16=False):
-    """One feval forward(+backward), SS:428-596.  Same I/O convention as oracle.step."""
+         backward=True, dtype=torch.float64, bf16=False, bf16_nudge=0.0):
+    """One feval forward(+backward), SS:428-596.  Same I/O convention as oracle.step.
+    bf16_nudge (with bf16=True): flip the rounding of every GEMM operand that lies within that
+    relative distance of a bf16 rounding boundary (tests/test_gpu_bf16.py derives its bar from it)."""
+    global _NUDGE
+    _NUDGE = float(bf16_nudge) if bf16 else 0.0
+    try:
+        return _step(sh, params, feats, tokens, lens, labels, masks, hop_w, backward, dtype, bf16)
+    finally:
+        _NUDGE = 0.0
+
+
+def _step(sh, params, feats, tokens, lens, labels, masks, hop_w, backward, dtype, bf16):
     t = lambda a: torch.as_tensor(a).to(dtype)
     flat = {k: t(params[k]).clone().requires_grad_(backward) for k in ("embed", "rnn", "mult")}
     Emb = flat["embed"].view(sh.V, sh.E)

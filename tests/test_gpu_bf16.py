@@ -2,11 +2,18 @@
 
 Two bars.  (1) Against the autograd restatement with the SAME rounding emulated
 (oracle/ref_torch.py bf16=True: every operand of the five conv GEMMs rounded to bfloat16,
-exact accumulation): 5e-4 max-norm relative -- what is left is f32 accumulation order plus the
-rare operand whose f32 value sits on a bf16 rounding boundary.  (2) Against the exact fp64
-oracle: 3e-2 -- the size of the bf16 rounding itself (about 1e-3 on these shapes), i.e. the
-mode is a precision trade, not a different computation.  Answer indices: exact wherever the
-emulated oracle's top-2 margin is decisive.
+exact accumulation).  What is left between device and emulation is f32 accumulation order
+(TOL_BASE) plus the operands whose f32 value sits so close to a bf16 rounding boundary that the
+device's own f32 error (~3e-7 relative on I, dS, dZ) decides the rounding the other way: one such
+flip changes a product by 2^-8 of its size, which on a 12-channel or one-position reduction is
+several 1e-4 of the result (round 2's soak: 5.1e-4 and 7.1e-4 on seeds 855 / 859 against a fixed
+5e-4 bar).  The bar is therefore DERIVED per tensor: the emulation is run twice more with every
+operand within NUDGE = 6e-7 (relative) of a boundary rounded the other way, upwards and downwards
+(ref_torch.step(bf16_nudge=+-NUDGE): operands further from a boundary keep their rounding bit
+for bit), and a tensor may differ from the plain emulation by TOL_BASE + SAFETY x the larger of the
+two shifts.  (2) Against the exact fp64 oracle: 3e-2 -- the size of the bf16 rounding itself (about
+1e-3 on these shapes), i.e. the mode is a precision trade, not a different computation.  Answer
+indices: exact wherever the emulated oracle's top-2 margin is decisive.
 """
 import numpy as np
 import pytest
@@ -16,7 +23,9 @@ from tests import util
 
 pytestmark = pytest.mark.gpu
 
-TOL_EMU = 5e-4
+TOL_BASE = 2e-4       # accumulation order alone (measured <= 6e-5 on the committed shapes)
+NUDGE = 6e-7          # 2x the measured f32 error (~3e-7) of the intermediate tensors that get rounded
+SAFETY = 2.0          # flips are independent: the device may take any subset of the two nudged runs' flips
 TOL_EXACT = 3e-2
 
 
@@ -28,6 +37,8 @@ def run(dims, scale, mode="train", lens="ragged"):
     mk = masks if mode == "train" else None
     args = (sh, params, batch["feats"], batch["tokens"], batch["lens"], batch["labels"], mk, hop_w)
     emu = RT.step(*args, bf16=True)
+    emu_up = RT.step(*args, bf16=True, bf16_nudge=NUDGE)
+    emu_dn = RT.step(*args, bf16=True, bf16_nudge=-NUDGE)
     exact = RT.step(*args)
     cfg = Config(**{k: getattr(sh, k) for k in
                     ("B", "T", "V", "E", "Rq", "D", "S", "M", "A", "R", "K", "H",
@@ -47,15 +58,32 @@ def run(dims, scale, mode="train", lens="ragged"):
     g = m.get_grads()
     layouts = {k: m.layout(k) for k in ("embed", "rnn", "mult")}
     m.close()
-    for ref, tol, what in ((emu, TOL_EMU, "emulated"), (exact, TOL_EXACT, "exact")):
-        errs = {k: util.rel_err(got[k], ref[k]) for k in util.OUT_KEYS}
+    def tensors(res, grads):
+        out = {k: np.asarray(res[k]) for k in util.OUT_KEYS}
         for grp in layouts:
             for name, sl in util.layer_slices(layouts[grp]):
-                r = ref["g_" + grp][sl]
-                errs[name] = (float(np.max(np.abs(g[grp][sl] - r))) if np.max(np.abs(r)) < 1e-12
-                              else util.rel_err(g[grp][sl], r))
-        bad = {k: v for k, v in errs.items() if not v < tol}
-        assert not bad, f"vs {what} oracle above {tol}: {bad}\nall: {errs}"
+                out[name] = np.asarray(grads[grp][sl])
+        return out
+
+    def as_grads(ref):
+        return {grp: ref["g_" + grp] for grp in layouts}
+    dev = tensors(got, g)
+    t_emu, t_up, t_dn, t_ex = (tensors(r, as_grads(r)) for r in (emu, emu_up, emu_dn, exact))
+
+    def err(a, b):
+        return float(np.max(np.abs(a - b))) if np.max(np.abs(b)) < 1e-12 else util.rel_err(a, b)
+    bad, widest = {}, 0.0
+    for k in dev:
+        flip = max(err(t_up[k], t_emu[k]), err(t_dn[k], t_emu[k]))
+        tol = TOL_BASE + SAFETY * flip
+        widest = max(widest, tol)
+        e = err(dev[k], t_emu[k])
+        if not e < tol:
+            bad[k] = (e, tol)
+    assert not bad, f"vs emulated oracle, (error, derived bar): {bad}"
+    bad = {k: err(dev[k], t_ex[k]) for k in dev if not err(dev[k], t_ex[k]) < TOL_EXACT}
+    assert not bad, f"vs exact oracle above {TOL_EXACT}: {bad}"
+    print(f"bf16: widest derived bar {widest:.2e}")
     ok, _, _ = util.argmax_margin_ok(emu["logits"], got["argmax"], emu["argmax"], margin=5e-3)
     assert ok
 
