@@ -56,6 +56,20 @@ static hipError_t lin_gemm(hipStream_t st, int M, int N, int K, const float* A, 
   GemmParams P = lin_params(M, N, K, A, lda, W, ldw, C, ldc, o);
   if ((long)M * N >= 128L * 128 * 256 && !o.defer_splits)
     return launch_gemm<128, 128, BK, ASRC, BSRC, EPI_LIN>(st, P, 1);
+  if (o.slab && skinny_dma_ok(M, K, lda, ldw, BSRC == SRC_RC, 1, &N, &A, &W)) {
+    const int tiles = ((M + 63) / 64) * ((N + 63) / 64);
+    const int s = skinny_dma_splits(M, K, tiles, (size_t)N, o.slab_floats);
+    if ((size_t)s * M * N <= o.slab_floats && (s > 1 || o.defer_splits)) {
+      const long off = 0;
+      hipError_t e = skinny_dma(st, BSRC == SRC_RC, 1, M, K, &A, lda, &W, ldw, &N, o.slab, &off, s);
+      if (e != hipSuccess) return e;
+      if (o.defer_splits) {
+        *o.defer_splits = s;
+        return hipSuccess;
+      }
+      return lin_reduce_epilogue(st, M, N, s, o.slab, C, ldc, o);
+    }
+  }
   P.nk = (K + BKS - 1) / BKS;
   const int s = skinny_splits(M, N, K, o);
   if (o.defer_splits) {  // partials stay in the slab; the consumer kernel reduces them
@@ -92,6 +106,19 @@ static hipError_t batched_deferred(hipStream_t st, int nb, int M, int N, int K,
                                    const float* const* A, long lda, const float* const* W,
                                    long ldw, float* slab, size_t slab_floats, int* splits) {
   if (nb < 1 || nb > 3) return hipErrorInvalidValue;
+  {
+    const int Ns[3] = {N, N, N};
+    if (skinny_dma_ok(M, K, lda, ldw, BSRC == SRC_RC, nb, Ns, A, W)) {
+      const int tiles = ((M + 63) / 64) * ((N + 63) / 64);
+      const int s = skinny_dma_splits(M, K, nb * tiles, (size_t)nb * N, slab_floats);
+      if ((size_t)nb * s * M * N <= slab_floats) {
+        long off[3];
+        for (int i = 0; i < nb; ++i) off[i] = (long)i * s * M * N;
+        *splits = s;
+        return skinny_dma(st, BSRC == SRC_RC, nb, M, K, A, lda, W, ldw, Ns, slab, off, s);
+      }
+    }
+  }
   LinOpts o;
   o.slab = slab;
   o.slab_floats = slab_floats / nb;
@@ -133,6 +160,23 @@ hipError_t gemm_nt_hetero_deferred(hipStream_t st, int nb, int M, int K, const f
     nmax = N[i] > nmax ? N[i] : nmax;
     tiles += ((M + 63) / 64) * ((N[i] + 63) / 64);
     nsum += (size_t)N[i];
+  }
+  {
+    const float* As[3] = {A, A, A};
+    if (skinny_dma_ok(M, K, lda, ldw, false, nb, N, As, W)) {
+      const int s = skinny_dma_splits(M, K, tiles, nsum, slab_floats);
+      if ((size_t)s * M * nsum <= slab_floats) {
+        long o2[3];
+        size_t acc = 0;
+        for (int i = 0; i < nb; ++i) {
+          o2[i] = (long)acc;
+          off[i] = acc;
+          acc += (size_t)s * M * N[i];
+        }
+        *splits = s;
+        return skinny_dma(st, false, nb, M, K, As, lda, W, ldw, N, slab, o2, s);
+      }
+    }
   }
   const int nk = (K + BKS - 1) / BKS;
   int s = (160 * nb + tiles - 1) / tiles;     // the merged launch stands for nb launches

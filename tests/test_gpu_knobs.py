@@ -22,6 +22,7 @@ KNOBS = [
     ({"RAU_ATT_WAVES_FWD": "4", "RAU_ATT_WAVES_BWD": "4"}, 72),
     ({"RAU_ATT_DMA_OFF": "1"}, 72),
     ({"RAU_WGRAD_DMA_OFF": "1"}, 72),
+    ({"RAU_SKINNY_DMA_OFF": "1"}, 72),
     ({"RAU_ATT_SPLIT": "1", "RAU_ATT_CHUNKS": "4"}, 72),
     ({"RAU_ATT_FUSED": "1"}, 24),
     ({"RAU_ENC_WS": "0"}, 24),

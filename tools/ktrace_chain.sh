@@ -1,0 +1,19 @@
+#!/bin/bash
+# kernel trace of one bench run; prints per-kernel durations of the recurrence's small kernels
+# usage (GPU box): bash tools/ktrace_chain.sh [bench args]      (development tool)
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+rm -rf $R/gpurun_out/sk
+rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/sk -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline "$@" > $R/gpurun_out/sk.log 2>&1
+cd $R && python3 - <<PY
+import csv, glob, collections
+f = glob.glob("gpurun_out/sk/**/*kernel_trace.csv", recursive=True)[0]
+d = collections.defaultdict(list)
+for r in csv.DictReader(open(f)):
+    n = r["Kernel_Name"]
+    if any(t in n for t in ("skinny", "lstm_", "lin_reduce", "gemm_kernel<64", "k_att_", "k_hop", "k_q")):
+        d[(n[:64], r.get("Grid_Size_X", r.get("Grid_Size", "")))].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+for k, v in sorted(d.items(), key=lambda kv: -sum(kv[1])):
+    v.sort()
+    print(k, len(v), "sum %.0f avg %.1f med %.1f min %.1f" % (sum(v), sum(v) / len(v), v[len(v) // 2], v[0]))
+PY
