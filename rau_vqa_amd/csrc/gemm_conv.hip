@@ -250,6 +250,8 @@ hipError_t conv_embed_wgrad(hipStream_t st, int nB, int D, int S, int M, const f
 
 hipError_t conv_embed_wgrad_b16(hipStream_t st, int nB, int D, int S, int M, const void* dZ16,
                                 const void* X16, float* dWi, float* slab) {
+  if (wgrad16_ok(M, D, S))
+    return wgrad16(st, nB, M, D, S, dZ16, (long)M * S, X16, (long)D * S, dWi, slab);
   GemmParams P{};
   P.M = M; P.N = D;
   P.A = reinterpret_cast<const float*>(dZ16); P.a_bs = (long)M * S;  // both in bf16 elements

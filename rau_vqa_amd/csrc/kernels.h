@@ -119,6 +119,25 @@ hipError_t conv_embed_dgrad(hipStream_t st, int nB, int D, int S, int M, const f
 // dWp[k,m] += sum_{b,s} dS[b,k,s] I[b,m,s]   and, with dZ = dI (1 - I^2),
 // dWi[m,d] += sum_{b,s} dZ[b,m,s] X'[b,d,s]
 size_t conv_wgrad_slab_floats(int nB, int rowsA, int rowsB, int S);
+// bf16-operand i_embed weight gradient on 14 x 14 maps, 256 x 256 tiles fed by LDS-DMA
+// (wgrad16.hip, round 3): dW[ra][rb] += sum_{b,s} A16[b][ra][s] B16[b][rb][s], operands bf16 in HBM
+// (a_bs / b_bs in elements).  _ok: S == 196, ra and rb multiples of 256; RAU_WGRAD16_OFF=1 keeps the
+// 128 x 128 register-staged tile (A/B knob).  The slab must hold wgrad16_slab_floats().
+bool wgrad16_ok(int ra, int rb, int S);
+size_t wgrad16_slab_floats(int nB, int ra, int rb, int S);
+hipError_t wgrad16(hipStream_t st, int nB, int ra, int rb, int S, const void* A16, long a_bs,
+                   const void* B16, long b_bs, float* dW, float* slab);
+// Split-K partials of the recurrence's skinny Linear GEMMs with LDS-DMA operand staging
+// (skinny_dma.hip, round 3): nprob (<= 3) problems C_p = A_p W_p^T (brc = false, W [N][K]) or
+// A_p W_p (brc = true, W [K][N]) of one M and K; problem p's partials at slab + off[p] laid out
+// [split][M][N[p]].  _ok: K % 32 == 0, 16-byte aligned rows, [K][N] weights a multiple of 64 wide;
+// RAU_SKINNY_DMA_OFF=1 keeps the register-staged tile of gemm_core.h (A/B knob).
+bool skinny_dma_ok(int M, int K, long lda, long ldb, bool brc, int nprob, const int* N,
+                   const float* const* A, const float* const* B);
+int skinny_dma_splits(int M, int K, int tiles_all, size_t cols_all, size_t slab_floats);
+hipError_t skinny_dma(hipStream_t st, bool brc, int nprob, int M, int K, const float* const* A,
+                      long lda, const float* const* B, long ldb, const int* N, float* slab,
+                      const long* off, int splits);
 // the same products with both operands staged by LDS-DMA (wgrad_dma.hip, round 3): 14 x 14 maps,
 // row counts multiples of 128, plain operands (dZ already final)
 bool wgrad_dma_ok(int ra, int rb, int S);

@@ -422,8 +422,9 @@ int rau_create(const rau_config* cfg, rau_ctx** out) {
   CK(dalloc(ctx, &ctx->dq, (size_t)B * Q));
   {
     // split-K workspaces: one per stream (the two streams run concurrently)
-    const size_t sl2 = std::max(conv_wgrad_slab_floats(H * B, A, M, S),
-                                conv_wgrad_slab_floats(H * B, M, D, S));
+    size_t sl2 = std::max(conv_wgrad_slab_floats(H * B, A, M, S),
+                          conv_wgrad_slab_floats(H * B, M, D, S));
+    if (ctx->bf16) sl2 = std::max(sl2, wgrad16_slab_floats(H * B, M, D, S));
     CK(dalloc(ctx, &ctx->slab2, sl2));
     const int rowsH = H * B, rowsT = T * B;
     const int shapes[][3] = {{K, M, rowsH},      {M, R, rowsH},      {4 * R, M, rowsH},

@@ -23,6 +23,8 @@ KNOBS = [
     ({"RAU_ATT_DMA_OFF": "1"}, 72),
     ({"RAU_WGRAD_DMA_OFF": "1"}, 72),
     ({"RAU_SKINNY_DMA_OFF": "1"}, 72),
+    ({"BF16": "1"}, 12),                                    # bf16 mode, wgrad16.hip on ...
+    ({"BF16": "1", "RAU_WGRAD16_OFF": "1"}, 12),            # ... and off (round-2 tile)
     ({"RAU_ATT_SPLIT": "1", "RAU_ATT_CHUNKS": "4"}, 72),
     ({"RAU_ATT_FUSED": "1"}, 24),
     ({"RAU_ENC_WS": "0"}, 24),
@@ -33,6 +35,7 @@ KNOBS = [
                                                   for e, b in KNOBS])
 def test_knob_setting_keeps_parity(env, batch):
     e = dict(os.environ, **env)
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "knob_check.py"), str(batch)],
+    args = [str(batch)] + (["bf16"] if env.get("BF16") else [])
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "knob_check.py")] + args,
                          env=e, cwd=ROOT, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]

@@ -186,6 +186,58 @@ int main(int argc, char** argv) {
       CK(hipFree(dS)); CK(hipFree(I)); CK(hipFree(dZ)); CK(hipFree(X)); CK(hipFree(dWp)); CK(hipFree(dWi)); CK(hipFree(slab));
     }
   }
+  if (want("wgrad16")) {
+    // bf16-operand i_embed weight gradient (configs[2]): conv_embed_wgrad_b16 -> wgrad16.hip;
+    // RAU_WGRAD16_OFF=1 times the round-2 128x128x32 register-staged tile instead
+    auto to_bf16 = [](float f) { uint32_t u; memcpy(&u, &f, 4); u += 0x7fff + ((u >> 16) & 1); return (uint16_t)(u >> 16); };
+    auto from_bf16 = [](uint16_t h) { uint32_t u = (uint32_t)h << 16; float f; memcpy(&f, &u, 4); return f; };
+    for (int D : {512, 2048}) {
+      {
+        const int nb = 5;
+        std::vector<uint16_t> hA((size_t)nb * M * S), hB((size_t)nb * D * S);
+        for (auto& v : hA) v = to_bf16(0.01f * ((rand() % 2001) / 1000.f - 1.f));
+        for (auto& v : hB) v = to_bf16((rand() % 2001) / 1000.f - 1.f);
+        uint16_t *dA, *dB; float *dW, *slab;
+        CK(hipMalloc(&dA, hA.size() * 2)); CK(hipMalloc(&dB, hB.size() * 2));
+        CK(hipMemcpy(dA, hA.data(), hA.size() * 2, hipMemcpyHostToDevice));
+        CK(hipMemcpy(dB, hB.data(), hB.size() * 2, hipMemcpyHostToDevice));
+        CK(hipMalloc(&dW, (size_t)M * D * 4)); CK(hipMemset(dW, 0, (size_t)M * D * 4));
+        size_t sl = conv_wgrad_slab_floats(nb, M, D, S); if (wgrad16_slab_floats(nb, M, D, S) > sl) sl = wgrad16_slab_floats(nb, M, D, S);
+        CK(hipMalloc(&slab, sl * 4));
+        CK(conv_embed_wgrad_b16(st, nb, D, S, M, dA, dB, dW, slab));
+        CK(hipStreamSynchronize(st));
+        std::vector<float> hW((size_t)M * D);
+        CK(hipMemcpy(hW.data(), dW, hW.size() * 4, hipMemcpyDeviceToHost));
+        double md = 0, mx = 0;
+        for (int m = 0; m < M; m += 3)
+          for (int d = 0; d < D; d += 7) {
+            double v = 0;
+            for (int b = 0; b < nb; ++b)
+              for (int s2 = 0; s2 < S; ++s2)
+                v += (double)from_bf16(hA[((size_t)b * M + m) * S + s2]) * from_bf16(hB[((size_t)b * D + d) * S + s2]);
+            md = fmax(md, fabs(v - hW[(size_t)m * D + d])); mx = fmax(mx, fabs(v));
+          }
+        printf("conv_embed_wgrad_b16 D=%d nB=%d vs host double: max |diff| %.3g (max |ref| %.3g)\n", D, nb, md, mx);
+        CK(hipFree(dA)); CK(hipFree(dB)); CK(hipFree(dW)); CK(hipFree(slab));
+      }
+      for (int nh : {1, 2}) {
+        const int nB = nh * B;
+        uint16_t *dZ, *X; float *dWi, *slab;
+        CK(hipMalloc(&dZ, (size_t)nB * M * S * 2)); CK(hipMalloc(&X, (size_t)nB * D * S * 2));
+        CK(hipMemset(dZ, 0x3c, (size_t)nB * M * S * 2)); CK(hipMemset(X, 0x3b, (size_t)nB * D * S * 2));
+        CK(hipMalloc(&dWi, (size_t)M * D * 4));
+        size_t sl = conv_wgrad_slab_floats(nB, M, D, S); if (wgrad16_slab_floats(nB, M, D, S) > sl) sl = wgrad16_slab_floats(nB, M, D, S);
+        CK(hipMalloc(&slab, sl * 4));
+        const double bytes = ((double)nB * M * S + (double)nB * D * S) * 2;
+        for (int rep = 0; rep < 2; ++rep) {
+          const double us = timeit(st, 10, [&] { return conv_embed_wgrad_b16(st, nB, D, S, M, dZ, X, dWi, slab); });
+          printf("  conv_embed_wgrad_b16 D=%d nB=%d: %.1f us  %.2f TB/s algorithmic  %.0f TFLOP/s\n", D, nB, us,
+                 bytes / us * 1e-6, 2.0 * M * D * (double)nB * S / us * 1e-6);
+        }
+        CK(hipFree(dZ)); CK(hipFree(X)); CK(hipFree(dWi)); CK(hipFree(slab));
+      }
+    }
+  }
   printf("done\n");
   return 0;
 }
