@@ -60,7 +60,8 @@ def classify(rows):
             out[i] = ("conv_att_pre", None)
     # conv weight gradients: with the tanh factor applied in the dgrad's epilogue both use the
     # plain (SC, SC) kernel; in stream order conv_att_wgrad precedes conv_embed_wgrad in every group
-    plain = [i for i, n in enumerate(names) if "128, 128, 28, 3, 3, 1, 0>" in n]
+    # (round 3: wgrad_dma.hip's k_wgrad_dma takes them on 14 x 14 maps)
+    plain = [i for i, n in enumerate(names) if "128, 128, 28, 3, 3, 1, 0>" in n or "k_wgrad_dma" in n]
     dtanh = [i for i, n in enumerate(names) if "128, 128, 28, 4, 3, 1, 0>" in n]
     if dtanh:
         for i in plain:

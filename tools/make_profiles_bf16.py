@@ -19,6 +19,7 @@ CLASSES = {
     "k_conv_sample<2, 2>": ("conv_att_dgrad", B * A * S * 4 + B * M * S * 4 + B * M * S * 2 + A * M * 4, 1024),
     "gemm_split_xcd_kernel<128, 128, 32, 3, 3, 1, 1>": ("conv_att_wgrad", (B * A * S + B * M * S) * 4, None),
     "gemm_split_xcd_kernel<128, 128, 32, 7, 7, 1, 1>": ("conv_embed_wgrad", B * M * S * 2 + B * D * S * 2, None),
+    "k_wgrad16": ("conv_embed_wgrad", B * M * S * 2 + B * D * S * 2, None),   # round 3 (wgrad16.hip)
     "k_dropout_features_b16": ("dropout_features", None, None),
 }
 def per_kernel(d, counter):
