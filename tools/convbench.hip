@@ -10,6 +10,7 @@
 #include <vector>
 #include <cmath>
 #include "../rau_vqa_amd/csrc/kernels.h"
+#include "exp_fwd16.h"
 using namespace rau;
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1);} } while (0)
@@ -235,6 +236,62 @@ int main(int argc, char** argv) {
                  bytes / us * 1e-6, 2.0 * M * D * (double)nB * S / us * 1e-6);
         }
         CK(hipFree(dZ)); CK(hipFree(X)); CK(hipFree(dWi)); CK(hipFree(slab));
+      }
+    }
+  }
+  if (want("fwd16")) {
+    // bf16-operand i_embed forward (configs[2]): the EXPERIMENT tools/exp_fwd16.hip vs host double, then
+    // its timing next to the library's kernel (conv_embed_fwd_b16)
+    auto to_bf16 = [](float f) { uint32_t u; memcpy(&u, &f, 4); u += 0x7fff + ((u >> 16) & 1); return (uint16_t)(u >> 16); };
+    auto from_bf16 = [](uint16_t h) { uint32_t u = (uint32_t)h << 16; float f; memcpy(&f, &u, 4); return f; };
+    for (int D : {512, 2048}) {
+      {
+        const int nb = 6;
+        std::vector<uint16_t> hX((size_t)nb * D * S);
+        std::vector<float> hW((size_t)M * D), hb(M);
+        for (auto& v : hX) v = to_bf16((rand() % 2001) / 1000.f - 1.f);
+        for (auto& v : hW) v = 0.05f * ((rand() % 2001) / 1000.f - 1.f);
+        for (auto& v : hb) v = 0.1f * ((rand() % 2001) / 1000.f - 1.f);
+        uint16_t *dX, *dWD; float *dWf, *dbias, *dI;
+        CK(hipMalloc(&dX, hX.size() * 2)); CK(hipMalloc(&dWD, (size_t)M * D * 2)); CK(hipMalloc(&dWf, (size_t)M * D * 4));
+        CK(hipMalloc(&dbias, M * 4)); CK(hipMalloc(&dI, (size_t)nb * M * S * 4));
+        CK(hipMemcpy(dX, hX.data(), hX.size() * 2, hipMemcpyHostToDevice));
+        CK(hipMemcpy(dWf, hW.data(), hW.size() * 4, hipMemcpyHostToDevice));
+        CK(hipMemcpy(dbias, hb.data(), hb.size() * 4, hipMemcpyHostToDevice));
+        CK(hipMemset(dI, 0xff, (size_t)nb * M * S * 4));
+        CK(weights_kblocked(st, M, D, dWf, dWD));
+        CK(fwd16(st, nb, D, S, M, dX, dWD, dbias, dI));
+        CK(hipStreamSynchronize(st));
+        std::vector<float> oI((size_t)nb * M * S);
+        CK(hipMemcpy(oI.data(), dI, oI.size() * 4, hipMemcpyDeviceToHost));
+        double md = 0, mx = 0; size_t nanc = 0;
+        for (size_t i = 0; i < oI.size(); ++i) if (oI[i] != oI[i]) ++nanc;
+        for (int b = 0; b < nb; ++b)
+          for (int m = 0; m < M; m += 5)
+            for (int s2 = 0; s2 < S; s2 += 3) {
+              double v = hb[m];
+              for (int d = 0; d < D; ++d) v += (double)from_bf16(to_bf16(hW[(size_t)m * D + d])) * from_bf16(hX[((size_t)b * D + d) * S + s2]);
+              v = tanh(v);
+              md = fmax(md, fabs(v - oI[((size_t)b * M + m) * S + s2])); mx = fmax(mx, fabs(v));
+            }
+        printf("fwd16 D=%d nB=%d vs host double: max |diff| %.3g (max |ref| %.3g), unwritten/NaN words %zu\n", D, nb, md, mx, nanc);
+        CK(hipFree(dX)); CK(hipFree(dWD)); CK(hipFree(dWf)); CK(hipFree(dbias)); CK(hipFree(dI));
+      }
+      for (int nh : {1, 2}) {
+        const int nB = nh * B;
+        uint16_t *X, *WD, *WT; float *bias, *I;
+        CK(hipMalloc(&X, (size_t)nB * D * S * 2)); CK(hipMalloc(&WD, (size_t)M * D * 2)); CK(hipMalloc(&WT, (size_t)M * D * 2));
+        CK(hipMemset(X, 0x3b, (size_t)nB * D * S * 2)); CK(hipMemset(WD, 0x3a, (size_t)M * D * 2)); CK(hipMemset(WT, 0x3a, (size_t)M * D * 2));
+        CK(hipMalloc(&bias, M * 4)); CK(hipMemset(bias, 0, M * 4));
+        CK(hipMalloc(&I, (size_t)nB * M * S * 4));
+        const double fb = (double)nB * D * S * 2 + (double)nB * M * S * 4, fl = 2.0 * M * D * (double)nB * S;
+        for (int rep = 0; rep < 2; ++rep) {
+          double us = timeit(st, 10, [&] { return fwd16(st, nB, D, S, M, X, WD, bias, I); });
+          printf("  fwd16            D=%d nB=%d: %.1f us  %.2f TB/s algorithmic  %.0f TFLOP/s\n", D, nB, us, fb / us * 1e-6, fl / us * 1e-6);
+          us = timeit(st, 10, [&] { return conv_embed_fwd_b16(st, nB, D, S, M, X, WT, bias, I); });
+          printf("  round-2 128x128  D=%d nB=%d: %.1f us  %.2f TB/s algorithmic  %.0f TFLOP/s\n", D, nB, us, fb / us * 1e-6, fl / us * 1e-6);
+        }
+        CK(hipFree(X)); CK(hipFree(WD)); CK(hipFree(WT)); CK(hipFree(bias)); CK(hipFree(I));
       }
     }
   }
