@@ -11,9 +11,10 @@ f = glob.glob("gpurun_out/sk/**/*kernel_trace.csv", recursive=True)[0]
 d = collections.defaultdict(list)
 for r in csv.DictReader(open(f)):
     n = r["Kernel_Name"]
-    if any(t in n for t in ("skinny", "lstm_", "lin_reduce", "gemm_kernel<64", "k_att_", "k_hop", "k_q")):
+    if True:
         d[(n[:64], r.get("Grid_Size_X", r.get("Grid_Size", "")))].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
 for k, v in sorted(d.items(), key=lambda kv: -sum(kv[1])):
     v.sort()
     print(k, len(v), "sum %.0f avg %.1f med %.1f min %.1f" % (sum(v), sum(v) / len(v), v[len(v) // 2], v[0]))
+print("total kernel time %.1f ms over %d kernels" % (sum(sum(v) for v in d.values()) / 1e3, sum(len(v) for v in d.values())))
 PY
