@@ -345,7 +345,9 @@ int rau_timer_begin(rau_ctx* ctx);
 int rau_timer_end(rau_ctx* ctx, float* ms);
 /* Average duration (ms) and launch count of the named kernel class since the
  * last rau_prof_reset, measured with HIP events on the ctx stream when
- * profiling is enabled (adds two events per launch; off by default). */
+ * profiling is enabled (adds two events per launch; off by default).
+ * on = 2: sparse -- only the launches of the bulk and weight-gradient streams and the
+ * recurrence's phase markers are bracketed, so the recurrence keeps its un-profiled pace. */
 int rau_prof_enable(rau_ctx* ctx, int on);
 int rau_prof_reset(rau_ctx* ctx);
 int rau_prof_count(rau_ctx* ctx);

@@ -190,6 +190,8 @@ struct rau_ctx {
   // timing
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   bool prof_on = false;
+  bool prof_sparse = false;   // rau_prof_enable(ctx, 2): chain-stream launches are NOT bracketed except phase
+                              // markers, so the recurrence runs at its un-profiled speed under the timeline
   std::vector<ProfCls> pcls;
   std::vector<ProfRec> precs;
   std::vector<hipEvent_t> evpool;
@@ -257,6 +259,12 @@ static inline hipEvent_t prof_event(rau_ctx* c) {
   return e;
 }
 
+// chain-stream classes the sparse timeline keeps (one launch each per phase boundary)
+static inline bool prof_marker(const char* n) {
+  for (const char* m : {"embed_fwd", "gather_q", "loss_reduce", "scale_hops", "dq_reduce", "embed_bwd"})
+    if (std::strcmp(n, m) == 0) return true;
+  return false;
+}
 // Launch wrapper: counts launches/FLOPs/bytes per kernel class and, when
 // profiling is on, brackets the launch with HIP events on the ctx stream.
 #define RUN(cname, fl, by, expr) RUNS(ctx->st, cname, fl, by, expr)
@@ -264,7 +272,7 @@ static inline hipEvent_t prof_event(rau_ctx* c) {
   do {                                                                                    \
     ProfRec pr_;                                                                          \
     int pc_ = -1;                                                                         \
-    if (ctx->prof_on) {                                                                   \
+    if (ctx->prof_on && !(ctx->prof_sparse && (rstream) == ctx->st && !prof_marker(cname))) { \
       pc_ = prof_class(ctx, cname);                                                       \
       ctx->pcls[pc_].launches++;                                                          \
       ctx->pcls[pc_].flops += (double)(fl);                                               \

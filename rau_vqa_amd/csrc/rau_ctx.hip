@@ -1920,6 +1920,7 @@ int rau_prof_enable(rau_ctx* ctx, int on) {
   if (!on)
     if (int rc = prof_collect(ctx)) return rc;
   ctx->prof_on = on != 0;
+  ctx->prof_sparse = on == 2;
   return RAU_OK;
 }
 int rau_prof_reset(rau_ctx* ctx) {

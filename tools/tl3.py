@@ -11,6 +11,8 @@ for line in open(sys.argv[1]):
 recs = steps[-1]
 # two steps per dump: split at second fill_masks group
 fm = [i for i, r in enumerate(recs) if r[0] == 'fill_masks']
+if not fm:   # evaluate mode draws no masks: a step starts at the bulk stream's first transpose
+    fm = [i for i, r in enumerate(recs) if r[0] == 'transpose']
 starts = [fm[i] for i in range(len(fm)) if i == 0 or fm[i] - fm[i-1] > 10]
 recs = recs[starts[-1]:]
 t0 = min(r[2] for r in recs)
