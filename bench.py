@@ -358,17 +358,49 @@ def main():
         fence()
         inf_s = (time.perf_counter() - t2) / 10
         extra["inference_qa_per_s"] = cfg.B / inf_s
-        # the evaluate-mode forward is HBM-bound by construction: i_embed / ifeatproj run
-        # once, each hop streams I [M,S] and P [A,S] of every sample once.  Algorithmic bytes per batch:
-        # X read + I, P written once, then H x (I + P) read, f32.
-        inf_bytes = 4.0 * cfg.B * cfg.S * (cfg.D + cfg.M + cfg.A + cfg.H * (cfg.M + cfg.A))
-        extra["inference"] = {"qa_per_s": cfg.B / inf_s, "ms_per_batch": inf_s * 1e3,
-                              "roofline": {"bound": "hbm", "achieved": inf_bytes / inf_s / 1e9,
-                                           "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                           "frac": inf_bytes / inf_s / 1e9 / HBM_PEAK_GBS,
-                                           "algorithmic_bytes_per_batch": inf_bytes},
-                              "note": "whole evaluate-mode forward (encoder + conv once + 8 hops), wall time over "
-                                      "10 batches; the hop chain's ~60 dependent launches bound it, not HBM"}
+        # Roofline of the evaluate-mode forward (i_embed / ifeatproj once, encoder, H hops).  Per QA pair:
+        # FLOPs = convs + encoder + hops (Linears + attention), bytes = X read, I and P written once and
+        # read once per hop (f32).  At the reference's sizes the MFMA floor (0.41 GFLOP/QA / 157 TFLOP/s)
+        # is 3.5x the HBM floor, so the bound is the matrix pipe, not HBM (SURVEY 8f next-2 assumed HBM).
+        def inference_roofline(c, secs):
+            fl = (2.0 * c.S * (c.M * c.D + c.A * c.M)
+                  + c.T * (2.0 * 4 * c.Rq * c.E + 3 * 2.0 * 4 * c.Rq * c.Rq)
+                  + 2.0 * c.Q * c.M
+                  + c.H * (2.0 * c.R * (c.M + c.S + 4 * c.R) + 2.0 * c.M * c.A + 2.0 * c.S * c.M
+                           + 2.0 * c.M * 4 * c.R + 2.0 * c.R * c.M + 2.0 * c.M * c.K
+                           + 2.0 * c.S * (c.A + c.M))) * c.B
+            by = 4.0 * c.B * c.S * (c.D + c.M + c.A + c.H * (c.M + c.A))
+            t_mfma, t_hbm = fl / (MFMA_F32_PEAK_TFLOPS * 1e12), by / (HBM_PEAK_GBS * 1e9)
+            return {"bound": "mfma" if t_mfma >= t_hbm else "hbm",
+                    "achieved": fl / secs / 1e12, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": fl / secs / 1e12 / MFMA_F32_PEAK_TFLOPS,
+                    "flops_per_batch": fl, "algorithmic_bytes_per_batch": by,
+                    "hbm_gbs_algorithmic": by / secs / 1e9, "hbm_frac": by / secs / 1e9 / HBM_PEAK_GBS}
+        extra["inference"] = {"qa_per_s": cfg.B / inf_s, "batch": cfg.B, "ms_per_batch": inf_s * 1e3,
+                              "roofline": inference_roofline(cfg, inf_s),
+                              "note": "whole evaluate-mode forward, wall time over 10 batches; at this batch the "
+                                      "27 encoder steps and 8 hops (~90 dependent launches) bound it"}
+        m.training()
+        # the same forward at a serving batch (the recurrences' launch chain does not grow with the batch)
+        if world == 1 and args.dtype == "f32" and not args.graph and args.batch == 256:
+            from dataclasses import replace
+            cfg_b = replace(cfg, B=1024)
+            mb = RAU(cfg_b)
+            mb.set_params(m.get_params())
+            mb.set_batch(**synth.make_batch(cfg_b.B, cfg.T, cfg.V, cfg.D, cfg.S, cfg.K, seed=5, lens="full"))
+            mb.evaluate()
+            for i in range(2):
+                mb.forward()
+            mb.sync()
+            t4 = time.perf_counter()
+            for i in range(5):
+                mb.forward()
+            mb.sync()
+            inf_b = (time.perf_counter() - t4) / 5
+            mb.close()
+            extra["inference_b1024"] = {"qa_per_s": cfg_b.B / inf_b, "batch": cfg_b.B,
+                                        "ms_per_batch": inf_b * 1e3,
+                                        "roofline": inference_roofline(cfg_b, inf_b)}
         m.training()
         if world == 1 and not args.no_cpu_baseline:
             extra["cpu_baseline"] = cpu_baseline(cfgd)

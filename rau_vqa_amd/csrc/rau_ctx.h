@@ -139,6 +139,7 @@ struct rau_ctx {
   void* WpT16 = nullptr;
   void* xd16 = nullptr;  // RAU_BF16 step path, S % 4 == 0: the same maps stored as bf16 (xd stays unwritten)
   bool I_shared = false;  // evaluate mode: i_embed output is hop-invariant, computed once
+  bool yq_shared = false; // no dropout on q (evaluate mode): q_embed's question half is hop-invariant, rows of hop 0 only
   float *WiT, *WpT;   // i_embed / ifeatproj weights transposed ([D][M], [M][A]), refreshed per forward
   float *P0;          // [B][A][S] hop-invariant attention pre-activation (evaluate mode)
   float *qd, *Yq, *qf, *I, *T, *u, *zm, *a, *jv, *j, *g4, *cc, *hh, *tc, *mf, *logits,

@@ -940,7 +940,7 @@ int hop_forward_chain(rau_ctx* ctx, int h, const float* cp, const float* hp, flo
   float *slab_z = slab_t + off[1], *slab_g = slab_t + off[2];
   {  // qf = tanh(Yq + h_prev Wh^T): the q half (with both biases) was computed for all hops at once
     LinOpts o;
-    o.addend = ctx->Yq + (size_t)h * BM_;
+    o.addend = ctx->Yq + (ctx->yq_shared ? 0 : (size_t)h * BM_);
     o.add_rs = M;
     o.act = 1;
     RUN("lin_reduce", 0, 0, lin_reduce_epilogue(st, B, M, ns_t, slab_t + off[0], qf, M, o));
@@ -1396,12 +1396,15 @@ int rau_forward(rau_ctx* ctx) {
   const size_t BM_ = (size_t)B * M, BR_ = (size_t)B * R;
   RUN("apply_mask", 0, (double)H * B * Q * 8,
       apply_mask(st, (size_t)H * B * Q, (size_t)B * Q, ctx->q, m_q, sc(RAU_MASK_Q), ctx->qd));
-  {
+  {  // q_embed's question half (SS:233) for every hop clone; without dropout on q (evaluate mode) the
+     // clones see the same rows: computed once
+    ctx->yq_shared = (m_q == nullptr);
+    const int qrows = ctx->yq_shared ? B : H * B;
     LINOPTS(o);
     o.bias = ctx->q_proj.b;
     o.bias2 = ctx->h_proj.b;
-    RUN("q_proj_gemm", gflop(H * B, M, Q), 0,
-        gemm_nt(st, H * B, M, Q, ctx->qd, Q, ctx->q_proj.W, Q, ctx->Yq, M, o));
+    RUN("q_proj_gemm", gflop(qrows, M, Q), 0,
+        gemm_nt(st, qrows, M, Q, ctx->qd, Q, ctx->q_proj.W, Q, ctx->Yq, M, o));
   }
   // i_embed SS:238-242 does not depend on the recurrence: all hops in one launch.
   // Train mode: each hop clone has its own dropout mask on the feature map

@@ -284,6 +284,7 @@ int rau_multimodal_forward(rau_ctx* ctx, int h, const float* q, const float* X, 
   float* qd = ctx->qd + (size_t)h * B * Q;
   RUN("apply_mask", 0, (double)B * Q * 8,
       apply_mask(st, (size_t)B * Q, (size_t)B * Q, q, m.q, m.s_q, qd, (size_t)h * B * Q));
+  ctx->yq_shared = false;   // this path fills the hop's own rows
   {
     LINOPTS(o);
     o.bias = ctx->q_proj.b;
