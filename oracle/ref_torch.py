@@ -78,8 +78,8 @@ class _Conv1x1BF16(torch.autograd.Function):
     def backward(ctx, dy):
         x, W = ctx.saved_tensors
         dyr = _rb(dy)
-        # exact_dx: on 14x14 maps the attention dgrad runs on the exact-f32 per-sample kernel in
-        # every dtype (its epilogue also forms dZ and the bias row sums), so no operand is rounded
+        # exact_dx: on 14x14 maps whose sizes dgrad16.hip does not take (M % 128, A % 32) the attention
+        # dgrad runs on the exact-f32 per-sample kernel in every dtype: no operand is rounded
         dx = (torch.einsum("oi,bos->bis", W, dy) if ctx.exact_dx
               else torch.einsum("oi,bos->bis", _rb(W), dyr))
         dW = torch.einsum("bos,bis->oi", dyr, _rb(x))
@@ -151,7 +151,8 @@ def multimodal(sh, P, q, feats4d, prev_c, prev_h, mq, mx, mmf, bf16=False):
     qatt = F.linear(qf, P["att_q.W"], P["att_q.b"]).unsqueeze(2).expand(B, sh.A, sh.S)
     # librau dispatch: per-sample exact-f32 dgrad when 176 < S <= 208 and S % 4 == 0 (gemm_sample.hip)
     iproj = _conv1x1(ifeat, P["att_i.W"], P["att_i.b"], bf16,
-                     exact_dx=(sh.S % 4 == 0 and 176 < sh.S <= 208 and sh.M % 4 == 0))
+                     exact_dx=(sh.S % 4 == 0 and 176 < sh.S <= 208 and sh.M % 4 == 0
+                               and not (sh.S == 196 and sh.M % 128 == 0 and sh.A % 32 == 0)))
     addfeat = torch.tanh(iproj + qatt).reshape(B, sh.A, sh.S, 1)
     attscore = F.conv2d(addfeat, P["att_score.W"].view(1, sh.A, 1, 1),
                         P["att_score.b"]).reshape(B, sh.S)

@@ -1,0 +1,204 @@
+// dgrad16.hip -- RAU_BF16 mode: attbycontent's input gradient on 14 x 14 maps with bf16 MFMA operands.
+//
+//   dZ[b, m, s] = ( sum_k Wp[k, m] * dS[b, k, s]  +  dj[b, m] * a[b, s] ) * (1 - I[b, m, s]^2)
+//   rs[b, m]    = sum_s dZ[b, m, s]
+//
+// (reference SS:565-579: the gradient of ifeatproj + attselect w.r.t. i_embed's output, then through
+//  i_embed's tanh; rs is the per-sample part of i_embed's bias gradient.)  Rounds 1-3 ran this product
+// on the exact-f32 per-sample kernel in every dtype (gemm_sample.hip EPI 2): 105 GFLOP per step on the
+// f32 matrix pipe, 1.6 of the 9.1 ms of the configs[2] step.  Here both GEMM operands are rounded to
+// bf16 (RNE) while they are staged into LDS, as the mode's other four conv GEMMs do, and the product
+// runs on v_mfma_f32_16x16x32_bf16 with f32 accumulation; the epilogue (rank-1 term, tanh derivative,
+// row sums) stays f32.  The kernel is then bound by its operands' bytes, not by the matrix pipe.
+//
+// Tiling = gemm_sample.hip's: 128 rows x ALL positions of ONE sample per workgroup (1024 tiles per
+// hop at M = 512, B = 256; whole 784-byte rows of dS in, one contiguous block of dZ out), 4 waves x
+// (32 rows x 208 columns = 2 x 13 accumulator blocks).  K-step 32: an LDS element is the 16-byte
+// k-octet {k .. k+7} of one position (X image [4][208]) or one row (W image [4][128]), which is exactly
+// one lane's MFMA operand (lane l: position / row l & 15, octet l >> 4), read with ds_read_b128.
+// Both sources are k-major in memory ([k][s], [k][m]): a thread loads the same four columns of eight
+// consecutive k rows and transposes in registers.  Two stages, register-staged loads one K-step ahead,
+// one barrier per K-step.
+#include "common.h"
+#include "kernels.h"
+
+namespace rau {
+
+namespace {
+
+constexpr int GS = 196, GS4 = GS / 4;          // positions per sample
+constexpr int GNCB = 13, GBN = GNCB * 16;      // 208 columns (12 zero pad columns)
+constexpr int GBM = 128;                       // rows per tile
+constexpr int GBK = 32, GKO = GBK / 8;         // K-step, octets per K-step
+constexpr int GXST = GKO * GBN;                // uint4 elements of the X image (832)
+constexpr int GWST = GKO * GBM;                // of the W image (512)
+constexpr int GSTAGE = GXST + GWST;            // 1344 x 16 B = 21.5 KB
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+struct Dgrad16Params {
+  int M, K, nB, tiles_m;
+  const float* Wt; long w_rs;          // [K][M]  (Wp as stored)
+  const float* X; long x_bs;           // [b][K][S]  (dS)
+  void* C; long c_bs;                  // [b][M][S]  dZ, f32 or bf16 elements
+  const float* dj; const float* av;    // [b][M], [b][S]
+  const float* Y; float* rs;           // I [b][M][S]; rs [b][M]
+  int c16;
+};
+
+__device__ __forceinline__ uint32_t pack2(float lo, float hi) {
+  bf16x2 v;
+  v[0] = (__bf16)lo;
+  v[1] = (__bf16)hi;
+  return __builtin_bit_cast(uint32_t, v);
+}
+// column c (0..3) of eight float4 rows -> the k-octet of that column
+#define OCTET(r, c)                                                                          \
+  make_uint4(pack2(r[0].c, r[1].c), pack2(r[2].c, r[3].c), pack2(r[4].c, r[5].c), pack2(r[6].c, r[7].c))
+
+__global__ __launch_bounds__(256, 2) void k_dgrad16(const Dgrad16Params P) {
+  __shared__ __attribute__((aligned(16))) uint4 smem[2 * GSTAGE];
+  const int tid = threadIdx.x, l = tid & 63, w = tid >> 6;
+  const int lr = l & 15, lq = l >> 4;
+  const int nwg = P.tiles_m * P.nB;
+  const int id = xcd_remap(blockIdx.x, nwg);      // the row tiles of one sample share an XCD's L2
+  const int tm = id % P.tiles_m, b = id / P.tiles_m;
+  const int m0 = tm * GBM;
+  const float* Xb = P.X + (size_t)b * P.x_bs;
+
+  // staging items: X (octet ko, position quad q4) for tid < 4 * 49; W (octet ko, row quad mq) for tid < 128
+  const bool x_on = tid < GKO * GS4, w_on = tid < GKO * (GBM / 4);
+  const int x_ko = x_on ? tid / GS4 : 0, x_q4 = x_on ? tid - x_ko * GS4 : 0;
+  const int w_ko = w_on ? tid / (GBM / 4) : 0, w_mq = w_on ? tid % (GBM / 4) : 0;
+  const float* x_ptr = Xb + (size_t)(8 * x_ko) * GS + 4 * x_q4;
+  const float* w_ptr = P.Wt + (size_t)(8 * w_ko) * P.w_rs + m0 + 4 * w_mq;
+
+  // zero the pad columns [196, 208) of both X images once: no load ever writes them
+  for (int e = tid; e < 2 * GKO * (GBN - GS); e += 256) {
+    const int st = e / (GKO * (GBN - GS)), r = e % (GKO * (GBN - GS));
+    smem[st * GSTAGE + (r / (GBN - GS)) * GBN + GS + r % (GBN - GS)] = make_uint4(0u, 0u, 0u, 0u);
+  }
+
+  f32x4 acc[2][GNCB];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < GNCB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nsteps = P.K / GBK;
+  float4 rx[8], rw[8];
+  auto load = [&](int T) {
+    const size_t k0 = (size_t)T * GBK;
+    if (x_on) {
+#pragma unroll
+      for (int r = 0; r < 8; ++r) rx[r] = *reinterpret_cast<const float4*>(x_ptr + (k0 + r) * GS);
+    }
+    if (w_on) {
+#pragma unroll
+      for (int r = 0; r < 8; ++r) rw[r] = *reinterpret_cast<const float4*>(w_ptr + (k0 + r) * P.w_rs);
+    }
+  };
+  auto store = [&](int stage) {
+    uint4* Xs = smem + stage * GSTAGE;
+    uint4* Ws = Xs + GXST;
+    if (x_on) {
+      uint4* d = Xs + x_ko * GBN + 4 * x_q4;
+      d[0] = OCTET(rx, x); d[1] = OCTET(rx, y); d[2] = OCTET(rx, z); d[3] = OCTET(rx, w);
+    }
+    if (w_on) {
+      uint4* d = Ws + w_ko * GBM + 4 * w_mq;
+      d[0] = OCTET(rw, x); d[1] = OCTET(rw, y); d[2] = OCTET(rw, z); d[3] = OCTET(rw, w);
+    }
+  };
+  auto compute = [&](int stage) {
+    const uint4* Xs = smem + stage * GSTAGE + lq * GBN + lr;
+    const uint4* Ws = smem + stage * GSTAGE + GXST + lq * GBM + 32 * w + lr;
+    const bf16x8 a0 = __builtin_bit_cast(bf16x8, Ws[0]);
+    const bf16x8 a1 = __builtin_bit_cast(bf16x8, Ws[16]);
+#pragma unroll
+    for (int j = 0; j < GNCB; ++j) {
+      // dS as the MFMA's A operand, Wp as its B operand: the accumulator block is C^T, a lane's four
+      // registers are four CONSECUTIVE positions of one row m (16-byte / 8-byte stores)
+      const bf16x8 xb = __builtin_bit_cast(bf16x8, Xs[16 * j]);
+      acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xb, a0, acc[0][j], 0, 0, 0);
+      acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xb, a1, acc[1][j], 0, 0, 0);
+    }
+  };
+
+  if (nsteps > 0) {
+    load(0);
+    store(0);
+  }
+  __syncthreads();
+  for (int T = 0; T < nsteps; ++T) {
+    const int cur = T & 1;
+    const bool more = T + 1 < nsteps;
+    if (more) load(T + 1);
+    compute(cur);
+    if (more) store(cur ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue (as gemm_sample.hip EPI 2): accumulator (i, j) register r =
+  // C[m0 + 32 w + 16 i + lr][16 j + 4 lq + r]
+  float* rowv = reinterpret_cast<float*>(smem);   // [128] dj of this sample's rows
+  float* colv = rowv + GBM;                        // [208] a of this sample's positions
+  if (tid < GBM) rowv[tid] = P.dj[(size_t)b * P.M + m0 + tid];
+  if (tid < GBN) colv[tid] = tid < GS ? P.av[(size_t)b * GS + tid] : 0.f;
+  __syncthreads();
+  const float* Yb = P.Y + (size_t)b * P.c_bs;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int rl = 32 * w + 16 * i + lr;
+    const int m = m0 + rl;
+    const float rv = rowv[rl];
+    float rsum = 0.f;
+#pragma unroll
+    for (int j = 0; j < GNCB; ++j) {
+      const int s = 16 * j + 4 * lq;
+      if (s >= GS) continue;   // 196 % 4 == 0: a quad is all valid or all pad
+      const float4 c4 = *reinterpret_cast<const float4*>(colv + s);
+      const float4 y = *reinterpret_cast<const float4*>(Yb + (size_t)m * GS + s);
+      float4 v = make_float4(acc[i][j][0] + rv * c4.x, acc[i][j][1] + rv * c4.y,
+                             acc[i][j][2] + rv * c4.z, acc[i][j][3] + rv * c4.w);
+      v.x *= 1.f - y.x * y.x; v.y *= 1.f - y.y * y.y;
+      v.z *= 1.f - y.z * y.z; v.w *= 1.f - y.w * y.w;
+      rsum += (v.x + v.y) + (v.z + v.w);
+      const size_t e = (size_t)b * P.c_bs + (size_t)m * GS + s;
+      if (P.c16)
+        *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(P.C) + e) =
+            make_uint2(pack2(v.x, v.y), pack2(v.z, v.w));
+      else
+        *reinterpret_cast<float4*>(reinterpret_cast<float*>(P.C) + e) = v;
+    }
+    // the four lanes lr, lr + 16, lr + 32, lr + 48 hold the row's four position quarters
+    rsum += __shfl_xor(rsum, 16, 64);
+    rsum += __shfl_xor(rsum, 32, 64);
+    if (lq == 0) P.rs[(size_t)b * P.M + m] = rsum;
+  }
+}
+#undef OCTET
+
+}  // namespace
+
+bool dgrad16_ok(int M, int K, int S, long w_rs) {
+  return S == GS && M % GBM == 0 && K % GBK == 0 && K >= GBK && w_rs % 4 == 0;
+}
+
+hipError_t dgrad16(hipStream_t st, int nB, int M, int K, int S, const float* Wt, long w_rs,
+                   const float* X, long x_bs, void* C, long c_bs, const float* dj, const float* av,
+                   const float* Y, float* rs, int c16) {
+  if (!dgrad16_ok(M, K, S, w_rs)) return hipErrorInvalidValue;
+  if (nB == 0) return hipSuccess;
+  Dgrad16Params P{};
+  P.M = M; P.K = K; P.nB = nB; P.tiles_m = M / GBM;
+  P.Wt = Wt; P.w_rs = w_rs;
+  P.X = X; P.x_bs = x_bs;
+  P.C = C; P.c_bs = c_bs;
+  P.dj = dj; P.av = av; P.Y = Y; P.rs = rs; P.c16 = c16;
+  hipLaunchKernelGGL(k_dgrad16, dim3(P.tiles_m * nB), dim3(256), 0, st, P);
+  return hipGetLastError();
+}
+
+}  // namespace rau

@@ -137,7 +137,9 @@ bool conv_dz_fused_ok(int S, int M, int bf16) {
 }
 hipError_t conv_att_dgrad_dz(hipStream_t st, int nB, int M, int S, int A, const float* dS,
                              const float* Wp, const float* dj, const float* a, const float* I,
-                             float* dZ, float* rs, int dz16) {
+                             float* dZ, float* rs, int dz16, int bf16) {
+  if (bf16 == 1 && dgrad16_ok(M, A, S, M))
+    return dgrad16(st, nB, M, A, S, Wp, M, dS, (long)A * S, dZ, (long)M * S, dj, a, I, rs, dz16);
   int n4 = 0;
   if (wide_on(4) && conv_wide_ok(M, A, S, M) && nB >= 4) {
     n4 = nB & ~3;

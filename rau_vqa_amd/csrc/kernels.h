@@ -112,7 +112,14 @@ hipError_t conv_att_dgrad(hipStream_t st, int nB, int M, int S, int A, const flo
 bool conv_dz_fused_ok(int S, int M, int bf16);
 hipError_t conv_att_dgrad_dz(hipStream_t st, int nB, int M, int S, int A, const float* dS,
                              const float* Wp, const float* dj, const float* a, const float* I,
-                             float* dZ, float* rs, int dz16 = 0);   // dz16: dZ stored as bf16
+                             float* dZ, float* rs, int dz16 = 0,    // dz16: dZ stored as bf16
+                             int bf16 = 0);   // RAU_BF16 mode: bf16-rounded GEMM operands where dgrad16 applies
+// RAU_BF16 mode, 14 x 14 maps, M % 128 == 0, K % 32 == 0 (dgrad16.hip): the product above with both GEMM
+// operands rounded to bf16 while staged, f32 accumulate and epilogue; C = dZ as f32 or bf16 elements
+bool dgrad16_ok(int M, int K, int S, long w_rs);
+hipError_t dgrad16(hipStream_t st, int nB, int M, int K, int S, const float* Wt, long w_rs,
+                   const float* X, long x_bs, void* C, long c_bs, const float* dj, const float* av,
+                   const float* Y, float* rs, int c16);
 // dX'[b,d,s] = sum_m Wi[m,d] dZ[b,m,s]   (dead in feval, SS:579; module-level API only)
 hipError_t conv_embed_dgrad(hipStream_t st, int nB, int D, int S, int M, const float* dZ,
                             const float* Wi, float* dX);
@@ -276,6 +283,11 @@ hipError_t att_bwd_split(hipStream_t st, int nB, int M, int A, int S, const floa
 hipError_t dropout_features(hipStream_t st, int H, size_t per_hop, const float* X,
                             const uint32_t* mask, float mscale, float* xd, size_t mask_e0 = 0,
                             int SL = 0, int Sp = 0);
+// The same pass (f32 or, b16 != 0, bf16 output) drawing the site's keep bits itself instead of reading
+// them: per_hop % 16 == 0, logical == physical layout; bit-identical to fill_masks + dropout_features
+hipError_t dropout_features_gen(hipStream_t st, uint64_t seed, uint32_t site, uint32_t step, float p,
+                                const uint64_t* key_dev, int H, size_t per_hop, const float* X,
+                                float mscale, void* xd, int b16);
 // RAU_BF16 mode (S % 4 == 0): the same values stored as bf16, [h][i], the form conv_embed_fwd_b16 /
 // conv_embed_wgrad_b16 read
 hipError_t dropout_features_b16(hipStream_t st, int H, size_t per_hop, const float* X,

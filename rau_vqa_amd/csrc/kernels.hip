@@ -1391,6 +1391,62 @@ __global__ void k_dropout_features_b16(int H, size_t per4, const float4* __restr
     }
   }
 }
+// The same two passes drawing their keep bits themselves (the step path when the site's mask is not
+// caller-supplied): a thread owns 16 consecutive elements = one Philox block per hop, so the bits never
+// travel through memory and fill_masks' pass over the site (44 us at D = 512, 163 us at D = 2048 per
+// step, in front of the first conv GEMM) disappears under this pass's HBM time.  Same (seed, site,
+// step, element) -> bit function as fill_masks: the masks are bit-identical.
+template <bool B16>
+__global__ void k_dropout_features_gen(uint64_t seed, uint32_t site, uint32_t step, uint32_t thr,
+                                       const uint64_t* __restrict__ key, int H, size_t per16,
+                                       const float4* __restrict__ X, float mscale,
+                                       void* __restrict__ xd) {
+  if (key) {
+    seed = key[0];
+    step = (uint32_t)key[1];
+  }
+  for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < per16;
+       t += (size_t)gridDim.x * blockDim.x) {
+    float4 x[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) x[i] = X[4 * t + i];
+    for (int h = 0; h < H; ++h) {
+      const uint32_t bits = philox_keep16(seed, site, step, (size_t)h * per16 + t, thr);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const uint32_t nib = bits >> (4 * i);
+        float4 o;
+        o.x = (nib & 1u) ? x[i].x * mscale : 0.f;
+        o.y = (nib & 2u) ? x[i].y * mscale : 0.f;
+        o.z = (nib & 4u) ? x[i].z * mscale : 0.f;
+        o.w = (nib & 8u) ? x[i].w * mscale : 0.f;
+        const size_t q = ((size_t)h * per16 + t) * 4 + i;
+        if (B16) {
+          typedef __bf16 b16x4 __attribute__((ext_vector_type(4)));
+          b16x4 v;
+          v[0] = (__bf16)o.x; v[1] = (__bf16)o.y; v[2] = (__bf16)o.z; v[3] = (__bf16)o.w;
+          reinterpret_cast<uint2*>(xd)[q] = __builtin_bit_cast(uint2, v);
+        } else {
+          reinterpret_cast<float4*>(xd)[q] = o;
+        }
+      }
+    }
+  }
+}
+hipError_t dropout_features_gen(hipStream_t st, uint64_t seed, uint32_t site, uint32_t step, float p,
+                                const uint64_t* key_dev, int H, size_t per_hop, const float* X,
+                                float mscale, void* xd, int b16) {
+  if (per_hop % 16 != 0) return hipErrorInvalidValue;
+  const uint32_t thr = (uint32_t)lroundf(p * 256.0f);
+  const size_t per16 = per_hop / 16;
+  if (b16)
+    hipLaunchKernelGGL(k_dropout_features_gen<true>, dim3(grid_for(per16)), dim3(256), 0, st, seed, site,
+                       step, thr, key_dev, H, per16, reinterpret_cast<const float4*>(X), mscale, xd);
+  else
+    hipLaunchKernelGGL(k_dropout_features_gen<false>, dim3(grid_for(per16)), dim3(256), 0, st, seed, site,
+                       step, thr, key_dev, H, per16, reinterpret_cast<const float4*>(X), mscale, xd);
+  return hipGetLastError();
+}
 // Pitched rows (S not a multiple of 4): the mask is defined over the LOGICAL tensor
 // [.., rows, SL], the data has row pitch Sp; pad columns are written as zeros.
 __global__ void k_dropout_features_pitch(int H, size_t rows, int SL, int Sp,

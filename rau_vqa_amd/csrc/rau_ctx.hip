@@ -1350,11 +1350,20 @@ int rau_forward(rau_ctx* ctx) {
     hipStream_t sb = ctx->st2;
     HIPC(hipEventRecord(ctx->evA, st));
     HIPC(hipStreamWaitEvent(sb, ctx->evA, 0));
-    if (int rc = gen_masks(ctx, -1, RAU_MASK_X, sb)) return rc;
+    // feature-map dropout, SS:239: unless the caller supplied the mask, the pass that makes the H masked
+    // copies draws the keep bits itself (they have no other reader on this path)
+    const bool x16 = m_x && ctx->xd16;   // bf16 mode: the hop copies of the feature map are stored as bf16
+    const bool x_gen = m_x && !ctx->mexplicit[RAU_MASK_X] && SL == S && ((size_t)B * D * S) % 16 == 0;
+    if (!x_gen)
+      if (int rc = gen_masks(ctx, -1, RAU_MASK_X, sb)) return rc;
     RUNS(sb, "transpose", 0, (double)M * D * 8, transpose2d(sb, M, D, ctx->i_embed.W, ctx->WiT, ctx->WiT16));
     RUNS(sb, "transpose", 0, (double)A * M * 8, transpose2d(sb, A, M, ctx->att_i.W, ctx->WpT, ctx->WpT16));
-    const bool x16 = m_x && ctx->xd16;   // bf16 mode: the hop copies of the feature map are stored as bf16
-    if (x16)
+    if (x_gen)
+      RUNS(sb, "dropout_features", 0, (double)(x16 ? H + 2 : 2 * H + 2) * B * D * S * 2,
+           dropout_features_gen(sb, ctx->seed, RAU_MASK_X, ctx->step, ctx->mp[RAU_MASK_X], ctx->dkey, H,
+                                (size_t)B * D * S, ctx->feats, sc(RAU_MASK_X),
+                                x16 ? (void*)ctx->xd16 : (void*)ctx->xd, x16 ? 1 : 0));
+    else if (x16)
       RUNS(sb, "dropout_features", 0, (double)(H + 2) * B * D * S * 2,
            dropout_features_b16(sb, H, (size_t)B * D * S, ctx->feats, m_x, sc(RAU_MASK_X), ctx->xd16));
     else if (m_x)
@@ -1567,7 +1576,7 @@ int rau_backward(rau_ctx* ctx, const float* hop_w) {
                conv_att_dgrad_dz(sb, nH, M, S, A, ctx->T + hb * A * S, ctx->att_i.W, ctx->dj + hb * M,
                                  ctx->a + hb * S, ctx->I + hb * M * S,
                                  ctx->xd16 ? (float*)((uint16_t*)ctx->dZ + hb * M * S) : ctx->dZ + hb * M * S,
-                                 ctx->dbi_part + hb * M, ctx->xd16 ? 1 : 0));
+                                 ctx->dbi_part + hb * M, ctx->xd16 ? 1 : 0, ctx->bf16));
         else
           RUNS(sb, "conv_att_dgrad", gflop(M, (double)nH * S, A),
                ((double)nH * A * S + 2.0 * nH * M * S) * 4,

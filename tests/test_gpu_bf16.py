@@ -105,6 +105,13 @@ def test_bf16_resnet_channels_d2048():
     run(dims, 0.05)
 
 
+def test_bf16_dgrad16_tile_shapes():
+    """14x14 map with M % 128 == 0 and A % 32 == 0: the attention dgrad runs on dgrad16.hip (bf16-rounded
+    dS and Wp); two row tiles per sample, odd sample count."""
+    dims = dict(B=5, T=4, V=40, E=16, Rq=32, D=64, S=196, M=256, A=64, R=32, K=52, H=2)
+    run(dims, 0.1)
+
+
 def test_bf16_7x7_feature_map_s49():
     dims = dict(B=6, T=5, V=40, E=8, Rq=16, D=24, S=49, M=40, A=20, R=16, K=12, H=3)
     run(dims, 0.5)
