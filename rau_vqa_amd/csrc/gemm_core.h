@@ -858,8 +858,11 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& P, const int bx, con
   }
 }
 
+#ifndef RAU_B16_FWD_WGS
+#define RAU_B16_FWD_WGS 4   // workgroups per CU of the forward bf16 kernels with pre-converted weights
+#endif
 template <int BM, int BN, int BKT, int ASRC, int BSRC, int EPI, int DT = 0>
-__global__ __launch_bounds__(256, DT == 1 ? 3 : 2) void gemm_kernel(const GemmParams P) {
+__global__ __launch_bounds__(256, DT == 1 ? (ASRC == SRC_RC_B16 ? RAU_B16_FWD_WGS : 3) : 2) void gemm_kernel(const GemmParams P) {
   gemm_tile<BM, BN, BKT, ASRC, BSRC, EPI, DT>(P, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 

@@ -19,6 +19,7 @@
 using namespace rau;
 
 // LinOpts pre-wired with the ctx's split-K workspace
+constexpr int kEncHeadTokens = 4;   // tokens whose layer-1 input projection stays on the chain stream
 #define LINOPTS(name) LinOpts name; name.slab = ctx->slab; name.slab_floats = ctx->slab_floats
 
 // ------------------------------------------------------------------ errors
@@ -94,7 +95,8 @@ struct rau_ctx {
   hipStream_t st2 = nullptr;   // bulk stream: hop-batched 1x1-conv GEMMs, overlapped with the chain
   hipStream_t st3 = nullptr;   // weight-gradient stream: throughput GEMMs nobody waits for until the end
   hipEvent_t evA = nullptr, evD = nullptr, evW = nullptr, evE = nullptr, evW3 = nullptr,
-             evM3 = nullptr, evEnd = nullptr, evE1 = nullptr, evHd = nullptr;
+             evM3 = nullptr, evEnd = nullptr, evE1 = nullptr, evHd = nullptr,
+             evG0 = nullptr, evG = nullptr, evQ0 = nullptr, evQ = nullptr, evDq = nullptr;   // side-stream forks / joins
   std::vector<hipEvent_t> evH;       // per hop: forward chain done (the head stream waits on it)
   std::vector<hipEvent_t> evF, evK;  // per hop group: forward bulk done / backward chain done
   // hops per bulk launch (pipelines the bulk GEMMs with the hop loops): gsize[h] = n if hops
@@ -150,6 +152,7 @@ struct rau_ctx {
   // persistent encoder forward (enc_ws.hip): device error word (a bounded spin gave up), copied to pinned memory behind the launch
   bool enc_ws = false;          // weight-stationary persistent encoder forward (enc_ws.hip): evaluate mode
   bool enc_ws_train = false;    // ... and in training steps
+  int side_split_env = -1;      // RAU_SIDE_SPLIT=0|1 (A/B variable); -1 = by shape, see side_split()
   unsigned* ws_cnt = nullptr;   // its 16 progress counters
   int* perr_d = nullptr;
   int* perr_h = nullptr;
@@ -201,6 +204,15 @@ struct rau_ctx {
 // Effective drop probability of a mask site.  Masks the device draws itself (Philox, 8-bit draws)
 // drop with p quantised to 1/256 and scale by 1/(1-pq), so that E[mask * scale] = 1 exactly;
 // caller-supplied masks (rau_set_mask) are nn.Dropout's: scale 1/(1-p) with the configured p.
+// Non-recurrent GEMMs of the recurrence's stream (layer-1 input projection beyond the first tokens,
+// q_embed's question half of hops 1.., the dq terms of finished backward groups) run on the
+// weight-gradient stream where the recurrence is the longer path: evaluate mode, bf16 mode (forward
+// phase bound by the encoder), contexts of up to 64 samples.  In the f32 step at 256 samples the bulk
+// stream is the longer path and the extra concurrency costs it 1 %.
+inline bool side_split(const rau_ctx* ctx) {
+  if (ctx->side_split_env >= 0) return ctx->side_split_env != 0;
+  return ctx->mode == RAU_MODE_EVAL || ctx->bf16 || ctx->cfg.B <= 64;
+}
 inline float mask_p(const rau_ctx* ctx, int site) {
   return ctx->mexplicit[site] ? ctx->mp_exact[site] : ctx->mp[site];
 }

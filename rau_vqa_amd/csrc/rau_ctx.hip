@@ -179,7 +179,8 @@ int rau_create(const rau_config* cfg, rau_ctx** out) {
   hipEventCreate(&ctx->ev0);
   hipEventCreate(&ctx->ev1);
   const unsigned evflags = hipEventDisableTiming;
-  for (hipEvent_t* e : {&ctx->evA, &ctx->evD, &ctx->evW, &ctx->evE, &ctx->evW3, &ctx->evM3, &ctx->evEnd, &ctx->evE1})
+  for (hipEvent_t* e : {&ctx->evA, &ctx->evD, &ctx->evW, &ctx->evE, &ctx->evW3, &ctx->evM3, &ctx->evEnd, &ctx->evE1,
+                        &ctx->evG0, &ctx->evG, &ctx->evQ0, &ctx->evQ, &ctx->evDq})
     hipEventCreateWithFlags(e, evflags);
   {
     int plo = 0, phi = 0;
@@ -367,6 +368,7 @@ int rau_create(const rau_config* cfg, rau_ctx** out) {
     // Every workgroup reads all h rows of its sample half each step, so the traffic grows with B while
     // the weights it avoids re-reading do not: training contexts up to 32 samples, inference up to 64.
     ctx->enc_ws_train = enc_ws_ok(B, Rq) && (e ? std::atoi(e) != 0 : B <= 32);
+    if (const char* ss = std::getenv("RAU_SIDE_SPLIT")) ctx->side_split_env = std::atoi(ss) != 0;
     ctx->enc_ws = enc_ws_ok(B, Rq) && (e ? std::atoi(e) != 0 : B <= 64);
     float* f = nullptr;
     CK(dalloc(ctx, &f, 16));
@@ -497,7 +499,8 @@ void rau_destroy(rau_ctx* ctx) {
   for (auto e : ctx->evpool) hipEventDestroy(e);
   if (ctx->ev0) hipEventDestroy(ctx->ev0);
   if (ctx->ev1) hipEventDestroy(ctx->ev1);
-  for (hipEvent_t e : {ctx->evA, ctx->evD, ctx->evW, ctx->evE, ctx->evW3, ctx->evM3, ctx->evEnd, ctx->evE1})
+  for (hipEvent_t e : {ctx->evA, ctx->evD, ctx->evW, ctx->evE, ctx->evW3, ctx->evM3, ctx->evEnd, ctx->evE1,
+                       ctx->evG0, ctx->evG, ctx->evQ0, ctx->evQ, ctx->evDq})
     if (e) hipEventDestroy(e);
   if (ctx->st3) hipStreamDestroy(ctx->st3);
   if (ctx->perr_h) hipHostFree(ctx->perr_h);
@@ -1237,14 +1240,32 @@ int rau_forward(rau_ctx* ctx) {
     RUN("embed_fwd", 0, rows * E * 8.0,
         embed_fwd(st, rows, E, c.V, ctx->grp[RAU_GROUP_EMBED].w, ctx->tokens, m_we, sc(RAU_MASK_WE),
                   ctx->we));
-    {  // layer-1 input projection of every token at once (no recurrence in it)
+    const bool ws_path = (ctx->mode == RAU_MODE_EVAL ? ctx->enc_ws : ctx->enc_ws_train) && ctx->perr_h;
+    // Layer-1 input projection of every token (no recurrence in it).  Only the first tokens' rows
+    // are needed at once: they stay on this stream, the rest runs on the weight-gradient stream
+    // (idle in the forward pass) and the wavefront waits for it where it first reads it.
+    const int t_head = (!ws_path && side_split(ctx) && TL > kEncHeadTokens) ? kEncHeadTokens : TL;
+    {
       LINOPTS(o);
       o.bias = ctx->i2h[0].b;
       o.bias2 = ctx->h2h[0].b;
-      RUN("enc_i2h_gemm", gflop(rows, 4 * Rq, E), 0,
-          gemm_nt(st, rows, 4 * Rq, E, ctx->we, E, ctx->i2h[0].W, E, ctx->G1, 4 * Rq, o));
+      RUN("enc_i2h_gemm", gflop(t_head * B, 4 * Rq, E), 0,
+          gemm_nt(st, t_head * B, 4 * Rq, E, ctx->we, E, ctx->i2h[0].W, E, ctx->G1, 4 * Rq, o));
     }
-    if ((ctx->mode == RAU_MODE_EVAL ? ctx->enc_ws : ctx->enc_ws_train) && ctx->perr_h) {
+    if (t_head < TL) {
+      HIPC(hipEventRecord(ctx->evG0, st));            // embed_fwd is done
+      HIPC(hipStreamWaitEvent(ctx->st3, ctx->evG0, 0));
+      LinOpts o;
+      o.slab = ctx->slab3; o.slab_floats = ctx->slab3_floats;
+      o.bias = ctx->i2h[0].b;
+      o.bias2 = ctx->h2h[0].b;
+      const int r1 = (TL - t_head) * B;
+      RUNS(ctx->st3, "enc_i2h_gemm", gflop(r1, 4 * Rq, E), 0,
+           gemm_nt(ctx->st3, r1, 4 * Rq, E, ctx->we + (size_t)t_head * B * E, E, ctx->i2h[0].W, E,
+                   ctx->G1 + (size_t)t_head * G4, 4 * Rq, o));
+      HIPC(hipEventRecord(ctx->evG, ctx->st3));
+    }
+    if (ws_path) {
       // both layers, all tokens: one launch, weights resident in registers (enc_ws.hip)
       EncWsParams q{};
       q.B = B; q.R = Rq; q.TL = TL;
@@ -1260,6 +1281,7 @@ int rau_forward(rau_ctx* ctx) {
     } else if (ctx->mode == RAU_MODE_EVAL) {
       // one launch per wavefront step: gate GEMM + cell fused (lstm_fused.hip)
       for (int s = 1; s <= TL + 1; ++s) {
+        if (s == t_head + 1 && t_head < TL) HIPC(hipStreamWaitEvent(st, ctx->evG, 0));   // G1 rows of token s
         LstmStepParams sp{};
         sp.B = B; sp.R = Rq;
         double fl = 0;
@@ -1294,6 +1316,7 @@ int rau_forward(rau_ctx* ctx) {
       }
     } else
     for (int s = 1; s <= TL + 1; ++s) {
+      if (s == t_head + 1 && t_head < TL) HIPC(hipStreamWaitEvent(st, ctx->evG, 0));   // G1 rows of token s
       const float* Ap[3];
       const float* Wp[3];
       int nb = 0, i0 = -1, i1 = -1, i2 = -1;
@@ -1405,15 +1428,30 @@ int rau_forward(rau_ctx* ctx) {
   const size_t BM_ = (size_t)B * M, BR_ = (size_t)B * R;
   RUN("apply_mask", 0, (double)H * B * Q * 8,
       apply_mask(st, (size_t)H * B * Q, (size_t)B * Q, ctx->q, m_q, sc(RAU_MASK_Q), ctx->qd));
+  bool q_split = false;
   {  // q_embed's question half (SS:233) for every hop clone; without dropout on q (evaluate mode) the
      // clones see the same rows: computed once
     ctx->yq_shared = (m_q == nullptr);
-    const int qrows = ctx->yq_shared ? B : H * B;
+    // with dropout: hop 0's rows here, the other hops' rows on the weight-gradient stream (hop 1 waits)
+    q_split = !ctx->yq_shared && side_split(ctx) && H > 1;
+    const int qrows = (ctx->yq_shared || q_split) ? B : H * B;
     LINOPTS(o);
     o.bias = ctx->q_proj.b;
     o.bias2 = ctx->h_proj.b;
     RUN("q_proj_gemm", gflop(qrows, M, Q), 0,
         gemm_nt(st, qrows, M, Q, ctx->qd, Q, ctx->q_proj.W, Q, ctx->Yq, M, o));
+  }
+  if (q_split) {
+    HIPC(hipEventRecord(ctx->evQ0, st));            // qd is complete
+    HIPC(hipStreamWaitEvent(ctx->st3, ctx->evQ0, 0));
+    LinOpts o;
+    o.slab = ctx->slab3; o.slab_floats = ctx->slab3_floats;
+    o.bias = ctx->q_proj.b;
+    o.bias2 = ctx->h_proj.b;
+    RUNS(ctx->st3, "q_proj_gemm", gflop((H - 1) * B, M, Q), 0,
+         gemm_nt(ctx->st3, (H - 1) * B, M, Q, ctx->qd + (size_t)B * Q, Q, ctx->q_proj.W, Q,
+                 ctx->Yq + (size_t)B * M, M, o));
+    HIPC(hipEventRecord(ctx->evQ, ctx->st3));
   }
   // i_embed SS:238-242 does not depend on the recurrence: all hops in one launch.
   // Train mode: each hop clone has its own dropout mask on the feature map
@@ -1430,6 +1468,7 @@ int rau_forward(rau_ctx* ctx) {
       HIPC(hipStreamWaitEvent(st, ctx->evF[h], 0));  // this group's I and P are ready
       gstart = h;
     }
+    if (h == 1 && q_split) HIPC(hipStreamWaitEvent(st, ctx->evQ, 0));   // Yq rows of hops 1..
     if (int rc = hop_forward_chain(ctx, h, ctx->cc + (size_t)h * BR_, ctx->hh + (size_t)h * BR_,
                                    ctx->cc + (size_t)(h + 1) * BR_, ctx->hh + (size_t)(h + 1) * BR_,
                                    ctx->I + (ctx->I_shared ? 0 : (size_t)h * BM_ * S),
@@ -1534,6 +1573,8 @@ int rau_backward(rau_ctx* ctx, const float* hop_w) {
   const float* dc_next = nullptr;  // grad_att_c / grad_att_h zeros, SS:561-562
   float* dh_part = nullptr;        // gradient at next_h: K-split partials left by the previous hop
   int dh_part_ns = 0;
+  bool dq_side = false;
+  int dq_rows_left = HA;           // hops [0, dq_rows_left) whose dq term this stream still owes
   for (int h = HA - 1; h >= 0; --h) {
     float* dc_out = ctx->dcn[h & 1];
     {
@@ -1554,6 +1595,22 @@ int rau_backward(rau_ctx* ctx, const float* hop_w) {
         return rc;
     }
     dc_next = dc_out;
+    // dq's per-hop terms dq~_h Wq (ConcatTable backward, SS:579) do not feed the recurrence: the
+    // rows of a finished hop group go to the weight-gradient stream (idle until the hop loop
+    // ends); only the last group's stay on this stream, in front of dq_reduce below
+    if (gsz[h] && h > 0 && side_split(ctx)) {
+      const int nh = std::min(h + gsz[h], HA) - h;
+      HIPC(hipEventRecord(ctx->evK[h], st));
+      HIPC(hipStreamWaitEvent(ctx->st3, ctx->evK[h], 0));
+      LinOpts o;
+      o.slab = ctx->slab3; o.slab_floats = ctx->slab3_floats;
+      RUNS(ctx->st3, "q_proj_dgrad", gflop(nh * B, Q, M), 0,
+           gemm_nn(ctx->st3, nh * B, Q, M, ctx->dqt + (size_t)h * BM_, M, ctx->q_proj.W, Q,
+                   ctx->dQD + (size_t)h * B * Q, Q, o));
+      HIPC(hipEventRecord(ctx->evDq, ctx->st3));
+      dq_side = true;
+      dq_rows_left = h;       // hops [0, h) are still to do
+    }
     // ---------------- bulk stream: the 1x1-conv gradients are off the recurrence's
     // critical path (dZ only feeds weight gradients; the feature-map gradient is dead,
     // SS:579, never formed).  As soon as a hop group's chain is done its conv gradients
@@ -1620,9 +1677,10 @@ int rau_backward(rau_ctx* ctx, const float* hop_w) {
   }
   {  // dq = sum_h (dq~_h Wq) (.) mask_h     (ConcatTable backward, SS:579)
     LINOPTS(o);
-    if (HA > 0)
-      RUN("q_proj_dgrad", gflop(HA * B, Q, M), 0,
-          gemm_nn(st, HA * B, Q, M, ctx->dqt, M, ctx->q_proj.W, Q, ctx->dQD, Q, o));
+    if (dq_rows_left > 0)
+      RUN("q_proj_dgrad", gflop(dq_rows_left * B, Q, M), 0,
+          gemm_nn(st, dq_rows_left * B, Q, M, ctx->dqt, M, ctx->q_proj.W, Q, ctx->dQD, Q, o));
+    if (dq_side) HIPC(hipStreamWaitEvent(st, ctx->evDq, 0));
     RUN("dq_reduce", 0, (double)HA * B * Q * 4,
         dq_reduce(st, HA, (size_t)B * Q, ctx->dQD, m_q, sc(RAU_MASK_Q), ctx->dq));
   }

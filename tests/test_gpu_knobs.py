@@ -28,6 +28,8 @@ KNOBS = [
     ({"RAU_ATT_SPLIT": "1", "RAU_ATT_CHUNKS": "4"}, 72),
     ({"RAU_ATT_FUSED": "1"}, 24),
     ({"RAU_ENC_WS": "0"}, 24),
+    ({"RAU_SIDE_SPLIT": "1"}, 72),                          # the chain's non-recurrent GEMMs on the side stream
+    ({"RAU_SIDE_SPLIT": "0"}, 24),                          # ... and kept on the chain where they would be split
 ]
 
 
