@@ -40,11 +40,11 @@ typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 struct Dgrad16Params {
   int M, K, nB, tiles_m;
   const float* Wt; long w_rs;          // [K][M]  (Wp as stored)
-  const float* X; long x_bs;           // [b][K][S]  (dS)
+  const void* X; long x_bs;            // [b][K][S]  (dS), f32 or (x16) bf16 elements
   void* C; long c_bs;                  // [b][M][S]  dZ, f32 or bf16 elements
   const float* dj; const float* av;    // [b][M], [b][S]
   const float* Y; float* rs;           // I [b][M][S]; rs [b][M]
-  int c16;
+  int c16, x16;
 };
 
 __device__ __forceinline__ uint32_t pack2(float lo, float hi) {
@@ -53,10 +53,17 @@ __device__ __forceinline__ uint32_t pack2(float lo, float hi) {
   v[1] = (__bf16)hi;
   return __builtin_bit_cast(uint32_t, v);
 }
+// the same from rows that already hold bf16: c-th 16-bit field of eight uint2 rows
+__device__ __forceinline__ uint32_t pick2(uint2 lo, uint2 hi, int c) {
+  const uint32_t a = c < 2 ? lo.x : lo.y, b = c < 2 ? hi.x : hi.y;
+  return (c & 1) ? __builtin_amdgcn_perm(b, a, 0x07060302u) : __builtin_amdgcn_perm(b, a, 0x05040100u);
+}
+#define OCTET16(r, c) make_uint4(pick2(r[0], r[1], c), pick2(r[2], r[3], c), pick2(r[4], r[5], c), pick2(r[6], r[7], c))
 // column c (0..3) of eight float4 rows -> the k-octet of that column
 #define OCTET(r, c)                                                                          \
   make_uint4(pack2(r[0].c, r[1].c), pack2(r[2].c, r[3].c), pack2(r[4].c, r[5].c), pack2(r[6].c, r[7].c))
 
+template <bool X16>
 __global__ __launch_bounds__(256, 2) void k_dgrad16(const Dgrad16Params P) {
   __shared__ __attribute__((aligned(16))) uint4 smem[2 * GSTAGE];
   const int tid = threadIdx.x, l = tid & 63, w = tid >> 6;
@@ -65,13 +72,15 @@ __global__ __launch_bounds__(256, 2) void k_dgrad16(const Dgrad16Params P) {
   const int id = xcd_remap(blockIdx.x, nwg);      // the row tiles of one sample share an XCD's L2
   const int tm = id % P.tiles_m, b = id / P.tiles_m;
   const int m0 = tm * GBM;
-  const float* Xb = P.X + (size_t)b * P.x_bs;
+  const float* Xb = reinterpret_cast<const float*>(P.X) + (size_t)b * P.x_bs;
+  const uint16_t* Xb16 = reinterpret_cast<const uint16_t*>(P.X) + (size_t)b * P.x_bs;
 
   // staging items: X (octet ko, position quad q4) for tid < 4 * 49; W (octet ko, row quad mq) for tid < 128
   const bool x_on = tid < GKO * GS4, w_on = tid < GKO * (GBM / 4);
   const int x_ko = x_on ? tid / GS4 : 0, x_q4 = x_on ? tid - x_ko * GS4 : 0;
   const int w_ko = w_on ? tid / (GBM / 4) : 0, w_mq = w_on ? tid % (GBM / 4) : 0;
   const float* x_ptr = Xb + (size_t)(8 * x_ko) * GS + 4 * x_q4;
+  const uint16_t* x_ptr16 = Xb16 + (size_t)(8 * x_ko) * GS + 4 * x_q4;
   const float* w_ptr = P.Wt + (size_t)(8 * w_ko) * P.w_rs + m0 + 4 * w_mq;
 
   // zero the pad columns [196, 208) of both X images once: no load ever writes them
@@ -88,9 +97,15 @@ __global__ __launch_bounds__(256, 2) void k_dgrad16(const Dgrad16Params P) {
 
   const int nsteps = P.K / GBK;
   float4 rx[8], rw[8];
+  uint2 rx16[8];
   auto load = [&](int T) {
     const size_t k0 = (size_t)T * GBK;
-    if (x_on) {
+    if (X16) {
+      if (x_on) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) rx16[r] = *reinterpret_cast<const uint2*>(x_ptr16 + (k0 + r) * GS);
+      }
+    } else if (x_on) {
 #pragma unroll
       for (int r = 0; r < 8; ++r) rx[r] = *reinterpret_cast<const float4*>(x_ptr + (k0 + r) * GS);
     }
@@ -104,7 +119,11 @@ __global__ __launch_bounds__(256, 2) void k_dgrad16(const Dgrad16Params P) {
     uint4* Ws = Xs + GXST;
     if (x_on) {
       uint4* d = Xs + x_ko * GBN + 4 * x_q4;
-      d[0] = OCTET(rx, x); d[1] = OCTET(rx, y); d[2] = OCTET(rx, z); d[3] = OCTET(rx, w);
+      if (X16) {
+        d[0] = OCTET16(rx16, 0); d[1] = OCTET16(rx16, 1); d[2] = OCTET16(rx16, 2); d[3] = OCTET16(rx16, 3);
+      } else {
+        d[0] = OCTET(rx, x); d[1] = OCTET(rx, y); d[2] = OCTET(rx, z); d[3] = OCTET(rx, w);
+      }
     }
     if (w_on) {
       uint4* d = Ws + w_ko * GBM + 4 * w_mq;
@@ -131,14 +150,29 @@ __global__ __launch_bounds__(256, 2) void k_dgrad16(const Dgrad16Params P) {
     store(0);
   }
   __syncthreads();
-  for (int T = 0; T < nsteps; ++T) {
+  for (int T = 0; T + 1 < nsteps; ++T) {
     const int cur = T & 1;
-    const bool more = T + 1 < nsteps;
-    if (more) load(T + 1);
+    load(T + 1);
     compute(cur);
-    if (more) store(cur ^ 1);
+    store(cur ^ 1);
     __syncthreads();
   }
+  // The epilogue reads this tile's 100 KB of I.  Its 26 loads per lane go out HERE, in front of the
+  // last K-step's MFMAs (the staging registers are dead by now), so their latency is covered once
+  // instead of once per batch the compiler would otherwise form inside the epilogue.
+  const float* Yb = P.Y + (size_t)b * P.c_bs;
+  float4 yv[2][GNCB];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < GNCB; ++j) {
+      const int s = 16 * j + 4 * lq;
+      yv[i][j] = s < GS ? *reinterpret_cast<const float4*>(Yb + (size_t)(m0 + 32 * w + 16 * i + lr) * GS + s)
+                        : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  __builtin_amdgcn_sched_barrier(0);
+  if (nsteps > 0) compute((nsteps - 1) & 1);
+  __syncthreads();
 
   // ---- epilogue (as gemm_sample.hip EPI 2): accumulator (i, j) register r =
   // C[m0 + 32 w + 16 i + lr][16 j + 4 lq + r]
@@ -147,7 +181,6 @@ __global__ __launch_bounds__(256, 2) void k_dgrad16(const Dgrad16Params P) {
   if (tid < GBM) rowv[tid] = P.dj[(size_t)b * P.M + m0 + tid];
   if (tid < GBN) colv[tid] = tid < GS ? P.av[(size_t)b * GS + tid] : 0.f;
   __syncthreads();
-  const float* Yb = P.Y + (size_t)b * P.c_bs;
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int rl = 32 * w + 16 * i + lr;
@@ -159,7 +192,7 @@ __global__ __launch_bounds__(256, 2) void k_dgrad16(const Dgrad16Params P) {
       const int s = 16 * j + 4 * lq;
       if (s >= GS) continue;   // 196 % 4 == 0: a quad is all valid or all pad
       const float4 c4 = *reinterpret_cast<const float4*>(colv + s);
-      const float4 y = *reinterpret_cast<const float4*>(Yb + (size_t)m * GS + s);
+      const float4 y = yv[i][j];
       float4 v = make_float4(acc[i][j][0] + rv * c4.x, acc[i][j][1] + rv * c4.y,
                              acc[i][j][2] + rv * c4.z, acc[i][j][3] + rv * c4.w);
       v.x *= 1.f - y.x * y.x; v.y *= 1.f - y.y * y.y;
@@ -179,6 +212,7 @@ __global__ __launch_bounds__(256, 2) void k_dgrad16(const Dgrad16Params P) {
   }
 }
 #undef OCTET
+#undef OCTET16
 
 }  // namespace
 
@@ -187,8 +221,8 @@ bool dgrad16_ok(int M, int K, int S, long w_rs) {
 }
 
 hipError_t dgrad16(hipStream_t st, int nB, int M, int K, int S, const float* Wt, long w_rs,
-                   const float* X, long x_bs, void* C, long c_bs, const float* dj, const float* av,
-                   const float* Y, float* rs, int c16) {
+                   const void* X, long x_bs, void* C, long c_bs, const float* dj, const float* av,
+                   const float* Y, float* rs, int c16, int x16) {
   if (!dgrad16_ok(M, K, S, w_rs)) return hipErrorInvalidValue;
   if (nB == 0) return hipSuccess;
   Dgrad16Params P{};
@@ -196,8 +230,9 @@ hipError_t dgrad16(hipStream_t st, int nB, int M, int K, int S, const float* Wt,
   P.Wt = Wt; P.w_rs = w_rs;
   P.X = X; P.x_bs = x_bs;
   P.C = C; P.c_bs = c_bs;
-  P.dj = dj; P.av = av; P.Y = Y; P.rs = rs; P.c16 = c16;
-  hipLaunchKernelGGL(k_dgrad16, dim3(P.tiles_m * nB), dim3(256), 0, st, P);
+  P.dj = dj; P.av = av; P.Y = Y; P.rs = rs; P.c16 = c16; P.x16 = x16;
+  if (x16) hipLaunchKernelGGL(k_dgrad16<true>, dim3(P.tiles_m * nB), dim3(256), 0, st, P);
+  else hipLaunchKernelGGL(k_dgrad16<false>, dim3(P.tiles_m * nB), dim3(256), 0, st, P);
   return hipGetLastError();
 }
 

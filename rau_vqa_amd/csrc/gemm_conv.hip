@@ -137,9 +137,10 @@ bool conv_dz_fused_ok(int S, int M, int bf16) {
 }
 hipError_t conv_att_dgrad_dz(hipStream_t st, int nB, int M, int S, int A, const float* dS,
                              const float* Wp, const float* dj, const float* a, const float* I,
-                             float* dZ, float* rs, int dz16, int bf16) {
+                             float* dZ, float* rs, int dz16, int bf16, int ds16) {
   if (bf16 == 1 && dgrad16_ok(M, A, S, M))
-    return dgrad16(st, nB, M, A, S, Wp, M, dS, (long)A * S, dZ, (long)M * S, dj, a, I, rs, dz16);
+    return dgrad16(st, nB, M, A, S, Wp, M, dS, (long)A * S, dZ, (long)M * S, dj, a, I, rs, dz16, ds16);
+  if (ds16) return hipErrorInvalidValue;
   int n4 = 0;
   if (wide_on(4) && conv_wide_ok(M, A, S, M) && nB >= 4) {
     n4 = nB & ~3;
@@ -235,6 +236,15 @@ hipError_t conv_att_wgrad(hipStream_t st, int nB, int M, int S, int A, const flo
   P.A = dS; P.a_bs = (long)A * S;
   P.B = I; P.b_bs = (long)M * S;
   return conv_wgrad_any<SRC_SC>(st, P, nB, S, dWp, slab, bf16);
+}
+
+hipError_t conv_att_wgrad_ds16(hipStream_t st, int nB, int M, int S, int A, const void* dS16,
+                               const float* I, float* dWp, float* slab) {
+  GemmParams P{};
+  P.M = A; P.N = M;
+  P.A = reinterpret_cast<const float*>(dS16); P.a_bs = (long)A * S;   // in bf16 elements
+  P.B = I; P.b_bs = (long)M * S;
+  return conv_wgrad<32, SRC_SC_B16, 1, SRC_SC>(st, P, nB, S, dWp, slab);
 }
 
 // dWi[m,d] += sum_{b,s} dZ[b,m,s] X'[b,d,s] with dZ = dI * (1 - I^2) formed while

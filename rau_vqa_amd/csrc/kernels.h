@@ -113,13 +113,17 @@ bool conv_dz_fused_ok(int S, int M, int bf16);
 hipError_t conv_att_dgrad_dz(hipStream_t st, int nB, int M, int S, int A, const float* dS,
                              const float* Wp, const float* dj, const float* a, const float* I,
                              float* dZ, float* rs, int dz16 = 0,    // dz16: dZ stored as bf16
-                             int bf16 = 0);   // RAU_BF16 mode: bf16-rounded GEMM operands where dgrad16 applies
+                             int bf16 = 0,    // RAU_BF16 mode ...
+                             int ds16 = 0);   // ... and dS points at bf16 elements (dgrad16 only)   // RAU_BF16 mode: bf16-rounded GEMM operands where dgrad16 applies
 // RAU_BF16 mode, 14 x 14 maps, M % 128 == 0, K % 32 == 0 (dgrad16.hip): the product above with both GEMM
 // operands rounded to bf16 while staged, f32 accumulate and epilogue; C = dZ as f32 or bf16 elements
 bool dgrad16_ok(int M, int K, int S, long w_rs);
 hipError_t dgrad16(hipStream_t st, int nB, int M, int K, int S, const float* Wt, long w_rs,
-                   const float* X, long x_bs, void* C, long c_bs, const float* dj, const float* av,
-                   const float* Y, float* rs, int c16);
+                   const void* X, long x_bs, void* C, long c_bs, const float* dj, const float* av,
+                   const float* Y, float* rs, int c16, int x16 = 0 /* X stored as bf16 */);
+// dWp += sum dS I^T in RAU_BF16 mode with dS stored as bf16 (att_bwd_fused's dS16), I f32
+hipError_t conv_att_wgrad_ds16(hipStream_t st, int nB, int M, int S, int A, const void* dS16,
+                               const float* I, float* dWp, float* slab);
 // dX'[b,d,s] = sum_m Wi[m,d] dZ[b,m,s]   (dead in feval, SS:579; module-level API only)
 hipError_t conv_embed_dgrad(hipStream_t st, int nB, int D, int S, int M, const float* dZ,
                             const float* Wi, float* dX);
@@ -263,7 +267,11 @@ hipError_t att_bwd_fused(hipStream_t st, int nB, int M, int A, int S, const floa
                          const float* u = nullptr,
                          // da_ns > 0: da_lin holds K-split partials [split][nB][SL] of dj Wf (summed
                          // by the kernel, plus the optional pitched addend da_add [nB][S])
-                         int da_ns = 0, int SL = 0, const float* da_add = nullptr);
+                         int da_ns = 0, int SL = 0, const float* da_add = nullptr,
+                         // dS16 != nullptr (only where att_bwd_dma_ok): dS leaves as bf16 [nB][A][S] there
+                         // and T_to_dS keeps P
+                         void* dS16 = nullptr);
+bool att_bwd_dma_ok(int M, int A, int S);
 // The same two passes cut into 4-wave workgroups (NC row chunks per sample, two launches per
 // pass): they always fit next to resident bulk-GEMM workgroups.  `part` is scratch of
 // att_split_part_floats(nB, S) floats.  T is never kept (the backward recomputes tanh(Psrc + u)

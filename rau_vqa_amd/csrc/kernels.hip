@@ -855,13 +855,16 @@ __global__ __launch_bounds__(NW * 64) void k_att_bwd_fused(
 // never changes -- row i has landed once at most 2 D - 2 younger operations are outstanding (D - 1
 // while the ring's first lap is still in flight; waiting for a smaller count is always safe).
 // Only the recompute form (Psrc != nullptr: the forward kept P, not tanh(P + u)) is built this way.
-template <int NW, int D>
+// DS16: dS leaves as bf16 (RNE) into its own [b][A][S] buffer instead of f32 in place over P -- RAU_BF16
+// mode, where both consumers of dS (attention dgrad, att_i weight gradient) round it to bf16 while
+// staging anyway: same values, half the bytes written here and read there.
+template <int NW, int D, bool DS16>
 __global__ __launch_bounds__(NW * 64) void k_att_bwd_dma(
     int M, int A, int S, const float* __restrict__ I, const float* __restrict__ dj,
     const float* __restrict__ a, const float* __restrict__ da_lin, const float* __restrict__ ws,
     float* __restrict__ T, float* __restrict__ dz, float* __restrict__ du, float* __restrict__ dwsp,
     const float* __restrict__ Psrc, const float* __restrict__ u, int da_ns, int SL, int nB,
-    const float* __restrict__ da_add) {
+    const float* __restrict__ da_add, uint16_t* __restrict__ dS16) {
   RAU_CHAIN_PRIO();
   extern __shared__ __attribute__((aligned(16))) float sm[];
   float* red = sm;                     // [NW][S]
@@ -975,7 +978,15 @@ __global__ __launch_bounds__(NW * 64) void k_att_bwd_dma(
         s2 = d4.x * t.x + d4.y * t.y + d4.z * t.z + d4.w * t.w;
       }
       // one store per iteration, always (its lanes past S/4 are masked off)
-      if (lane_on) reinterpret_cast<float4*>(Tb + (size_t)(w + NW * i) * S)[l] = o;
+      if (DS16) {
+        typedef __bf16 b16x4 __attribute__((ext_vector_type(4)));
+        b16x4 ob;
+        ob[0] = (__bf16)o.x; ob[1] = (__bf16)o.y; ob[2] = (__bf16)o.z; ob[3] = (__bf16)o.w;
+        if (lane_on)
+          reinterpret_cast<uint2*>(dS16 + ((size_t)b * A + w + NW * i) * S)[l] = __builtin_bit_cast(uint2, ob);
+      } else {
+        if (lane_on) reinterpret_cast<float4*>(Tb + (size_t)(w + NW * i) * S)[l] = o;
+      }
       s1 = wave_sum(s1);
       s2 = wave_sum(s2);
       if (l == i) { r1 = s1; r2 = s2; }
@@ -987,35 +998,43 @@ __global__ __launch_bounds__(NW * 64) void k_att_bwd_dma(
   }
 }
 
+// whether att_bwd_fused takes the LDS-DMA kernel for these sizes (the only one that can write dS as bf16)
+static bool att_bwd_dma_sizes(int nw, int M, int A, int S) {
+  static const bool dma_off = std::getenv("RAU_ATT_DMA_OFF") != nullptr;   // A/B knob
+  if (dma_off || S % 4 != 0 || S > 256 || A > 64 * 8 || M > 64 * 8 || (nw != 8 && nw != 16)) return false;
+  const int d = nw == 8 ? 8 : 4;
+  return ((size_t)(nw + 1) * S + nw + (size_t)nw * d * S + 256) * sizeof(float) <= 96 * 1024;
+}
+bool att_bwd_dma_ok(int M, int A, int S) { return att_bwd_dma_sizes(att_waves(true), M, A, S); }
+
 hipError_t att_bwd_fused(hipStream_t st, int nB, int M, int A, int S, const float* I,
                          const float* dj, const float* a, const float* da_lin,
                          const float* ws, float* T_to_dS, float* dz, float* du, float* dwsp,
                          const float* Psrc, const float* u, int da_ns, int SL,
-                         const float* da_add) {
+                         const float* da_add, void* dS16) {
   const int nw = att_waves(true);
-  static const bool dma_off = std::getenv("RAU_ATT_DMA_OFF") != nullptr;   // A/B knob
-  if (!dma_off && Psrc && u && S % 4 == 0 && S <= 256 && A <= 64 * 8 && M <= 64 * 8 && (nw == 8 || nw == 16)) {
+  if (Psrc && u && att_bwd_dma_sizes(nw, M, A, S)) {
     constexpr int kD8 = 8, kD16 = 4;
     const int d = nw == 8 ? kD8 : kD16;
     const size_t ldsd = ((size_t)(nw + 1) * S + nw + (size_t)nw * d * S + 256) * sizeof(float);
-    static bool attr = false;
-    if (!attr) {
-      hipFuncSetAttribute(reinterpret_cast<const void*>(k_att_bwd_dma<8, kD8>),
-                          hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-      hipFuncSetAttribute(reinterpret_cast<const void*>(k_att_bwd_dma<16, kD16>),
-                          hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-      attr = true;
-    }
-    if (ldsd <= 96 * 1024) {
-      if (nw == 8)
-        hipLaunchKernelGGL((k_att_bwd_dma<8, kD8>), dim3(nB), dim3(512), ldsd, st, M, A, S, I, dj, a, da_lin, ws,
-                           T_to_dS, dz, du, dwsp, Psrc, u, da_ns, SL, nB, da_add);
-      else
-        hipLaunchKernelGGL((k_att_bwd_dma<16, kD16>), dim3(nB), dim3(1024), ldsd, st, M, A, S, I, dj, a, da_lin,
-                           ws, T_to_dS, dz, du, dwsp, Psrc, u, da_ns, SL, nB, da_add);
-      return hipGetLastError();
-    }
+#define ATT_BWD_DMA(NW_, D_, B16_)                                                                     \
+  do {                                                                                                 \
+    static bool attr = false;                                                                          \
+    if (!attr) {                                                                                       \
+      hipFuncSetAttribute(reinterpret_cast<const void*>(k_att_bwd_dma<NW_, D_, B16_>),                 \
+                          hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);                      \
+      attr = true;                                                                                     \
+    }                                                                                                  \
+    hipLaunchKernelGGL((k_att_bwd_dma<NW_, D_, B16_>), dim3(nB), dim3(NW_ * 64), ldsd, st, M, A, S, I, \
+                       dj, a, da_lin, ws, T_to_dS, dz, du, dwsp, Psrc, u, da_ns, SL, nB, da_add,       \
+                       reinterpret_cast<uint16_t*>(dS16));                                             \
+  } while (0)
+    if (nw == 8) { if (dS16) ATT_BWD_DMA(8, kD8, true); else ATT_BWD_DMA(8, kD8, false); }
+    else { if (dS16) ATT_BWD_DMA(16, kD16, true); else ATT_BWD_DMA(16, kD16, false); }
+#undef ATT_BWD_DMA
+    return hipGetLastError();
   }
+  if (dS16) return hipErrorInvalidValue;   // callers ask for bf16 dS only where att_bwd_dma_ok says so
   const size_t lds = ((size_t)(nw + 1) * S + nw) * sizeof(float);
 #define ATT_BWD(NW_) hipLaunchKernelGGL(k_att_bwd_fused<NW_>, dim3(nB), dim3(NW_ * 64), lds, st, M, A, \
                                         S, I, dj, a, da_lin, ws, T_to_dS, dz, du, dwsp, Psrc, u, \

@@ -139,6 +139,8 @@ struct rau_ctx {
   float *xd;          // [H][B][D][S] feature map after per-hop dropout (train mode)
   void* WiT16 = nullptr;  // with xd16: bf16 copies of the transposed conv weights WiT, WpT
   void* WpT16 = nullptr;
+  void* dS16 = nullptr;  // with xd16: the attention backward's dS as bf16 [H][B][A][S] (both consumers round it anyway)
+  bool ds16_step = false;   // set by rau_backward while its hop loop runs: hop_backward writes dS16, not T
   void* xd16 = nullptr;  // RAU_BF16 step path, S % 4 == 0: the same maps stored as bf16 (xd stays unwritten)
   bool I_shared = false;  // evaluate mode: i_embed output is hop-invariant, computed once
   bool yq_shared = false; // no dropout on q (evaluate mode): q_embed's question half is hop-invariant, rows of hop 0 only

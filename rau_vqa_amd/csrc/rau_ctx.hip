@@ -340,6 +340,11 @@ int rau_create(const rau_config* cfg, rau_ctx** out) {
     CK(dalloc(ctx, &p16, ((size_t)A * M + 1) / 2));
     ctx->WiT16 = w16;
     ctx->WpT16 = p16;
+    if (dgrad16_ok(M, A, S, M) && att_bwd_dma_ok(M, A, S)) {
+      float* d16 = nullptr;
+      CK(dalloc(ctx, &d16, (HB * A * S + 1) / 2));
+      ctx->dS16 = d16;
+    }
   }
   CK(dalloc(ctx, &ctx->I, HB * M * S));
   CK(dalloc(ctx, &ctx->T, HB * A * S));
@@ -1153,7 +1158,8 @@ int hop_backward(rau_ctx* ctx, int h, const float* cp, const float* Ih, const Ho
     RUN("att_bwd_fused", 2.0 * B * S * (A + M), ((double)B * A * S * 2 + BM_ * S) * 4,
         att_bwd_fused(st, B, M, A, S, Ih, djh, ah, ctx->slab, ctx->att_score.W, Th, dzh, duh,
                       ctx->dwsp + (size_t)h * B * A, ctx->I_shared ? ctx->P0 : Th,
-                      ctx->u + (size_t)h * B * A, ns_a, SL, g.da_out));
+                      ctx->u + (size_t)h * B * A, ns_a, SL, g.da_out,
+                      ctx->ds16_step ? (void*)((uint16_t*)ctx->dS16 + (size_t)h * B * A * S) : nullptr));
   else
     RUN("att_bwd_split", 2.0 * B * S * (A + M), ((double)B * A * S * 2 + BM_ * S) * 4,
         att_bwd_split(st, B, M, A, S, Ih, djh, ah, ctx->slab, ctx->att_score.W, Th, dzh, duh,
@@ -1573,6 +1579,9 @@ int rau_backward(rau_ctx* ctx, const float* hop_w) {
   const float* dc_next = nullptr;  // grad_att_c / grad_att_h zeros, SS:561-562
   float* dh_part = nullptr;        // gradient at next_h: K-split partials left by the previous hop
   int dh_part_ns = 0;
+  // bf16 mode, train-mode step on 14x14 maps: dS goes out as bf16 (its consumers below read that)
+  ctx->ds16_step = ctx->dS16 && !ctx->I_shared && !ctx->att_split_env && conv_dz_fused_ok(S, M, ctx->bf16);
+  struct Ds16Reset { rau_ctx* c; ~Ds16Reset() { c->ds16_step = false; } } ds16_reset{ctx};
   bool dq_side = false;
   int dq_rows_left = HA;           // hops [0, dq_rows_left) whose dq term this stream still owes
   for (int h = HA - 1; h >= 0; --h) {
@@ -1630,16 +1639,25 @@ int rau_backward(rau_ctx* ctx, const float* hop_w) {
         if (dzf)
           RUNS(sb, "conv_att_dgrad", gflop(M, (double)nH * S, A),
                ((double)nH * A * S + 3.0 * nH * M * S) * 4,
-               conv_att_dgrad_dz(sb, nH, M, S, A, ctx->T + hb * A * S, ctx->att_i.W, ctx->dj + hb * M,
+               conv_att_dgrad_dz(sb, nH, M, S, A,
+                                 ctx->ds16_step ? (const float*)((const uint16_t*)ctx->dS16 + hb * A * S)
+                                                : ctx->T + hb * A * S,
+                                 ctx->att_i.W, ctx->dj + hb * M,
                                  ctx->a + hb * S, ctx->I + hb * M * S,
                                  ctx->xd16 ? (float*)((uint16_t*)ctx->dZ + hb * M * S) : ctx->dZ + hb * M * S,
-                                 ctx->dbi_part + hb * M, ctx->xd16 ? 1 : 0, ctx->bf16));
+                                 ctx->dbi_part + hb * M, ctx->xd16 ? 1 : 0, ctx->bf16, ctx->ds16_step ? 1 : 0));
         else
           RUNS(sb, "conv_att_dgrad", gflop(M, (double)nH * S, A),
                ((double)nH * A * S + 2.0 * nH * M * S) * 4,
                conv_att_dgrad(sb, nH, M, S, A, ctx->T + hb * A * S, ctx->att_i.W, ctx->dj + hb * M,
                               ctx->a + hb * S, ctx->dZ + hb * M * S, ctx->bf16));
         {   // RAU_BULK2: the att_i weight gradient (independent of dZ) on the second bulk stream
+          if (ctx->ds16_step)
+            RUNS(sb, "conv_att_wgrad", gflop(A, M, (double)nH * S),
+                 (double)nH * A * S * 2 + (double)nH * M * S * 4,
+                 conv_att_wgrad_ds16(sb, nH, M, S, A, (const uint16_t*)ctx->dS16 + hb * A * S,
+                                     ctx->I + hb * M * S, ctx->att_i.dW, ctx->slab2));
+          else
           RUNS(sb, "conv_att_wgrad", gflop(A, M, (double)nH * S),
                ((double)nH * A * S + (double)nH * M * S) * 4,
                conv_att_wgrad(sb, nH, M, S, A, ctx->T + hb * A * S, ctx->I + hb * M * S,
