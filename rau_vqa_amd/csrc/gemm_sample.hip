@@ -30,6 +30,9 @@ namespace rau {
 
 namespace {
 
+#ifndef RAU_SAMPLE_YPRE
+#define RAU_SAMPLE_YPRE 1   // row blocks of the EPI 2 tile whose Y loads are issued ahead of the last K-step
+#endif
 constexpr int SBK = 16, SNCB = 13, SBN = SNCB * 16;   // 208 columns
 constexpr int SLDB = SBN + 32;      // 240 = 16 mod 32
 
@@ -140,14 +143,39 @@ __global__ __launch_bounds__(256, 2) void k_conv_sample(const SampleParams P) {
     store(0);
   }
   __syncthreads();
-  for (int T = 0; T < nsteps; ++T) {
+  for (int T = 0; T + 1 < nsteps; ++T) {
     const int cur = T & 1;
-    const bool more = T + 1 < nsteps;
-    if (more) load(T + 1);
+    load(T + 1);
     compute(cur);
-    if (more) store(cur ^ 1);
+    store(cur ^ 1);
     __syncthreads();
   }
+  // EPI 2 reads this tile's block of Y (100 KB) in its epilogue: the loads of the first YPRE row
+  // blocks go out in front of the last K-step's MFMAs (the staging registers are dead by now), the
+  // rest right behind them, so the latency is covered once instead of once per batch of loads
+  // the compiler forms inside the epilogue loop.
+  constexpr int YPRE = EPI == 2 ? RAU_SAMPLE_YPRE : 0;
+  float4 yv[RB][SNCB];
+  auto yload = [&](int i) {
+#pragma unroll
+    for (int j = 0; j < SNCB; ++j) {
+      const int s = j * 16 + 4 * lq, m = m0 + w * 16 * RB + i * 16 + lr;
+      yv[i][j] = (s < S && m < P.M) ? *reinterpret_cast<const float4*>(P.Y + (size_t)b * P.c_bs + (size_t)m * S + s)
+                                    : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  if (EPI == 2) {
+#pragma unroll
+    for (int i = 0; i < YPRE; ++i) yload(i);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  if (nsteps > 0) compute((nsteps - 1) & 1);
+  if (EPI == 2) {
+#pragma unroll
+    for (int i = YPRE; i < RB; ++i) yload(i);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  __syncthreads();
 
   // ---- epilogue: accumulator (i, j) register r = C[m0 + w*16*RB + i*16 + lr][j*16 + 4*lq + r]
   float* rowv = smem;            // [SBM] bias / dj of this sample's rows
@@ -164,7 +192,6 @@ __global__ __launch_bounds__(256, 2) void k_conv_sample(const SampleParams P) {
   if (EPI >= 1 && tid < SBN) colv[tid] = tid < S ? P.av[(size_t)b * S + tid] : 0.f;
   __syncthreads();
   float* Cb = P.C + (size_t)b * P.c_bs;
-  const float* Yb = EPI == 2 ? P.Y + (size_t)b * P.c_bs : nullptr;
 #pragma unroll
   for (int i = 0; i < RB; ++i) {
     const int rl = w * 16 * RB + i * 16 + lr;
@@ -185,7 +212,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_sample(const SampleParams P) {
         const float4 c4 = *reinterpret_cast<const float4*>(colv + s);
         v.x += rv * c4.x; v.y += rv * c4.y; v.z += rv * c4.z; v.w += rv * c4.w;
         if (EPI == 2) {   // gradient through i_embed's tanh, and its row sums (the bias gradient)
-          const float4 y = *reinterpret_cast<const float4*>(Yb + (size_t)m * S + s);
+          const float4 y = yv[i][j];
           v.x *= 1.f - y.x * y.x; v.y *= 1.f - y.y * y.y;
           v.z *= 1.f - y.z * y.z; v.w *= 1.f - y.w * y.w;
           rsum += (v.x + v.y) + (v.z + v.w);
