@@ -20,7 +20,12 @@ CLASSES = {
     "gemm_split_xcd_kernel<128, 128, 32, 3, 3, 1, 1>": ("conv_att_wgrad", (B * A * S + B * M * S) * 4, None),
     "gemm_split_xcd_kernel<128, 128, 32, 7, 7, 1, 1>": ("conv_embed_wgrad", B * M * S * 2 + B * D * S * 2, None),
     "k_wgrad16": ("conv_embed_wgrad", B * M * S * 2 + B * D * S * 2, None),   # round 3 (wgrad16.hip)
+    # round 3, second half: dgrad16.hip (dS read as bf16, I f32, dZ written as bf16) and the att_i
+    # weight gradient with dS stored as bf16
+    "k_dgrad16<true>": ("conv_att_dgrad", B * A * S * 2 + B * M * S * 4 + B * M * S * 2 + A * M * 4, 1024),
+    "gemm_split_xcd_kernel<128, 128, 32, 7, 3, 1, 1>": ("conv_att_wgrad", B * A * S * 2 + B * M * S * 4, None),
     "k_dropout_features_b16": ("dropout_features", None, None),
+    "k_dropout_features_gen<true>": ("dropout_features", None, None),
 }
 def per_kernel(d, counter):
     f = newest(os.path.join(d, "*", "*_counter_collection.csv"))
