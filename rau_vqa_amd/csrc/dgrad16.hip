@@ -32,6 +32,9 @@ constexpr int GBM = 128;                       // rows per tile
 constexpr int GBK = 32, GKO = GBK / 8;         // K-step, octets per K-step
 constexpr int GXST = GKO * GBN;                // uint4 elements of the X image (832)
 constexpr int GWST = GKO * GBM;                // of the W image (512)
+#ifndef GYPRE
+#define GYPRE 2   // row blocks whose I loads go out ahead of the last K-step (the rest right behind it)
+#endif
 constexpr int GSTAGE = GXST + GWST;            // 1344 x 16 B = 21.5 KB
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -162,16 +165,21 @@ __global__ __launch_bounds__(256, 2) void k_dgrad16(const Dgrad16Params P) {
   // instead of once per batch the compiler would otherwise form inside the epilogue.
   const float* Yb = P.Y + (size_t)b * P.c_bs;
   float4 yv[2][GNCB];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
+  auto yload = [&](int i) {
 #pragma unroll
     for (int j = 0; j < GNCB; ++j) {
       const int s = 16 * j + 4 * lq;
       yv[i][j] = s < GS ? *reinterpret_cast<const float4*>(Yb + (size_t)(m0 + 32 * w + 16 * i + lr) * GS + s)
                         : make_float4(0.f, 0.f, 0.f, 0.f);
     }
+  };
+#pragma unroll
+  for (int i = 0; i < GYPRE; ++i) yload(i);
   __builtin_amdgcn_sched_barrier(0);
   if (nsteps > 0) compute((nsteps - 1) & 1);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int i = GYPRE; i < 2; ++i) yload(i);
   __syncthreads();
 
   // ---- epilogue (as gemm_sample.hip EPI 2): accumulator (i, j) register r =

@@ -56,6 +56,11 @@ hipError_t conv_embed_fwd(hipStream_t st, int nB, int D, int S, int M, const flo
   return launch_gemm<128, 128, BK, SRC_RC, SRC_RC_FLAT, EPI_CONV>(st, P, 1, one_per_cu ? 30 * 1024 : 0);
 }
 
+// The forward bf16 tiles are compiled for 128 registers (four could share a CU) but take 8 KB of unused
+// LDS so that only THREE do: with four the register file is full and every kernel of the recurrence waits
+// for a tile to retire before it can start -- in this mode the forward phase is bound by the encoder
+// (8.43 -> 8.22 ms per step at D = 2048; with 149-register tiles three per CU: 8.75).
+static int b16_fwd_pad() { return 8192; }
 hipError_t conv_embed_fwd_b16(hipStream_t st, int nB, int D, int S, int M, const void* X16,
                               const void* WiT16, const float* bi, float* I) {
   GemmParams P{};
@@ -66,7 +71,7 @@ hipError_t conv_embed_fwd_b16(hipStream_t st, int nB, int D, int S, int M, const
   P.C = I; P.c_bs = (long)M * S;
   P.bias = bi;
   P.act = 1;
-  return launch_gemm<128, 128, BK, SRC_RC_B16, SRC_RC_FLAT_B16, EPI_CONV, 1>(st, P, 1);
+  return launch_gemm<128, 128, BK, SRC_RC_B16, SRC_RC_FLAT_B16, EPI_CONV, 1>(st, P, 1, b16_fwd_pad());
 }
 hipError_t conv_att_pre_b16(hipStream_t st, int nB, int M, int S, int A, const float* I,
                             const void* WpT16, const float* bp, float* Pout) {
@@ -78,7 +83,7 @@ hipError_t conv_att_pre_b16(hipStream_t st, int nB, int M, int S, int A, const f
   P.C = Pout; P.c_bs = (long)A * S;
   P.bias = bp;
   P.act = 0;
-  return launch_gemm<128, 128, BK, SRC_RC_B16, SRC_RC_FLAT, EPI_CONV, 1>(st, P, 1);
+  return launch_gemm<128, 128, BK, SRC_RC_B16, SRC_RC_FLAT, EPI_CONV, 1>(st, P, 1, b16_fwd_pad());
 }
 
 // P[b,k,s] = sum_m Wp[k,m] I[b,m,s] + bp[k]: the hop-invariant part of attbycontent's
