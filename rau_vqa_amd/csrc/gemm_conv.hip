@@ -28,7 +28,7 @@ static bool wide_on(int which) {   // RAU_CONV_WIDE=<mask>: 1 i_embed forward, 2
 static int wide_per_cu(int which) {   // RAU_CONV_WIDE_PER_CU=<f><d>: workgroups per CU of the forward convs / the dgrad
   static const int v = [] { const char* e = std::getenv("RAU_CONV_WIDE_PER_CU"); return e ? std::atoi(e) : 12; }();
   const int d = which == 4 ? v % 10 : (v >= 10 ? v / 10 : v);
-  return d == 2 ? 2 : 1;
+  return d == 2 ? 2 : (d == 8 && which != 4) ? 8 : 1;   // 8: the eight-wave form of the forward tile, one per CU
 }
 
 hipError_t conv_embed_fwd(hipStream_t st, int nB, int D, int S, int M, const float* X,

@@ -15,6 +15,7 @@ KNOBS = [
     ({"RAU_CONV_WIDE": "0"}, 72),                           # round-2 tilings everywhere
     ({"RAU_CONV_WIDE": "7"}, 72),                           # + the attention dgrad on the wide tiling
     ({"RAU_CONV_WIDE": "7", "RAU_CONV_WIDE_PER_CU": "22"}, 72),
+    ({"RAU_CONV_WIDE_PER_CU": "82"}, 72),                   # forward convs on the eight-wave form of the wide tile
     ({"RAU_CONV_WIDE": "0", "RAU_CONV_SAMPLE": "15"}, 72),  # per-sample tiling for all four convs
     ({"RAU_CONV_WIDE": "0", "RAU_CONV_SAMPLE": "0"}, 72),   # flattened-column tiling for all
     ({"RAU_HOP_GROUPS": "1,3", "RAU_BWD_GROUPS": "2,2"}, 72),

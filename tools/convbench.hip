@@ -83,11 +83,16 @@ int main(int argc, char** argv) {
       CK(conv_wide(st, 0, nB, M, D, S, WiT, M, X, (long)D * S, I1, (long)M * S, bi, 1, nullptr, nullptr, nullptr, nullptr, 0, 1));
       CK(hipStreamSynchronize(st));
       compare("wide(1/CU) vs round-2 kernel", I1, I0, (size_t)nB * M * S);
+      CK(hipMemset(I1, 0xff, (size_t)nB * M * S * 4));
+      CK(conv_wide(st, 0, nB, M, D, S, WiT, M, X, (long)D * S, I1, (long)M * S, bi, 1, nullptr, nullptr, nullptr, nullptr, 0, 8));
+      CK(hipStreamSynchronize(st));
+      compare("wide 8 waves vs round-2 kernel", I1, I0, (size_t)nB * M * S);
       for (int rep = 0; rep < 2; ++rep) {
         report("round-2 flattened 128x128", timeit(st, 10, [&] { return conv_embed_fwd(st, nB, D, S, M, X, WiT, bi, I0, 0, 0); }), fl);
         report("round-2 per-sample 128x208", timeit(st, 10, [&] { return conv_sample(st, 0, nB, M, D, S, WiT, M, X, (long)D * S, I0, (long)M * S, bi, 1, nullptr, nullptr); }), fl);
         report("wide 64x784, 2 per CU", timeit(st, 10, [&] { return conv_wide(st, 0, nB, M, D, S, WiT, M, X, (long)D * S, I1, (long)M * S, bi, 1, nullptr, nullptr, nullptr, nullptr, 0, 2); }), fl);
         report("wide 64x784, 1 per CU", timeit(st, 10, [&] { return conv_wide(st, 0, nB, M, D, S, WiT, M, X, (long)D * S, I1, (long)M * S, bi, 1, nullptr, nullptr, nullptr, nullptr, 0, 1); }), fl);
+        report("wide 64x784, 8 waves", timeit(st, 10, [&] { return conv_wide(st, 0, nB, M, D, S, WiT, M, X, (long)D * S, I1, (long)M * S, bi, 1, nullptr, nullptr, nullptr, nullptr, 0, 8); }), fl);
       }
       CK(hipFree(X)); CK(hipFree(WiT)); CK(hipFree(bi)); CK(hipFree(I0)); CK(hipFree(I1));
     }
@@ -110,6 +115,7 @@ int main(int argc, char** argv) {
         report("round-2 flattened 128x128", timeit(st, 10, [&] { return conv_att_pre(st, nB, M, S, A, I, WpT, bp, P0, 0, 0); }), fl);
         report("wide 64x784, 2 per CU", timeit(st, 10, [&] { return conv_wide(st, 0, nB, A, M, S, WpT, A, I, (long)M * S, P1, (long)A * S, bp, 0, nullptr, nullptr, nullptr, nullptr, 0, 2); }), fl);
         report("wide 64x784, 1 per CU", timeit(st, 10, [&] { return conv_wide(st, 0, nB, A, M, S, WpT, A, I, (long)M * S, P1, (long)A * S, bp, 0, nullptr, nullptr, nullptr, nullptr, 0, 1); }), fl);
+        report("wide 64x784, 8 waves", timeit(st, 10, [&] { return conv_wide(st, 0, nB, A, M, S, WpT, A, I, (long)M * S, P1, (long)A * S, bp, 0, nullptr, nullptr, nullptr, nullptr, 0, 8); }), fl);
       }
       CK(hipFree(I)); CK(hipFree(WpT)); CK(hipFree(bp)); CK(hipFree(P0)); CK(hipFree(P1));
     }
