@@ -32,9 +32,6 @@ constexpr int GBM = 128;                       // rows per tile
 constexpr int GBK = 32, GKO = GBK / 8;         // K-step, octets per K-step
 constexpr int GXST = GKO * GBN;                // uint4 elements of the X image (832)
 constexpr int GWST = GKO * GBM;                // of the W image (512)
-#ifndef GYPRE
-#define GYPRE 2   // row blocks whose I loads go out ahead of the last K-step (the rest right behind it)
-#endif
 constexpr int GSTAGE = GXST + GWST;            // 1344 x 16 B = 21.5 KB
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -164,22 +161,25 @@ __global__ __launch_bounds__(256, 2) void k_dgrad16(const Dgrad16Params P) {
   // last K-step's MFMAs (the staging registers are dead by now), so their latency is covered once
   // instead of once per batch the compiler would otherwise form inside the epilogue.
   const float* Yb = P.Y + (size_t)b * P.c_bs;
-  float4 yv[2][GNCB];
+  // Register budget: with both row blocks' 26 loads of I in flight the kernel needs 242 registers, two
+  // workgroups fill a SIMD's 512, and no kernel of the recurrence can start on the CU until a tile
+  // retires (measured: one tile per CU is 0.2 ms slower here and the step 0.11 ms FASTER).  So the
+  // first row block's loads go out ahead of the last K-step, and the second block's only when the
+  // first block's accumulators and I values are dead: ~190 registers, and two tiles leave a third of
+  // the register file free.
+  float4 yv[GNCB];
   auto yload = [&](int i) {
 #pragma unroll
     for (int j = 0; j < GNCB; ++j) {
       const int s = 16 * j + 4 * lq;
-      yv[i][j] = s < GS ? *reinterpret_cast<const float4*>(Yb + (size_t)(m0 + 32 * w + 16 * i + lr) * GS + s)
-                        : make_float4(0.f, 0.f, 0.f, 0.f);
+      yv[j] = s < GS ? *reinterpret_cast<const float4*>(Yb + (size_t)(m0 + 32 * w + 16 * i + lr) * GS + s)
+                     : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   };
-#pragma unroll
-  for (int i = 0; i < GYPRE; ++i) yload(i);
+  yload(0);
   __builtin_amdgcn_sched_barrier(0);
   if (nsteps > 0) compute((nsteps - 1) & 1);
   __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-  for (int i = GYPRE; i < 2; ++i) yload(i);
   __syncthreads();
 
   // ---- epilogue (as gemm_sample.hip EPI 2): accumulator (i, j) register r =
@@ -191,6 +191,11 @@ __global__ __launch_bounds__(256, 2) void k_dgrad16(const Dgrad16Params P) {
   __syncthreads();
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
+    if (i == 1) {
+      asm volatile("" ::: "memory");          // block 0's stores are issued: its registers are free
+      __builtin_amdgcn_sched_barrier(0);
+      yload(1);
+    }
     const int rl = 32 * w + 16 * i + lr;
     const int m = m0 + rl;
     const float rv = rowv[rl];
@@ -200,7 +205,7 @@ __global__ __launch_bounds__(256, 2) void k_dgrad16(const Dgrad16Params P) {
       const int s = 16 * j + 4 * lq;
       if (s >= GS) continue;   // 196 % 4 == 0: a quad is all valid or all pad
       const float4 c4 = *reinterpret_cast<const float4*>(colv + s);
-      const float4 y = yv[i][j];
+      const float4 y = yv[j];
       float4 v = make_float4(acc[i][j][0] + rv * c4.x, acc[i][j][1] + rv * c4.y,
                              acc[i][j][2] + rv * c4.z, acc[i][j][3] + rv * c4.w);
       v.x *= 1.f - y.x * y.x; v.y *= 1.f - y.y * y.y;
@@ -239,8 +244,9 @@ hipError_t dgrad16(hipStream_t st, int nB, int M, int K, int S, const float* Wt,
   P.X = X; P.x_bs = x_bs;
   P.C = C; P.c_bs = c_bs;
   P.dj = dj; P.av = av; P.Y = Y; P.rs = rs; P.c16 = c16; P.x16 = x16;
-  if (x16) hipLaunchKernelGGL(k_dgrad16<true>, dim3(P.tiles_m * nB), dim3(256), 0, st, P);
-  else hipLaunchKernelGGL(k_dgrad16<false>, dim3(P.tiles_m * nB), dim3(256), 0, st, P);
+  const int pad = 0;
+  if (x16) hipLaunchKernelGGL(k_dgrad16<true>, dim3(P.tiles_m * nB), dim3(256), pad, st, P);
+  else hipLaunchKernelGGL(k_dgrad16<false>, dim3(P.tiles_m * nB), dim3(256), pad, st, P);
   return hipGetLastError();
 }
 

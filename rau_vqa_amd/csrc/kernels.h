@@ -270,8 +270,9 @@ hipError_t att_bwd_fused(hipStream_t st, int nB, int M, int A, int S, const floa
                          int da_ns = 0, int SL = 0, const float* da_add = nullptr,
                          // dS16 != nullptr (only where att_bwd_dma_ok): dS leaves as bf16 [nB][A][S] there
                          // and T_to_dS keeps P
-                         void* dS16 = nullptr);
-bool att_bwd_dma_ok(int M, int A, int S);
+                         void* dS16 = nullptr,
+                         int waves_hint = 0 /* 8 | 16 waves per workgroup where RAU_ATT_WAVES_BWD is unset */);
+bool att_bwd_dma_ok(int M, int A, int S, int waves_hint = 0);
 // The same two passes cut into 4-wave workgroups (NC row chunks per sample, two launches per
 // pass): they always fit next to resident bulk-GEMM workgroups.  `part` is scratch of
 // att_split_part_floats(nB, S) floats.  T is never kept (the backward recomputes tanh(Psrc + u)

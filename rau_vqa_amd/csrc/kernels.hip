@@ -374,13 +374,20 @@ hipError_t lstm_bwd_multi(hipStream_t st, int order, int nB, int R, const LstmBw
 // for conv tiles (130 us each) to retire -- 117-265 us per launch in the step against 52 alone.
 // With 8 waves (2 x 104) it starts at once: 10.02 -> 9.78 ms per step.  The backward kernel (48
 // VGPRs) fits either way and stays at 16.  RAU_ATT_WAVES_FWD / RAU_ATT_WAVES_BWD (4, 8 or 16) override.
-static int att_waves(bool bwd) {
+// hint: the caller's choice where the environment does not override (0 = the default: 8 forward, 16
+// backward).  RAU_BF16 mode asks for 8 backward waves: beside that mode's two 206-register dgrad tiles a
+// SIMD has ~100 registers free, which two waves of 28 fit and four do not (step 8.28 -> 8.04 ms at
+// D = 2048; f32 mode: no difference).
+static int att_waves(bool bwd, int hint = 0) {
   static const int v[2] = {
       [] { const char* e = std::getenv("RAU_ATT_WAVES_FWD"); const int n = e ? std::atoi(e) : 0;
-           return (n == 4 || n == 8 || n == 16) ? n : 8; }(),
+           return (n == 4 || n == 8 || n == 16) ? n : 0; }(),
       [] { const char* e = std::getenv("RAU_ATT_WAVES_BWD"); const int n = e ? std::atoi(e) : 0;
-           return (n == 4 || n == 8 || n == 16) ? n : 16; }()};
-  return v[bwd ? 1 : 0];
+           return (n == 4 || n == 8 || n == 16) ? n : 0; }()};
+  const int env = v[bwd ? 1 : 0];
+  if (env) return env;
+  if (hint == 4 || hint == 8 || hint == 16) return hint;
+  return bwd ? 16 : 8;
 }
 
 constexpr int kAttLoads = 8;   // independent row loads a wave issues before it consumes the first
@@ -1005,14 +1012,14 @@ static bool att_bwd_dma_sizes(int nw, int M, int A, int S) {
   const int d = nw == 8 ? 8 : 4;
   return ((size_t)(nw + 1) * S + nw + (size_t)nw * d * S + 256) * sizeof(float) <= 96 * 1024;
 }
-bool att_bwd_dma_ok(int M, int A, int S) { return att_bwd_dma_sizes(att_waves(true), M, A, S); }
+bool att_bwd_dma_ok(int M, int A, int S, int waves_hint) { return att_bwd_dma_sizes(att_waves(true, waves_hint), M, A, S); }
 
 hipError_t att_bwd_fused(hipStream_t st, int nB, int M, int A, int S, const float* I,
                          const float* dj, const float* a, const float* da_lin,
                          const float* ws, float* T_to_dS, float* dz, float* du, float* dwsp,
                          const float* Psrc, const float* u, int da_ns, int SL,
-                         const float* da_add, void* dS16) {
-  const int nw = att_waves(true);
+                         const float* da_add, void* dS16, int waves_hint) {
+  const int nw = att_waves(true, waves_hint);
   if (Psrc && u && att_bwd_dma_sizes(nw, M, A, S)) {
     constexpr int kD8 = 8, kD16 = 4;
     const int d = nw == 8 ? kD8 : kD16;

@@ -340,7 +340,7 @@ int rau_create(const rau_config* cfg, rau_ctx** out) {
     CK(dalloc(ctx, &p16, ((size_t)A * M + 1) / 2));
     ctx->WiT16 = w16;
     ctx->WpT16 = p16;
-    if (dgrad16_ok(M, A, S, M) && att_bwd_dma_ok(M, A, S)) {
+    if (dgrad16_ok(M, A, S, M) && att_bwd_dma_ok(M, A, S, 8)) {
       float* d16 = nullptr;
       CK(dalloc(ctx, &d16, (HB * A * S + 1) / 2));
       ctx->dS16 = d16;
@@ -1159,7 +1159,8 @@ int hop_backward(rau_ctx* ctx, int h, const float* cp, const float* Ih, const Ho
         att_bwd_fused(st, B, M, A, S, Ih, djh, ah, ctx->slab, ctx->att_score.W, Th, dzh, duh,
                       ctx->dwsp + (size_t)h * B * A, ctx->I_shared ? ctx->P0 : Th,
                       ctx->u + (size_t)h * B * A, ns_a, SL, g.da_out,
-                      ctx->ds16_step ? (void*)((uint16_t*)ctx->dS16 + (size_t)h * B * A * S) : nullptr));
+                      ctx->ds16_step ? (void*)((uint16_t*)ctx->dS16 + (size_t)h * B * A * S) : nullptr,
+                      ctx->bf16 ? 8 : 0));
   else
     RUN("att_bwd_split", 2.0 * B * S * (A + M), ((double)B * A * S * 2 + BM_ * S) * 4,
         att_bwd_split(st, B, M, A, S, Ih, djh, ah, ctx->slab, ctx->att_score.W, Th, dzh, duh,
