@@ -30,9 +30,6 @@ namespace rau {
 
 namespace {
 
-#ifndef RAU_SAMPLE_YPRE
-#define RAU_SAMPLE_YPRE 1   // row blocks of the EPI 2 tile whose Y loads are issued ahead of the last K-step
-#endif
 constexpr int SBK = 16, SNCB = 13, SBN = SNCB * 16;   // 208 columns
 constexpr int SLDB = SBN + 32;      // 240 = 16 mod 32
 
@@ -150,31 +147,25 @@ __global__ __launch_bounds__(256, 2) void k_conv_sample(const SampleParams P) {
     store(cur ^ 1);
     __syncthreads();
   }
-  // EPI 2 reads this tile's block of Y (100 KB) in its epilogue: the loads of the first YPRE row
-  // blocks go out in front of the last K-step's MFMAs (the staging registers are dead by now), the
-  // rest right behind them, so the latency is covered once instead of once per batch of loads
-  // the compiler forms inside the epilogue loop.
-  constexpr int YPRE = EPI == 2 ? RAU_SAMPLE_YPRE : 0;
-  float4 yv[RB][SNCB];
+  // EPI 2 reads this tile's block of Y (100 KB) in its epilogue: the first row block's 13 loads per
+  // lane go out in front of the last K-step's MFMAs (the staging registers are dead by now), the next
+  // block's once the previous block is stored -- one exposed round trip per further block instead of
+  // one per batch of loads the compiler forms inside the epilogue loop, and the tile stays under ~180
+  // registers (all blocks in flight at once: 226, and two tiles then leave the recurrence's kernels 60).
+  float4 yv[SNCB];
   auto yload = [&](int i) {
 #pragma unroll
     for (int j = 0; j < SNCB; ++j) {
       const int s = j * 16 + 4 * lq, m = m0 + w * 16 * RB + i * 16 + lr;
-      yv[i][j] = (s < S && m < P.M) ? *reinterpret_cast<const float4*>(P.Y + (size_t)b * P.c_bs + (size_t)m * S + s)
-                                    : make_float4(0.f, 0.f, 0.f, 0.f);
+      yv[j] = (s < S && m < P.M) ? *reinterpret_cast<const float4*>(P.Y + (size_t)b * P.c_bs + (size_t)m * S + s)
+                                 : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   };
   if (EPI == 2) {
-#pragma unroll
-    for (int i = 0; i < YPRE; ++i) yload(i);
+    yload(0);
     __builtin_amdgcn_sched_barrier(0);
   }
   if (nsteps > 0) compute((nsteps - 1) & 1);
-  if (EPI == 2) {
-#pragma unroll
-    for (int i = YPRE; i < RB; ++i) yload(i);
-    __builtin_amdgcn_sched_barrier(0);
-  }
   __syncthreads();
 
   // ---- epilogue: accumulator (i, j) register r = C[m0 + w*16*RB + i*16 + lr][j*16 + 4*lq + r]
@@ -194,6 +185,11 @@ __global__ __launch_bounds__(256, 2) void k_conv_sample(const SampleParams P) {
   float* Cb = P.C + (size_t)b * P.c_bs;
 #pragma unroll
   for (int i = 0; i < RB; ++i) {
+    if (EPI == 2 && i > 0) {
+      asm volatile("" ::: "memory");          // the previous block's stores are issued: its registers are free
+      __builtin_amdgcn_sched_barrier(0);
+      yload(i);
+    }
     const int rl = w * 16 * RB + i * 16 + lr;
     const int m = m0 + rl;
     const bool mok = m < P.M;
@@ -212,7 +208,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_sample(const SampleParams P) {
         const float4 c4 = *reinterpret_cast<const float4*>(colv + s);
         v.x += rv * c4.x; v.y += rv * c4.y; v.z += rv * c4.z; v.w += rv * c4.w;
         if (EPI == 2) {   // gradient through i_embed's tanh, and its row sums (the bias gradient)
-          const float4 y = yv[i][j];
+          const float4 y = yv[j];
           v.x *= 1.f - y.x * y.x; v.y *= 1.f - y.y * y.y;
           v.z *= 1.f - y.z * y.z; v.w *= 1.f - y.w * y.w;
           rsum += (v.x + v.y) + (v.z + v.w);
