@@ -146,6 +146,15 @@ hipError_t wgrad16(hipStream_t st, int nB, int ra, int rb, int S, const void* A1
 bool skinny_dma_ok(int M, int K, long lda, long ldb, bool brc, int nprob, const int* N,
                    const float* const* A, const float* const* B);
 int skinny_dma_splits(int M, int K, int tiles_all, size_t cols_all, size_t slab_floats);
+// the same three with 32-deep stages (skinny_dma32.hip; K % 64 == 0); skinny_dma_* delegate to them for
+// the calling thread while skinny_dma_set_deep(1) is in force
+void skinny_dma_set_deep(int on);
+bool skinny_dma32_ok(int M, int K, long lda, long ldb, bool brc, int nprob, const int* N,
+                     const float* const* A, const float* const* B);
+int skinny_dma32_splits(int M, int K, int tiles_all, size_t cols_all, size_t slab_floats);
+hipError_t skinny_dma32(hipStream_t st, bool brc, int nprob, int M, int K, const float* const* A,
+                        long lda, const float* const* B, long ldb, const int* N, float* slab,
+                        const long* off, int splits);
 hipError_t skinny_dma(hipStream_t st, bool brc, int nprob, int M, int K, const float* const* A,
                       long lda, const float* const* B, long ldb, const int* N, float* slab,
                       const long* off, int splits);

@@ -211,9 +211,18 @@ struct rau_ctx {
 // weight-gradient stream where the recurrence is the longer path: evaluate mode, bf16 mode (forward
 // phase bound by the encoder), contexts of up to 64 samples.  In the f32 step at 256 samples the bulk
 // stream is the longer path and the extra concurrency costs it 1 %.
+inline bool chain_bound(const rau_ctx* ctx) {
+  return ctx->mode == RAU_MODE_EVAL || ctx->bf16 || ctx->cfg.B <= 64;
+}
 inline bool side_split(const rau_ctx* ctx) {
   if (ctx->side_split_env >= 0) return ctx->side_split_env != 0;
-  return ctx->mode == RAU_MODE_EVAL || ctx->bf16 || ctx->cfg.B <= 64;
+  return chain_bound(ctx);
+}
+// The recurrence's skinny GEMMs with 32-deep stages (skinny_dma32.hip) under the same predicate
+// (RAU_SKINNY_DEEP=0|1 overrides): set for the calling thread at every step-level entry point.
+inline void set_skinny_policy(const rau_ctx* ctx) {
+  static const int env = [] { const char* e = std::getenv("RAU_SKINNY_DEEP"); return e ? (std::atoi(e) != 0 ? 1 : 0) : -1; }();
+  skinny_dma_set_deep(env >= 0 ? env : (chain_bound(ctx) ? 1 : 0));
 }
 inline float mask_p(const rau_ctx* ctx, int site) {
   return ctx->mexplicit[site] ? ctx->mp_exact[site] : ctx->mp[site];

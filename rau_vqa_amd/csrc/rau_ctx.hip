@@ -1210,6 +1210,7 @@ extern "C" {
 int rau_forward(rau_ctx* ctx) {
   NEED(ctx, "null ctx");
   if (!ctx->have_batch) return fail(RAU_ERR_STATE, "rau_forward: no batch (call rau_set_batch)");
+  set_skinny_policy(ctx);
   const rau_config& c = ctx->cfg;
   const int B = c.B, E = c.E, Rq = c.Rq, D = c.D, S = ctx->Sp, SL = c.S, M = c.M, A = c.A, R = c.R,
             H = c.H, Q = ctx->Q;
@@ -1524,6 +1525,7 @@ static int upload_hop_weights(rau_ctx* ctx, const float* hop_w) {
 int rau_backward(rau_ctx* ctx, const float* hop_w) {
   NEED(ctx && hop_w, "null argument");
   if (!ctx->fwd_done) return fail(RAU_ERR_STATE, "rau_backward: call rau_forward first");
+  set_skinny_policy(ctx);
   if (!ctx->have_labels) return fail(RAU_ERR_STATE, "rau_backward: batch has no labels");
   const rau_config& c = ctx->cfg;
   const int B = c.B, E = c.E, Rq = c.Rq, D = c.D, S = ctx->Sp, SL = c.S, M = c.M, A = c.A, R = c.R,

@@ -144,6 +144,7 @@ int rau_embed_backward(rau_ctx* ctx, int t, const int32_t* tokens_dev, const flo
 // ------------------------------------------------------------ DeepLSTM clone t
 int rau_deeplstm_forward(rau_ctx* ctx, int t, const float* x, const float* state,
                          float** state_out) {
+  if (ctx) set_skinny_policy(ctx);
   NEED(ctx && x && state_out, "null argument");
   const rau_config& c = ctx->cfg;
   NEED(t >= 0 && t < c.T, "rau_deeplstm_forward: t=%d out of [0,%d)", t, c.T);
@@ -192,6 +193,7 @@ int rau_deeplstm_forward(rau_ctx* ctx, int t, const float* x, const float* state
 
 int rau_deeplstm_backward(rau_ctx* ctx, int t, const float* x, const float* state,
                           const float* d_state_out, float** d_x, float** d_state) {
+  if (ctx) set_skinny_policy(ctx);
   NEED(ctx && x && d_state_out && d_x && d_state, "null argument");
   const rau_config& c = ctx->cfg;
   NEED(t >= 0 && t < c.T, "rau_deeplstm_backward: t=%d out of [0,%d)", t, c.T);
@@ -256,6 +258,7 @@ int rau_deeplstm_backward(rau_ctx* ctx, int t, const float* x, const float* stat
 int rau_multimodal_forward(rau_ctx* ctx, int h, const float* q, const float* X, const float* c_prev,
                            const float* h_prev, float** logits, float** do_pred, float** attprob,
                            float** c_out, float** h_out) {
+  if (ctx) set_skinny_policy(ctx);
   NEED(ctx && q, "null argument");
   const rau_config& c = ctx->cfg;
   NEED(h >= 0 && h < c.H, "rau_multimodal_forward: h=%d out of [0,%d)", h, c.H);
@@ -331,6 +334,7 @@ int rau_multimodal_backward(rau_ctx* ctx, int h, const float* q, const float* X,
                             const float* d_do_pred, const float* d_attprob, const float* d_c,
                             const float* d_h, float** d_q, float** d_X, float** d_c_prev,
                             float** d_h_prev) {
+  if (ctx) set_skinny_policy(ctx);
   NEED(ctx && q && d_logits, "null argument");
   const rau_config& c = ctx->cfg;
   NEED(h >= 0 && h < c.H, "rau_multimodal_backward: h=%d out of [0,%d)", h, c.H);

@@ -1,23 +1,12 @@
-// Split-K partial products of the recurrence's Linear GEMMs (LSTM gates, hop projections, their
-// input gradients): C[M,N] = A[M,K] W^T (W stored [N][K]) or A[M,K] W (W stored [K][N]), M = batch
-// (<= 256), N 512..2048, K 512..2048.  Reference ops: model/DeepLSTM.lua:29-65 (i2h / h2h Linear),
-// train_vqa_RAU_SS.lua:448-462, 581-596 (encoder forward / backward through time).
-//
-// These launches sit on the step's critical path, ~100 per step, 14 us alone / 28 us in
-// the step with the register-staged 64x64x16 single-stage tile of gemm_core.h (one global round
-// trip and two barriers per 16-deep K-step; every XCD fetching all of W through the fabric).  Here:
-//  * operands go HBM/L2 -> LDS by DMA (global_load_lds_dwordx4) into a ring of KNST stages, one
-//    barrier per stage, fragments of stage s+1 read while stage s's MFMAs run.  KNST = 2 (16 KB):
-//    in the step a 4-slot ring (32 KB) measures the same and an 8-slot ring (64 KB) +0.5 ms -- the
-//    workgroups must fit next to the resident bulk tiles, and the request queue of the bulk
-//    kernels' own DMA, not this kernel's prefetch depth, sets the latency a stage sees;
-//  * work item g = (problem, K split, tile column, tile row) in that order, dealt to the XCDs in
-//    contiguous runs (workgroup L -> XCD L & 7 -> items [ (L & 7) * per, ... )), so that one XCD
-//    works on one K slice (or a column range of it): each L2 fetches its slice of W once;
-//  * the LDS image is DMA's lane-linear one; the XOR swizzle that makes the fragment reads
-//    conflict-free is applied on the GLOBAL side (which 16 bytes a lane fetches), not the LDS side.
-// Output: raw partial sums to the slab [split][M][N]; lin_reduce_epilogue / the LSTM cell kernels
-// add them in split order (deterministic), exactly as for the tile this replaces.
+// skinny_dma32.hip -- skinny_dma.hip's split-K partial products with 32-DEEP stages (round 3, second
+// session): a stage is 128 bytes of every [row][k] operand row (whole lines, 8 pieces with an 8-column
+// XOR swizzle) and two MFMA k-groups, so a workgroup passes half as many waits and barriers per K; 32 KB
+// of LDS and 90 registers instead of 16 KB and 36.  Stand-alone 10-18 % faster on the recurrence's
+// shapes (tools/linbench).  In the step it pays where the recurrence is the longer path (bf16 mode
+// -1.1 %, 64-sample contexts -1.9 %, evaluate-mode forward +1.5-3.5 %) and costs the f32 256-sample
+// step 0.9 % (its footprint beside the bulk tiles), so gemm_lin.hip picks it by the caller's policy
+// (skinny_dma_set_deep, set by the step-level entry points from side_split()'s predicate).
+// Reference ops as in skinny_dma.hip.
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
@@ -35,10 +24,11 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* glb_ptr_t;
 
 constexpr int KT = 64;            // tile rows and columns
-constexpr int KBK = 16;           // K-step per stage
-constexpr int KPART = KT * KBK;   // floats per operand per stage (4 KB)
-constexpr int KSTAGE = 2 * KPART; // 8 KB
+constexpr int KBK = 32;           // K-step per stage: 128 bytes of every [row][k] operand row = whole lines
+constexpr int KPART = KT * KBK;   // floats per operand per stage (8 KB)
+constexpr int KSTAGE = 2 * KPART; // 16 KB
 constexpr int KNST = 2;           // ring slots (power of two)
+constexpr int KDMA = 4;           // DMA instructions per wave and stage (two per operand)
 
 struct SkinnyParams {
   int M, K, nprob, splits, nst;   // nst = K-steps per split (even)
@@ -58,13 +48,14 @@ __device__ __forceinline__ void lds_read32(float& dst, uint32_t addr) {
   asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF) : "memory");
 }
 
-// 16-byte column swizzle of the [row][16 k] image (64-byte rows): the four rows a ds_read_b128
-// lane group takes on one 64-byte bank quarter get four different columns
-__device__ __forceinline__ int kc_swz(int row) { return (-((row & 15) >> 2)) & 3; }
+// 16-byte column swizzle of the [row][32 k] image (128-byte rows, 8 pieces): piece p of row r sits in
+// column p ^ ((r >> 1) & 7), so the sixteen rows a ds_read_b128 lane group takes at one k-group hit
+// sixteen different 16-byte bank groups
+__device__ __forceinline__ int kc_swz(int row) { return (row >> 1) & 7; }
 
 // BRC = false: W stored [N][K] (k contiguous);  true: W stored [K][N] (n contiguous)
 template <bool BRC>
-__global__ __launch_bounds__(256) void k_skinny_dma(const SkinnyParams P) {
+__global__ __launch_bounds__(256) void k_skinny_dma32(const SkinnyParams P) {
   RAU_CHAIN_PRIO();
   __shared__ __attribute__((aligned(16))) float smem[KNST * KSTAGE];
   const int tid = threadIdx.x, l = tid & 63;
@@ -90,51 +81,61 @@ __global__ __launch_bounds__(256) void k_skinny_dma(const SkinnyParams P) {
   if (nst > P.nst) nst = P.nst;
   if (nst <= 0) return;
 
-  // ---- DMA sources: one 16-byte piece of each operand per lane and stage
-  const char *ga, *gb;
+  // ---- DMA sources: two 16-byte pieces of each operand per lane and stage (pieces tid and tid + 256)
+  const char *ga[2], *gb[2];
   long stepb;
-  {
-    const int p = tid, row = p >> 2, c = (p & 3) ^ kc_swz(row);
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int p = tid + 256 * j, row = p >> 3, c = (p & 7) ^ kc_swz(row);
     int r = m0 + row;
     if (r > P.M - 1) r = P.M - 1;            // rows past M: a duplicate, never stored
-    ga = reinterpret_cast<const char*>(P.A[prob] + (long)r * P.lda + (long)s0 * KBK + c * 4);
+    ga[j] = reinterpret_cast<const char*>(P.A[prob] + (long)r * P.lda + (long)s0 * KBK + c * 4);
     if (!BRC) {
       int n = n0 + row;
       if (n > PN - 1) n = PN - 1;
-      gb = reinterpret_cast<const char*>(P.B[prob] + (long)n * P.ldb + (long)s0 * KBK + c * 4);
+      gb[j] = reinterpret_cast<const char*>(P.B[prob] + (long)n * P.ldb + (long)s0 * KBK + c * 4);
       stepb = KBK * 4;
     } else {
       const int k = p >> 4, cc = (p & 15) ^ (((k >> 2) & 1) << 2);
-      gb = reinterpret_cast<const char*>(P.B[prob] + ((long)s0 * KBK + k) * P.ldb + n0 + cc * 4);
+      gb[j] = reinterpret_cast<const char*>(P.B[prob] + ((long)s0 * KBK + k) * P.ldb + n0 + cc * 4);
       stepb = (long)KBK * P.ldb * 4;
     }
   }
   int issued = 0;
-  auto issue = [&]() {   // next stage, into ring slot issued % 4
+  auto issue = [&]() {   // next stage, into ring slot issued % KNST
     float* dst = smem + (issued & (KNST - 1)) * KSTAGE + w * 256;
-    __builtin_amdgcn_global_load_lds((glb_ptr_t)ga, (lds_ptr_t)dst, 16, 0, 0);
-    __builtin_amdgcn_global_load_lds((glb_ptr_t)gb, (lds_ptr_t)(dst + KPART), 16, 0, 0);
-    ga += KBK * 4;
-    gb += stepb;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      __builtin_amdgcn_global_load_lds((glb_ptr_t)ga[j], (lds_ptr_t)(dst + j * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((glb_ptr_t)gb[j], (lds_ptr_t)(dst + KPART + j * 1024), 16, 0, 0);
+      ga[j] += KBK * 4;
+      gb[j] += stepb;
+    }
     ++issued;
   };
 
-  // ---- fragment addresses (bytes, stage 0).  Lane (r = l & 15, kk = l >> 4) of MFMA e (0..3) of
-  // a stage holds k = 4 kk + e: one ds_read_b128 per 16-row block covers the stage for [row][k]
-  // operands; [k][n] operands take a ds_read_b32 per MFMA and block.
+  // ---- fragment addresses (bytes, stage 0).  Lane (r = l & 15, kk = l >> 4): MFMA e (0..3) of the
+  // stage's half h (0, 1) holds k = 16 h + 4 kk + e: two ds_read_b128 per 16-row block cover the stage
+  // for [row][k] operands (pieces kk and kk + 4 of the row); [k][n] operands take a ds_read_b32 per MFMA
+  // and block.
   const int fr = l & 15, kk = l >> 4;
   const uint32_t lds0 = (uint32_t)(size_t)(lds_ptr_t)smem;
-  uint32_t fa[2], fb[2];
+  uint32_t fa[2][2], fb[2][2];   // [block][half]
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int ra = wm * 32 + i * 16 + fr;
-    fa[i] = lds0 + (uint32_t)(ra * 64 + ((kk ^ kc_swz(ra)) << 4));
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+      fa[i][h] = lds0 + (uint32_t)(ra * 128 + (((kk + 4 * h) ^ kc_swz(ra)) << 4));
     if (!BRC) {
       const int rb = wn * 32 + i * 16 + fr;
-      fb[i] = lds0 + (uint32_t)(KPART * 4 + rb * 64 + ((kk ^ kc_swz(rb)) << 4));
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+        fb[i][h] = lds0 + (uint32_t)(KPART * 4 + rb * 128 + (((kk + 4 * h) ^ kc_swz(rb)) << 4));
     } else {
       const int nb = (wn * 32 + i * 16 + fr) ^ ((kk & 1) << 4);
-      fb[i] = lds0 + (uint32_t)(KPART * 4 + (4 * kk * 64 + nb) * 4);
+      fb[i][0] = lds0 + (uint32_t)(KPART * 4 + (4 * kk * 64 + nb) * 4);
+      fb[i][1] = fb[i][0] + 16 * 64 * 4;
     }
   }
 
@@ -146,36 +147,36 @@ __global__ __launch_bounds__(256) void k_skinny_dma(const SkinnyParams P) {
 
   // [set][block]; element e = MFMA e's value.  [k][n] operands: scalars, so that each ds_read_b32
   // lands in the register the MFMA reads (no compiler-made copy ahead of the wait)
-  f32x4 af[2][2], bq[2][2];
-  float bs[2][2][4];
+  f32x4 af[2][2][2], bq[2][2][2];   // [set][block][half]
+  float bs[2][2][8];
 
   auto read_frags = [&](int set, int slot) {
     const uint32_t so = (uint32_t)slot * (KSTAGE * 4);
-    lds_read128<0>(af[set][0], fa[0] + so);
-    lds_read128<0>(af[set][1], fa[1] + so);
-    if constexpr (!BRC) {
-      lds_read128<0>(bq[set][0], fb[0] + so);
-      lds_read128<0>(bq[set][1], fb[1] + so);
-    } else {
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        lds_read32<0>(bs[set][j][0], fb[j] + so);
-        lds_read32<256>(bs[set][j][1], fb[j] + so);
-        lds_read32<512>(bs[set][j][2], fb[j] + so);
-        lds_read32<768>(bs[set][j][3], fb[j] + so);
+    for (int h = 0; h < 2; ++h) {
+      lds_read128<0>(af[set][0][h], fa[0][h] + so);
+      lds_read128<0>(af[set][1][h], fa[1][h] + so);
+      if constexpr (!BRC) {
+        lds_read128<0>(bq[set][0][h], fb[0][h] + so);
+        lds_read128<0>(bq[set][1][h], fb[1][h] + so);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          lds_read32<0>(bs[set][j][4 * h + 0], fb[j][h] + so);
+          lds_read32<256>(bs[set][j][4 * h + 1], fb[j][h] + so);
+          lds_read32<512>(bs[set][j][4 * h + 2], fb[j][h] + so);
+          lds_read32<768>(bs[set][j][4 * h + 3], fb[j][h] + so);
+        }
       }
     }
   };
   // wait until the stage with `later` stages issued after it has landed (this wave's pieces)
   auto wait_landed = [&](int later) {
     if (later > KNST - 2) later = KNST - 2;
-    switch (later) {
-      case 6: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
-      case 5: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
-      case 4: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
-      case 3: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
-      case 2: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
-      case 1: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+    switch (later) {   // KDMA instructions per stage
+      case 3: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+      case 2: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+      case 1: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
       default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
     }
   };
@@ -194,14 +195,17 @@ __global__ __launch_bounds__(256) void k_skinny_dma(const SkinnyParams P) {
     // fragments of stage s are in registers (every consumer below depends on this wait)
     if constexpr (!BRC)
       asm volatile("s_waitcnt lgkmcnt(0)"
-                   : "+v"(af[set][0]), "+v"(af[set][1]), "+v"(bq[set][0]), "+v"(bq[set][1])
+                   : "+v"(af[set][0][0]), "+v"(af[set][0][1]), "+v"(af[set][1][0]), "+v"(af[set][1][1]),
+                     "+v"(bq[set][0][0]), "+v"(bq[set][0][1]), "+v"(bq[set][1][0]), "+v"(bq[set][1][1])
                    :
                    : "memory");
     else
       asm volatile("s_waitcnt lgkmcnt(0)"
-                   : "+v"(af[set][0]), "+v"(af[set][1]), "+v"(bs[set][0][0]), "+v"(bs[set][0][1]),
-                     "+v"(bs[set][0][2]), "+v"(bs[set][0][3]), "+v"(bs[set][1][0]),
-                     "+v"(bs[set][1][1]), "+v"(bs[set][1][2]), "+v"(bs[set][1][3])
+                   : "+v"(af[set][0][0]), "+v"(af[set][0][1]), "+v"(af[set][1][0]), "+v"(af[set][1][1]),
+                     "+v"(bs[set][0][0]), "+v"(bs[set][0][1]), "+v"(bs[set][0][2]), "+v"(bs[set][0][3]),
+                     "+v"(bs[set][0][4]), "+v"(bs[set][0][5]), "+v"(bs[set][0][6]), "+v"(bs[set][0][7]),
+                     "+v"(bs[set][1][0]), "+v"(bs[set][1][1]), "+v"(bs[set][1][2]), "+v"(bs[set][1][3]),
+                     "+v"(bs[set][1][4]), "+v"(bs[set][1][5]), "+v"(bs[set][1][6]), "+v"(bs[set][1][7])
                    :
                    : "memory");
     __builtin_amdgcn_sched_barrier(0);
@@ -212,13 +216,15 @@ __global__ __launch_bounds__(256) void k_skinny_dma(const SkinnyParams P) {
     if (more) read_frags(set ^ 1, (s + 1) & (KNST - 1));
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int e = 0; e < 4; ++e)
+    for (int h = 0; h < 2; ++h)
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int e = 0; e < 4; ++e)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(
-              af[set][i][e], BRC ? bs[set][j][e] : bq[set][j][e], acc[i][j], 0, 0, 0);
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(
+                af[set][i][h][e], BRC ? bs[set][j][4 * h + e] : bq[set][j][h][e], acc[i][j], 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
   };
 #pragma unroll 1
@@ -246,17 +252,9 @@ __global__ __launch_bounds__(256) void k_skinny_dma(const SkinnyParams P) {
 
 }  // namespace
 
-// Which form the calling thread's launches take: 32-deep stages (skinny_dma32.hip) where the caller
-// says the recurrence is the longer path and K allows it, else this file's 16-deep stages.
-static thread_local int g_deep = 0;
-void skinny_dma_set_deep(int on) { g_deep = on; }
-static bool use_deep(int K) { return g_deep && K % 64 == 0; }
-
-bool skinny_dma_ok(int M, int K, long lda, long ldb, bool brc, int nprob, const int* N,
+bool skinny_dma32_ok(int M, int K, long lda, long ldb, bool brc, int nprob, const int* N,
                    const float* const* A, const float* const* B) {
-  static const bool off = std::getenv("RAU_SKINNY_DMA_OFF") != nullptr;
-  if (!off && use_deep(K)) return skinny_dma32_ok(M, K, lda, ldb, brc, nprob, N, A, B);
-  if (off || M < 1 || nprob < 1 || nprob > 3) return false;
+  if (M < 1 || nprob < 1 || nprob > 3) return false;
   if (K % (2 * KBK) != 0 || (lda & 3) || (ldb & 3)) return false;
   for (int p = 0; p < nprob; ++p) {
     if (N[p] < 1) return false;
@@ -267,8 +265,7 @@ bool skinny_dma_ok(int M, int K, long lda, long ldb, bool brc, int nprob, const 
 }
 
 // K splits: about one workgroup per CU (256), an even number of K-steps per split
-int skinny_dma_splits(int M, int K, int tiles_all, size_t cols_all, size_t slab_floats) {
-  if (use_deep(K)) return skinny_dma32_splits(M, K, tiles_all, cols_all, slab_floats);
+int skinny_dma32_splits(int M, int K, int tiles_all, size_t cols_all, size_t slab_floats) {
   const int nk = K / KBK;
   int s = (256 + tiles_all / 2) / tiles_all;   // 160 .. 512 measured equal in the step
   if (s < 1) s = 1;
@@ -279,10 +276,9 @@ int skinny_dma_splits(int M, int K, int tiles_all, size_t cols_all, size_t slab_
   return (nk + per - 1) / per;
 }
 
-hipError_t skinny_dma(hipStream_t st, bool brc, int nprob, int M, int K, const float* const* A,
+hipError_t skinny_dma32(hipStream_t st, bool brc, int nprob, int M, int K, const float* const* A,
                       long lda, const float* const* B, long ldb, const int* N, float* slab,
                       const long* off, int splits) {
-  if (use_deep(K)) return skinny_dma32(st, brc, nprob, M, K, A, lda, B, ldb, N, slab, off, splits);
   SkinnyParams P{};
   P.M = M; P.K = K; P.nprob = nprob; P.splits = splits;
   const int nk = K / KBK;
@@ -299,8 +295,8 @@ hipError_t skinny_dma(hipStream_t st, bool brc, int nprob, int M, int K, const f
   P.tiles_n = (nmax + KT - 1) / KT;
   P.lda = lda; P.ldb = ldb; P.slab = slab;
   const int grid = nprob * splits * P.tiles_m * P.tiles_n;
-  if (brc) hipLaunchKernelGGL(k_skinny_dma<true>, dim3(grid), dim3(256), 0, st, P);
-  else hipLaunchKernelGGL(k_skinny_dma<false>, dim3(grid), dim3(256), 0, st, P);
+  if (brc) hipLaunchKernelGGL(k_skinny_dma32<true>, dim3(grid), dim3(256), 0, st, P);
+  else hipLaunchKernelGGL(k_skinny_dma32<false>, dim3(grid), dim3(256), 0, st, P);
   return hipGetLastError();
 }
 

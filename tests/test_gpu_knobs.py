@@ -29,6 +29,8 @@ KNOBS = [
     ({"RAU_ATT_SPLIT": "1", "RAU_ATT_CHUNKS": "4"}, 72),
     ({"RAU_ATT_FUSED": "1"}, 24),
     ({"RAU_ENC_WS": "0"}, 24),
+    ({"RAU_SKINNY_DEEP": "1"}, 72),                         # 32-deep stages for the skinny GEMMs at any shape
+    ({"RAU_SKINNY_DEEP": "0"}, 24),                         # ... and 16-deep where 32 would be chosen
     ({"RAU_SIDE_SPLIT": "1"}, 72),                          # the chain's non-recurrent GEMMs on the side stream
     ({"RAU_SIDE_SPLIT": "0"}, 24),                          # ... and kept on the chain where they would be split
 ]
