@@ -114,6 +114,8 @@ int rau_prof_reset(rau_ctx* ctx);
 int rau_prof_count(rau_ctx* ctx);
 int rau_prof_entry(rau_ctx* ctx, int index, const char** name, int64_t* launches,
                    double* total_ms, double* flops, double* bytes);
+int rau_split_guard_check(size_t ws_floats, size_t offset, int nsplit, size_t per_split_floats);
+int rau_enc_ws_coresident(int batch, int blocks_per_cu, int n_cus);
 ]]
 
 local C = ffi.load(os.getenv('RAU_LIB') or 'librau.so')
@@ -279,7 +281,11 @@ function Tensor:dim() return #self.size end
 function Tensor:row(k)                                         -- 1-based, view
   local cols = numel(self.size) / self.size[1]
   assert(k >= 1 and k <= self.size[1], 'row index out of range')
-  return Tensor.wrap(self.rau, self.ptr + (k - 1) * cols, cols)
+  local v = Tensor.wrap(self.rau, self.ptr + (k - 1) * cols, cols)
+  -- pointer arithmetic on the cdata makes a NEW cdata without the finalizer: the view keeps a
+  -- reference to its owner so that the owner (and the memory) outlives it
+  rawset(v, 'base', rawget(self, 'base') or self)
+  return v
 end
 function Tensor:zero() check(C.rau_dev_fill(self.rau.h, self.ptr, self:nElement(), 0)); return self end
 function Tensor:fill(v) check(C.rau_dev_fill(self.rau.h, self.ptr, self:nElement(), v)); return self end

@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define RAU_ABI_VERSION 4
+#define RAU_ABI_VERSION 5
 
 typedef enum rau_status {
   RAU_OK = 0,
@@ -164,7 +164,9 @@ int rau_batch_feats(rau_ctx* ctx, float** feats_dev);
  * TWO batch slots, each with device buffers and PINNED host staging:
  *   rau_batch_slot(slot)       -> host pointers of the slot's staging (feats [B,D,S], tokens [T,B],
  *                                 lens [B], labels [B]); the loader assembles the batch in place.
- *                                 Waits (on the host) until the slot's previous upload has left it.
+ *                                 Waits (on the host) until the slot's previous upload has left it:
+ *                                 CALL IT BEFORE EVERY IN-PLACE REFILL, never cache its pointers across
+ *                                 iterations (the host may run two steps ahead of the copy stream).
  *   rau_set_batch_async(slot, feats, tokens, lens, labels, has_labels)
  *                              -> checks the ids, builds the token index (host), enqueues the H2D
  *                                 copies on a dedicated copy stream and returns; no stream is
@@ -353,6 +355,21 @@ int rau_prof_reset(rau_ctx* ctx);
 int rau_prof_count(rau_ctx* ctx);
 int rau_prof_entry(rau_ctx* ctx, int index, const char** name, int64_t* launches,
                    double* total_ms, double* flops, double* bytes);
+
+/* ---- diagnostics: host-side predicates of the library, callable without a device --------------
+ * (what tests/test_host_logic.py pins on the CPU; nothing here touches the GPU or a ctx)
+ *
+ * rau_split_guard_check: the range check every consumer of split-K partial sums applies before it
+ * launches (lin_reduce_epilogue, the LSTM cell kernels, the attention kernels, the criterion head,
+ * splitk_reduce_acc): would a consumer reading `nsplit` partials of `per_split_floats` floats at
+ * `offset` floats into a workspace of `ws_floats` floats be launched?  RAU_OK, or RAU_ERR_STATE --
+ * the code rau_forward / rau_backward return instead of launching when a split count or slab
+ * offset is stale.
+ * rau_enc_ws_coresident: 1 if the weight-stationary persistent encoder (whose workgroups wait on each
+ * other's progress counters) may be selected for `batch` samples on a device that admits
+ * `blocks_per_cu` of its workgroups per CU on `n_cus` CUs, else 0. */
+int rau_split_guard_check(size_t ws_floats, size_t offset, int nsplit, size_t per_split_floats);
+int rau_enc_ws_coresident(int batch, int blocks_per_cu, int n_cus);
 
 #ifdef __cplusplus
 }

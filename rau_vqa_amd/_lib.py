@@ -140,6 +140,8 @@ _SIGS = {
     "rau_prof_entry": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_char_p),
                                  C.POINTER(C.c_int64), C.POINTER(C.c_double),
                                  C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "rau_split_guard_check": (C.c_int, [C.c_size_t, C.c_size_t, C.c_int, C.c_size_t]),
+    "rau_enc_ws_coresident": (C.c_int, [C.c_int, C.c_int, C.c_int]),
 }
 
 _lib = None

@@ -296,180 +296,6 @@ __global__ __launch_bounds__(256, 2) void k_conv_wide(const WideParams P) {
   }
 }
 
-
-// ---- the same tile on EIGHT waves (EPI 0 only; round 3, second session).  One 255-register wave per
-// SIMD cannot cover its own LDS and barrier waits: stand-alone the 4-wave kernel runs at 0.70 of peak
-// with one workgroup per CU and at 0.80 with two, but two of them leave the recurrence's kernels no
-// registers.  Here the 64 x 784 tile is cut in position halves as well: wave w owns the 16 rows of row
-// block w & 3 and the position blocks [25 (w >> 2), +25) -- 25 accumulator blocks instead of 49, about
-// 140 registers -- so two waves share a SIMD inside the same half-CU budget and cover each other's
-// waits.  The second half has 24 real blocks; its 25th slot computes on whatever follows the row in
-// LDS and is never stored (2 % of the MFMAs).  Same ring, same barrier placement, same fragment
-// pipeline in chunks of 5 x 5; per stage the 27 DMA instructions are dealt 4 / 3 to the waves
-// (waves 0-2 take a fourth).  Results are bitwise those of the 4-wave kernel.
-constexpr int W8NJ = 25;              // accumulator blocks per wave
-constexpr int W8CH = 5;               // chunk size and chunk count of the fragment pipeline
-
-__global__ __launch_bounds__(512, 1) void k_conv_wide8(const WideParams P) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int tid = threadIdx.x, l = tid & 63;
-  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int rb = w & 3, ph = w >> 2;
-  const int lr = l & 15, lq = l >> 4;
-  const int nwg = P.tiles_m * P.nG;
-  const int id = xcd_remap(blockIdx.x, nwg);
-  const int tm = id % P.tiles_m, g = id / P.tiles_m;
-  const int m0 = tm * WBM, b0 = g * WNS;
-
-  // ---- LDS-DMA slots: instructions 0..23 = X pieces [64 i, +64), 24 = X pieces [1504, 1568), 25, 26 = W.
-  // Wave w issues i = w, w + 8, w + 16, and waves 0..2 also i = 24 + w.
-  constexpr int NSL = 4;
-  uint32_t voff[NSL];
-  int loff[NSL];
-  const bool has4 = w < 3;
-  const bool slot3_w = (w == 1 || w == 2);
-#pragma unroll
-  for (int n = 0; n < NSL; ++n) {
-    int i = n < 3 ? w + 8 * n : 24 + (has4 ? w : 0);
-    if (i < 25) {
-      const int p0 = i < 24 ? 64 * i : WXST / 4 - 64;
-      const int p = p0 + l;
-      const int kk = p / (WNP / 4), r = p - kk * (WNP / 4);
-      const int jj = r / (WS / 4), off = r - jj * (WS / 4);
-      voff[n] = (uint32_t)(((long)jj * P.x_bs + (long)kk * WS) * 4 + off * 16);
-      loff[n] = p0 * 4;
-    } else {
-      const int q0 = (i - 25) * 64;
-      const int q = q0 + l;
-      const int kk = q >> 4, c = q & 15;
-      voff[n] = (uint32_t)((long)kk * P.w_rs * 4 + c * 16);
-      loff[n] = WXST + q0 * 4;
-    }
-  }
-  const char* xk = reinterpret_cast<const char*>(P.X + (size_t)b0 * P.x_bs);
-  const char* wk = reinterpret_cast<const char*>(P.Wt + m0);
-  const long xstep = (long)WBK * WS * 4, wstep = (long)WBK * P.w_rs * 4;
-  auto issue = [&](int n, int stage, const char* xb, const char* wb) {
-    const char* base = (n == 3 && slot3_w) ? wb : xb;
-    uint32_t vo = voff[n];
-    asm volatile("" : "+v"(vo));
-    __builtin_amdgcn_global_load_lds((glb_ptr_t)(base + vo),
-                                     (lds_ptr_t)(smem + stage * WSTAGE + loff[n]), 16, 0, 0);
-  };
-  auto issue_stage = [&](int stage, const char* xb, const char* wb) {
-    issue(0, stage, xb, wb); issue(1, stage, xb, wb); issue(2, stage, xb, wb);
-    if (has4) issue(3, stage, xb, wb);
-  };
-
-  f32x4 acc[W8NJ];
-#pragma unroll
-  for (int j = 0; j < W8NJ; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  const int nk = P.K / WBK;
-  issue_stage(0, xk, wk);
-  issue_stage(1, xk + xstep, wk + wstep);
-  const int xfrag = lq * WNP + lr + 16 * W8NJ * ph;   // fragment of (k = 4q + lq, position 16 (25 ph + j) + lr)
-  const int wfrag = WXST + lq * WBM + 16 * rb + lr;    // fragment of (k = 4q + lq, row 16 rb + lr)
-
-  float fa[W8CH], fb[W8CH], wcur, wnext;
-  const uint32_t lds0 = (uint32_t)(size_t)(lds_ptr_t)smem;
-  const uint32_t xfrag_b = lds0 + (uint32_t)xfrag * 4, wfrag_b = lds0 + (uint32_t)wfrag * 4;
-  auto half_step = [&](auto start_a, auto dma, auto last, auto q_tag, auto qn_tag, uint32_t xa,
-                       uint32_t xa_n, uint32_t wa_n, int st2, const char* xn, const char* wn) {
-    constexpr bool A0 = decltype(start_a)::value, DMA = decltype(dma)::value;
-    constexpr bool LAST = decltype(last)::value;
-    constexpr int Q = decltype(q_tag)::value, QN = decltype(qn_tag)::value;
-    static_for<W8CH>([&](auto c_tag) {
-      constexpr int c = decltype(c_tag)::value;
-      constexpr bool cur_a = A0 ? (c % 2 == 0) : (c % 2 == 1);
-      float (&fn)[W8CH] = cur_a ? fb : fa;
-      const float (&fc)[W8CH] = cur_a ? fa : fb;
-      auto rd = [&](auto i_tag) {
-        constexpr int i = decltype(i_tag)::value;
-        if constexpr (LAST && c == W8CH - 1) return;
-        else if constexpr (c < W8CH - 1) ds_read_f32<(Q * 4 * WNP + 16 * (W8CH * (c + 1) + i)) * 4>(fn[i], xa);
-        else ds_read_f32<(QN * 4 * WNP + 16 * i) * 4>(fn[i], xa_n);
-      };
-      auto mma = [&](int i) {
-        acc[W8CH * c + i] = __builtin_amdgcn_mfma_f32_16x16x4f32(fc[i], wcur, acc[W8CH * c + i], 0, 0, 0);
-      };
-      using std::integral_constant;
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_sched_barrier(0);
-      mma(0);
-      __builtin_amdgcn_sched_barrier(0);
-      rd(integral_constant<int, 0>{}); rd(integral_constant<int, 1>{});
-      __builtin_amdgcn_sched_barrier(0);
-      mma(1);
-      __builtin_amdgcn_sched_barrier(0);
-      rd(integral_constant<int, 2>{}); rd(integral_constant<int, 3>{});
-      __builtin_amdgcn_sched_barrier(0);
-      mma(2);
-      __builtin_amdgcn_sched_barrier(0);
-      rd(integral_constant<int, 4>{});
-      if constexpr (c == W8CH - 1 && !LAST) ds_read_f32<QN * 4 * WBM * 4>(wnext, wa_n);
-      __builtin_amdgcn_sched_barrier(0);
-      mma(3);
-      if constexpr (DMA) {
-        if constexpr (c < 3) issue(c, st2, xn, wn);
-        else if constexpr (c == 3) { if (has4) issue(3, st2, xn, wn); }
-      }
-      mma(4);
-      __builtin_amdgcn_sched_barrier(0);
-    });
-    if constexpr (!LAST) wcur = wnext;
-  };
-  auto kstep = [&](auto dma, auto last, int stage) {
-    int st1 = stage + 1, st2 = stage + 2;
-    if (st1 >= WNST) st1 -= WNST;
-    if (st2 >= WNST) st2 -= WNST;
-    const uint32_t xa = xfrag_b + stage * (WSTAGE * 4);
-    const uint32_t xa1 = xfrag_b + st1 * (WSTAGE * 4), wa = wfrag_b + stage * (WSTAGE * 4);
-    const uint32_t wa1 = wfrag_b + st1 * (WSTAGE * 4);
-    using I0 = std::integral_constant<int, 0>;
-    using I1 = std::integral_constant<int, 1>;
-    half_step(std::true_type{}, std::false_type{}, std::false_type{}, I0{}, I1{}, xa, xa, wa, 0, nullptr,
-              nullptr);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    half_step(std::false_type{}, dma, last, I1{}, I0{}, xa, xa1, wa1, st2, xk + 2 * xstep, wk + 2 * wstep);
-    xk += xstep;
-    wk += wstep;
-  };
-
-  // K-step 0 has landed (this wave's share: the younger stage's 4 or 3 loads may still be in flight)
-  if (has4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-  else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  static_for<W8CH>([&](auto i_tag) {
-    constexpr int i = decltype(i_tag)::value;
-    ds_read_f32<16 * i * 4>(fa[i], xfrag_b);
-  });
-  ds_read_f32<0>(wcur, wfrag_b);
-  int stage = 0;
-  for (int t = 0; t + 2 < nk; ++t) {
-    kstep(std::true_type{}, std::false_type{}, stage);
-    stage = stage + 1 == WNST ? 0 : stage + 1;
-  }
-  kstep(std::false_type{}, std::false_type{}, stage);
-  stage = stage + 1 == WNST ? 0 : stage + 1;
-  kstep(std::false_type{}, std::true_type{}, stage);
-
-  // ---- epilogue: block j (of this wave's 25), register r = C[m][position 16 (25 ph + j) + 4 lq + r]
-  const int m = m0 + 16 * rb + lr;
-  const float bv = P.bias ? P.bias[m] : 0.f;
-#pragma unroll
-  for (int j = 0; j < W8NJ; ++j) {
-    const int jb = W8NJ * ph + j;
-    if (jb >= WNB) continue;           // the second half's 25th slot
-    const int p = 16 * jb + 4 * lq;
-    const int jj = p / WS, s = p - jj * WS;
-    float4 v = make_float4(acc[j][0] + bv, acc[j][1] + bv, acc[j][2] + bv, acc[j][3] + bv);
-    if (P.act) { v.x = tanh_fast(v.x); v.y = tanh_fast(v.y); v.z = tanh_fast(v.z); v.w = tanh_fast(v.w); }
-    *reinterpret_cast<float4*>(P.C + (size_t)(b0 + jj) * P.c_bs + (size_t)m * WS + s) = v;
-  }
-}
-
 }  // namespace
 
 // Shapes the wide tiling takes: 14 x 14 maps, rows a multiple of 64, reduction a multiple of 8 and
@@ -479,7 +305,8 @@ bool conv_wide_ok(int M, int K, int S, long w_rs) {
   return S == WS && M % WBM == 0 && K % WBK == 0 && K >= 2 * WBK && w_rs % 4 == 0;
 }
 
-// epi 0: C = act(acc + bias[m]);  epi 2: C = (acc + dj[b,m] a[b,s]) (1 - Y[b,m,s]^2), rs[b,m] = sum_s C.
+// epi 0: C = act(acc + bias[m]);  epi 2 (only in the tools' build, -DRAU_WIDE_DGRAD):
+// C = (acc + dj[b,m] a[b,s]) (1 - Y[b,m,s]^2), rs[b,m] = sum_s C.
 // per_cu: 1 = pad the LDS request so that only one workgroup fits a CU (leaves half of each CU's
 // registers and LDS to the recurrence's kernels running beside it), 2 = two per CU.
 hipError_t conv_wide(hipStream_t st, int epi, int nB, int M, int K, int S, const float* Wt, long w_rs,
@@ -496,30 +323,26 @@ hipError_t conv_wide(hipStream_t st, int epi, int nB, int M, int K, int S, const
   P.dj = dj; P.av = av; P.Y = Y; P.rs = rs; P.c16 = c16;
   constexpr int kRing = WNST * WSTAGE * 4;            // 81408 bytes: two fit the 160 KB of a CU
   const int lds = per_cu == 1 ? kRing + 2048 : kRing;
-  static bool attr_set = false;
-  if (!attr_set) {
+  // dynamic-LDS attribute, once per process (magic static: contexts may be driven from several threads)
+  static const hipError_t attr_err = [] {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_wide<0>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, kRing + 2048);
-    if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_wide<2>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, kRing + 2048);
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
+#ifdef RAU_WIDE_DGRAD
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_wide<2>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, kRing + 2048);
+#endif
+    return e;
+  }();
+  if (attr_err != hipSuccess) return attr_err;
   const dim3 grid(P.tiles_m * P.nG), block(256);
-  if (epi == 0 && per_cu == 8) {   // eight waves, one workgroup per CU
-    static bool attr8 = false;
-    if (!attr8) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_wide8),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, kRing + 2048);
-      if (e != hipSuccess) return e;
-      attr8 = true;
-    }
-    hipLaunchKernelGGL(k_conv_wide8, grid, dim3(512), kRing + 2048, st, P);
-    return hipGetLastError();
-  }
   if (epi == 0) hipLaunchKernelGGL((k_conv_wide<0>), grid, block, lds, st, P);
+#ifdef RAU_WIDE_DGRAD   // tools/convbench builds its own copy with the dgrad epilogue (a concluded negative
+                        // in the step, DESIGN.md section 8: the library keeps the dgrad on per-sample tiles)
   else hipLaunchKernelGGL((k_conv_wide<2>), grid, block, lds, st, P);
+#else
+  else return hipErrorInvalidValue;
+#endif
   return hipGetLastError();
 }
 

@@ -30,6 +30,8 @@
 #include <type_traits>
 #include <utility>
 
+#include <algorithm>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -338,22 +340,50 @@ __global__ __launch_bounds__(256, 2) void k_enc_ws(const EncWsParams Q) {
 bool enc_ws_ok(int B, int R) { return R == ER && B >= 16 && B % 16 == 0; }
 int enc_ws_workgroups(int B) { return (ER / 16 + ER / 8) * (B % 32 == 0 ? 2 : 1); }
 
+// The kernel's dynamic-LDS attribute, set once per process (a C++11 magic static: contexts may be
+// driven from several host threads).
+static hipError_t enc_ws_attr() {
+  static const hipError_t err = [] {
+    for (const void* f : {reinterpret_cast<const void*>(k_enc_ws<GATES_ATT>),
+                          reinterpret_cast<const void*>(k_enc_ws<GATES_DEEP>)}) {
+      const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, ESMEM * 4);
+      if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+  }();
+  return err;
+}
+
+// Workgroups of one launch wait on progress counters bumped by OTHER workgroups of the same launch
+// (higher-numbered ones too), so all of them must be resident at once.  The pure predicate: with
+// `blocks_per_cu` workgroups admitted per CU (occupancy query) on `n_cus` CUs.  It is deliberately
+// conservative: at most ONE workgroup per CU is counted, because in the step the kernel shares every
+// CU with a resident bulk tile that leaves room for exactly one (83 + 76 KB of LDS).
+bool enc_ws_coresident(int B, int blocks_per_cu, int n_cus) {
+  if (B < 1 || blocks_per_cu < 1 || n_cus < 1) return false;
+  return (long)std::min(blocks_per_cu, 1) * n_cus >= enc_ws_workgroups(B);
+}
+// The same question asked of the current device (CPX partitions and other reduced-CU devices say no).
+bool enc_ws_fits_device(int B) {
+  if (enc_ws_attr() != hipSuccess) return false;
+  int dev = 0, per_cu = 0;
+  hipDeviceProp_t prop;
+  if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return false;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(k_enc_ws<GATES_DEEP>),
+                                                   256, ESMEM * 4) != hipSuccess)
+    return false;
+  return enc_ws_coresident(B, per_cu, prop.multiProcessorCount);
+}
+
 // Q.cnt: 16 unsigned words owned by the caller, zeroed HERE (a memset node in front of the launch,
 // so a captured graph replays it too).
 hipError_t enc_ws_forward(hipStream_t st, int order, EncWsParams Q) {
   if (!enc_ws_ok(Q.B, Q.R) || Q.TL < 1 || !Q.cnt || !Q.err) return hipErrorInvalidValue;
   Q.P = Q.B % 32 == 0 ? 2 : 1;
-  hipError_t e = hipMemsetAsync(Q.cnt, 0, 16 * sizeof(unsigned), st);
+  hipError_t e = enc_ws_attr();
   if (e != hipSuccess) return e;
-  static bool attr_set = false;
-  if (!attr_set) {
-    for (const void* f : {reinterpret_cast<const void*>(k_enc_ws<GATES_ATT>),
-                          reinterpret_cast<const void*>(k_enc_ws<GATES_DEEP>)}) {
-      e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, ESMEM * 4);
-      if (e != hipSuccess) return e;
-    }
-    attr_set = true;
-  }
+  e = hipMemsetAsync(Q.cnt, 0, 16 * sizeof(unsigned), st);
+  if (e != hipSuccess) return e;
   const dim3 grid(enc_ws_workgroups(Q.B)), block(256);
   if (order == GATES_ATT) hipLaunchKernelGGL(k_enc_ws<GATES_ATT>, grid, block, ESMEM * 4, st, Q);
   else hipLaunchKernelGGL(k_enc_ws<GATES_DEEP>, grid, block, ESMEM * 4, st, Q);

@@ -21,14 +21,13 @@ constexpr int BK = 32;
 // 14 x 14 maps in exact f32: the wide tiling (conv_wide.hip) takes the samples in groups of four; a
 // remainder of 1-3 samples goes to the tiling `rest` falls back to.  RAU_CONV_WIDE_PER_CU=1|2 (A/B
 // knob): workgroups of the wide kernel per CU.
-static bool wide_on(int which) {   // RAU_CONV_WIDE=<mask>: 1 i_embed forward, 2 ifeatproj forward, 4 attention dgrad
+static bool wide_on(int which) {   // RAU_CONV_WIDE=<mask>: 1 i_embed forward, 2 ifeatproj forward
   static const int mask = [] { const char* e = std::getenv("RAU_CONV_WIDE"); return e ? std::atoi(e) : 3; }();
   return (mask & which) != 0;
 }
-static int wide_per_cu(int which) {   // RAU_CONV_WIDE_PER_CU=<f><d>: workgroups per CU of the forward convs / the dgrad
-  static const int v = [] { const char* e = std::getenv("RAU_CONV_WIDE_PER_CU"); return e ? std::atoi(e) : 12; }();
-  const int d = which == 4 ? v % 10 : (v >= 10 ? v / 10 : v);
-  return d == 2 ? 2 : (d == 8 && which != 4) ? 8 : 1;   // 8: the eight-wave form of the forward tile, one per CU
+static int wide_per_cu() {   // RAU_CONV_WIDE_PER_CU=1|2: workgroups per CU of the forward convs
+  static const int v = [] { const char* e = std::getenv("RAU_CONV_WIDE_PER_CU"); return e ? std::atoi(e) : 1; }();
+  return v == 2 ? 2 : 1;
 }
 
 hipError_t conv_embed_fwd(hipStream_t st, int nB, int D, int S, int M, const float* X,
@@ -44,7 +43,7 @@ hipError_t conv_embed_fwd(hipStream_t st, int nB, int D, int S, int M, const flo
   if (!bf16 && wide_on(1) && conv_wide_ok(M, D, S, M) && nB >= 4) {
     const int n4 = nB & ~3;
     hipError_t e = conv_wide(st, 0, n4, M, D, S, WiT, M, X, (long)D * S, I, (long)M * S, bi, 1, nullptr,
-                             nullptr, nullptr, nullptr, 0, one_per_cu ? 1 : wide_per_cu(1));
+                             nullptr, nullptr, nullptr, 0, one_per_cu ? 1 : wide_per_cu());
     if (e != hipSuccess || n4 == nB) return e;
     return conv_embed_fwd(st, nB - n4, D, S, M, X + (size_t)n4 * D * S, WiT, bi, I + (size_t)n4 * M * S,
                           bf16, one_per_cu);
@@ -102,7 +101,7 @@ hipError_t conv_att_pre(hipStream_t st, int nB, int M, int S, int A, const float
   if (!bf16 && wide_on(2) && conv_wide_ok(A, M, S, A) && nB >= 4) {
     const int n4 = nB & ~3;
     hipError_t e = conv_wide(st, 0, n4, A, M, S, WpT, A, I, (long)M * S, Pout, (long)A * S, bp, 0, nullptr,
-                             nullptr, nullptr, nullptr, 0, one_per_cu ? 1 : wide_per_cu(2));
+                             nullptr, nullptr, nullptr, 0, one_per_cu ? 1 : wide_per_cu());
     if (e != hipSuccess || n4 == nB) return e;
     return conv_att_pre(st, nB - n4, M, S, A, I + (size_t)n4 * M * S, WpT, bp, Pout + (size_t)n4 * A * S,
                         bf16, one_per_cu);
@@ -146,19 +145,10 @@ hipError_t conv_att_dgrad_dz(hipStream_t st, int nB, int M, int S, int A, const 
   if (bf16 == 1 && dgrad16_ok(M, A, S, M))
     return dgrad16(st, nB, M, A, S, Wp, M, dS, (long)A * S, dZ, (long)M * S, dj, a, I, rs, dz16, ds16);
   if (ds16) return hipErrorInvalidValue;
-  int n4 = 0;
-  if (wide_on(4) && conv_wide_ok(M, A, S, M) && nB >= 4) {
-    n4 = nB & ~3;
-    hipError_t e = conv_wide(st, 2, n4, M, A, S, Wp, M, dS, (long)A * S, dZ, (long)M * S, nullptr, 0, dj, a,
-                             I, rs, dz16, wide_per_cu(4));
-    if (e != hipSuccess || n4 == nB) return e;
-  }
-  // remainder (or all of it): one sample per tile; dZ advances in its stored element size
-  float* dZr = dz16 ? reinterpret_cast<float*>(reinterpret_cast<uint16_t*>(dZ) + (size_t)n4 * M * S)
-                    : dZ + (size_t)n4 * M * S;
-  return conv_sample(st, 2, nB - n4, M, A, S, Wp, M, dS + (size_t)n4 * A * S, (long)A * S, dZr, (long)M * S,
-                     nullptr, 0, dj + (size_t)n4 * M, a + (size_t)n4 * S, I + (size_t)n4 * M * S,
-                     rs + (size_t)n4 * M, dz16);
+  // one sample per tile (the wide tiling with this epilogue is a concluded negative in the step:
+  // DESIGN.md section 8; tools/convbench keeps it for the stand-alone comparison)
+  return conv_sample(st, 2, nB, M, A, S, Wp, M, dS, (long)A * S, dZ, (long)M * S, nullptr, 0, dj, a, I, rs,
+                     dz16);
 }
 
 // dX'[b,d,s] = sum_m Wi[m,d] dZ[b,m,s]: gradient w.r.t. i_embed's (dropped-out) input.  The

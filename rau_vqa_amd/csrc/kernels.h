@@ -7,6 +7,16 @@
 
 namespace rau {
 
+// ------------------------------------------------ split-K partials: fail closed (split_guard.hip)
+// Consumers of K-split partials read slab[split][..] for split < nsplit with no bound of their own.
+// Their launchers check the span first: inside ONE registered workspace, count in [1, kMaxSplits]
+// (0 = no partials, always fine); on violation they launch nothing and return kSplitStateError.
+constexpr long kMaxSplits = 4096;
+constexpr hipError_t kSplitStateError = hipErrorIllegalState;
+void split_ws_register(const float* base, size_t floats);
+void split_ws_unregister(const float* base);
+bool split_span_ok(const float* slab, long nsplit, size_t per_split_floats);
+
 // ------------------------------------------------------------ GEMM (gemm_lin.hip)
 struct LinOpts {
   const float* bias = nullptr;    // + bias[n]
@@ -146,15 +156,9 @@ hipError_t wgrad16(hipStream_t st, int nB, int ra, int rb, int S, const void* A1
 bool skinny_dma_ok(int M, int K, long lda, long ldb, bool brc, int nprob, const int* N,
                    const float* const* A, const float* const* B);
 int skinny_dma_splits(int M, int K, int tiles_all, size_t cols_all, size_t slab_floats);
-// the same three with 32-deep stages (skinny_dma32.hip; K % 64 == 0); skinny_dma_* delegate to them for
-// the calling thread while skinny_dma_set_deep(1) is in force
+// 16-deep or 32-deep stages (one kernel template; 32-deep needs K % 64 == 0): chosen for the calling
+// thread by skinny_dma_set_deep, which the step-level entry points set from chain_bound() (rau_ctx.h)
 void skinny_dma_set_deep(int on);
-bool skinny_dma32_ok(int M, int K, long lda, long ldb, bool brc, int nprob, const int* N,
-                     const float* const* A, const float* const* B);
-int skinny_dma32_splits(int M, int K, int tiles_all, size_t cols_all, size_t slab_floats);
-hipError_t skinny_dma32(hipStream_t st, bool brc, int nprob, int M, int K, const float* const* A,
-                        long lda, const float* const* B, long ldb, const int* N, float* slab,
-                        const long* off, int splits);
 hipError_t skinny_dma(hipStream_t st, bool brc, int nprob, int M, int K, const float* const* A,
                       long lda, const float* const* B, long ldb, const int* N, float* slab,
                       const long* off, int splits);
@@ -242,6 +246,10 @@ struct EncWsParams {
 };
 bool enc_ws_ok(int B, int R);
 int enc_ws_workgroups(int B);
+// All workgroups of a launch must be co-resident (they wait on each other's progress counters):
+// the pure predicate, and the same question asked of the current device (occupancy query).
+bool enc_ws_coresident(int B, int blocks_per_cu, int n_cus);
+bool enc_ws_fits_device(int B);
 hipError_t enc_ws_forward(hipStream_t st, int order, EncWsParams Q);
 struct LstmBwdCell {
   const float* gates; const float* c_prev; long cp_rs; const float* tanhc;

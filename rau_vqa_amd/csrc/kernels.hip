@@ -199,6 +199,7 @@ hipError_t lstm_fwd(hipStream_t st, int order, int nB, int R, float* g4, const f
                     long cp_rs, float* c, long c_rs, float* h, long h_rs, float* tanhc,
                     float* drop_out, const uint32_t* mask, size_t mask_e0, float mscale,
                     const float* slab, int nsplit) {
+  if (!split_span_ok(slab, nsplit, (size_t)nB * 4 * R)) return kSplitStateError;
   const dim3 g(grid_for((size_t)nB * R)), b(256);
   if (order == GATES_ATT)
     hipLaunchKernelGGL(k_lstm_fwd<GATES_ATT>, g, b, 0, st, nB, R, g4, c_prev, cp_rs, c, c_rs, h,
@@ -253,6 +254,7 @@ hipError_t lstm_bwd(hipStream_t st, int order, int nB, int R, const float* gates
                     long dh_rs, const float* dh2, const float* dc_next, float* dsum,
                     float* dc_prev, const int32_t* lens, int t, const float* dq_c,
                     const float* dq_h, long dq_rs, const float* slab, int nsplit) {
+  if (!split_span_ok(slab, nsplit, (size_t)nB * R)) return kSplitStateError;
   const dim3 g(grid_for((size_t)nB * R)), b(256);
   if (order == GATES_ATT)
     hipLaunchKernelGGL(k_lstm_bwd<GATES_ATT>, g, b, 0, st, nB, R, gates, c_prev, cp_rs, tanhc,
@@ -305,6 +307,9 @@ __global__ void k_lstm_fwd_multi(int nB, int R, LstmFwdCells cs) {
 }
 hipError_t lstm_fwd_multi(hipStream_t st, int order, int nB, int R, const LstmFwdCells& cells) {
   if (cells.n < 1) return hipSuccess;
+  if (cells.n > 2) return hipErrorInvalidValue;
+  for (int i = 0; i < cells.n; ++i)
+    if (!split_span_ok(cells.c[i].slab, cells.c[i].nsplit, (size_t)nB * 4 * R)) return kSplitStateError;
   const dim3 g(grid_for((size_t)nB * R, 256, 512), cells.n), b(256);
   if (order == GATES_ATT)
     hipLaunchKernelGGL(k_lstm_fwd_multi<GATES_ATT>, g, b, 0, st, nB, R, cells);
@@ -353,6 +358,11 @@ __global__ void k_lstm_bwd_multi(int nB, int R, LstmBwdCells cs) {
 }
 hipError_t lstm_bwd_multi(hipStream_t st, int order, int nB, int R, const LstmBwdCells& cells) {
   if (cells.n < 1) return hipSuccess;
+  if (cells.n > 2) return hipErrorInvalidValue;
+  for (int i = 0; i < cells.n; ++i)
+    if (!split_span_ok(cells.c[i].slabA, cells.c[i].nA, (size_t)nB * R) ||
+        !split_span_ok(cells.c[i].slabB, cells.c[i].nBp, (size_t)nB * R))
+      return kSplitStateError;
   const dim3 g(grid_for((size_t)nB * R, 256, 512), cells.n), b(256);
   if (order == GATES_ATT)
     hipLaunchKernelGGL(k_lstm_bwd_multi<GATES_ATT>, g, b, 0, st, nB, R, cells);
@@ -373,7 +383,7 @@ hipError_t lstm_bwd_multi(hipStream_t st, int order, int nB, int R, const LstmBw
 // kernels is 257 VGPRs per SIMD: the forward kernel's 4 x 102 do not fit and its workgroups waited
 // for conv tiles (130 us each) to retire -- 117-265 us per launch in the step against 52 alone.
 // With 8 waves (2 x 104) it starts at once: 10.02 -> 9.78 ms per step.  The backward kernel (48
-// VGPRs) fits either way and stays at 16.  RAU_ATT_WAVES_FWD / RAU_ATT_WAVES_BWD (4, 8 or 16) override.
+// VGPRs) fits either way and stays at 16.  RAU_ATT_WAVES_FWD / RAU_ATT_WAVES_BWD (8 or 16) override.
 // hint: the caller's choice where the environment does not override (0 = the default: 8 forward, 16
 // backward).  RAU_BF16 mode asks for 8 backward waves: beside that mode's two 206-register dgrad tiles a
 // SIMD has ~100 registers free, which two waves of 28 fit and four do not (step 8.28 -> 8.04 ms at
@@ -381,12 +391,12 @@ hipError_t lstm_bwd_multi(hipStream_t st, int order, int nB, int R, const LstmBw
 static int att_waves(bool bwd, int hint = 0) {
   static const int v[2] = {
       [] { const char* e = std::getenv("RAU_ATT_WAVES_FWD"); const int n = e ? std::atoi(e) : 0;
-           return (n == 4 || n == 8 || n == 16) ? n : 0; }(),
+           return (n == 8 || n == 16) ? n : 0; }(),
       [] { const char* e = std::getenv("RAU_ATT_WAVES_BWD"); const int n = e ? std::atoi(e) : 0;
-           return (n == 4 || n == 8 || n == 16) ? n : 0; }()};
+           return (n == 8 || n == 16) ? n : 0; }()};
   const int env = v[bwd ? 1 : 0];
   if (env) return env;
-  if (hint == 4 || hint == 8 || hint == 16) return hint;
+  if (hint == 8 || hint == 16) return hint;
   return bwd ? 16 : 8;
 }
 
@@ -699,6 +709,9 @@ hipError_t att_fwd_fused(hipStream_t st, int nB, int M, int A, int S, const floa
                          const float* u, const float* ws, const float* bs, const float* zm,
                          const float* I, const float* qf, float* T, float* a, float* jv,
                          const AttPartials& ap) {
+  if (!split_span_ok(u, ap.u_ns, (size_t)nB * A) ||
+      !split_span_ok(zm, ap.z_ns, (size_t)nB * (ap.SL ? ap.SL : S)))
+    return kSplitStateError;
   const int nw = att_waves(false);
   // 14 x 14 (and any S % 4 == 0, S <= 256) maps on the step path (tanh(P + u) not kept): the LDS-DMA kernel
   static const bool dma_off = std::getenv("RAU_ATT_DMA_OFF") != nullptr;   // A/B knob
@@ -706,14 +719,14 @@ hipError_t att_fwd_fused(hipStream_t st, int nB, int M, int A, int S, const floa
     constexpr int kD8 = 8, kD16 = 4;
     const int d = nw == 8 ? kD8 : kD16;
     const size_t ldsd = ((size_t)(nw + 2) * S + 2 * nw + A + (size_t)nw * d * S + 256) * sizeof(float);
-    static bool attr = false;
-    if (!attr) {
+    static const bool attr = [] {   // once per process; magic static (contexts on several host threads)
       hipFuncSetAttribute(reinterpret_cast<const void*>(k_att_fwd_dma<8, kD8>),
                           hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
       hipFuncSetAttribute(reinterpret_cast<const void*>(k_att_fwd_dma<16, kD16>),
                           hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-      attr = true;
-    }
+      return true;
+    }();
+    (void)attr;
     if (ldsd <= 96 * 1024) {
       if (nw == 8)
         hipLaunchKernelGGL((k_att_fwd_dma<8, kD8>), dim3(nB), dim3(512), ldsd, st, M, A, S, P, u, ws, bs, zm, I,
@@ -727,7 +740,7 @@ hipError_t att_fwd_fused(hipStream_t st, int nB, int M, int A, int S, const floa
   const size_t lds = ((size_t)(nw + 2) * S + 2 * nw + A) * sizeof(float);
 #define ATT_FWD(NW_) hipLaunchKernelGGL(k_att_fwd_fused<NW_>, dim3(nB), dim3(NW_ * 64), lds, st, M, A, \
                                         S, P, u, ws, bs, zm, I, qf, T, a, jv, ap)
-  if (nw == 4) ATT_FWD(4); else if (nw == 8) ATT_FWD(8); else ATT_FWD(16);
+  if (nw == 8) ATT_FWD(8); else ATT_FWD(16);
 #undef ATT_FWD
   return hipGetLastError();
 }
@@ -1019,6 +1032,7 @@ hipError_t att_bwd_fused(hipStream_t st, int nB, int M, int A, int S, const floa
                          const float* ws, float* T_to_dS, float* dz, float* du, float* dwsp,
                          const float* Psrc, const float* u, int da_ns, int SL,
                          const float* da_add, void* dS16, int waves_hint) {
+  if (!split_span_ok(da_lin, da_ns, (size_t)nB * (SL ? SL : S))) return kSplitStateError;
   const int nw = att_waves(true, waves_hint);
   if (Psrc && u && att_bwd_dma_sizes(nw, M, A, S)) {
     constexpr int kD8 = 8, kD16 = 4;
@@ -1026,12 +1040,12 @@ hipError_t att_bwd_fused(hipStream_t st, int nB, int M, int A, int S, const floa
     const size_t ldsd = ((size_t)(nw + 1) * S + nw + (size_t)nw * d * S + 256) * sizeof(float);
 #define ATT_BWD_DMA(NW_, D_, B16_)                                                                     \
   do {                                                                                                 \
-    static bool attr = false;                                                                          \
-    if (!attr) {                                                                                       \
+    static const bool attr = [] {   /* once per process, thread-safe */                                \
       hipFuncSetAttribute(reinterpret_cast<const void*>(k_att_bwd_dma<NW_, D_, B16_>),                 \
                           hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);                      \
-      attr = true;                                                                                     \
-    }                                                                                                  \
+      return true;                                                                                     \
+    }();                                                                                               \
+    (void)attr;                                                                                        \
     hipLaunchKernelGGL((k_att_bwd_dma<NW_, D_, B16_>), dim3(nB), dim3(NW_ * 64), ldsd, st, M, A, S, I, \
                        dj, a, da_lin, ws, T_to_dS, dz, du, dwsp, Psrc, u, da_ns, SL, nB, da_add,       \
                        reinterpret_cast<uint16_t*>(dS16));                                             \
@@ -1046,7 +1060,7 @@ hipError_t att_bwd_fused(hipStream_t st, int nB, int M, int A, int S, const floa
 #define ATT_BWD(NW_) hipLaunchKernelGGL(k_att_bwd_fused<NW_>, dim3(nB), dim3(NW_ * 64), lds, st, M, A, \
                                         S, I, dj, a, da_lin, ws, T_to_dS, dz, du, dwsp, Psrc, u, \
                                         da_ns, SL, nB, da_add)
-  if (nw == 4) ATT_BWD(4); else if (nw == 8) ATT_BWD(8); else ATT_BWD(16);
+  if (nw == 8) ATT_BWD(8); else ATT_BWD(16);
 #undef ATT_BWD
   return hipGetLastError();
 }
@@ -1203,6 +1217,9 @@ hipError_t att_fwd_split(hipStream_t st, int nB, int M, int A, int S, const floa
                          const float* u, const float* ws, const float* bs, const float* zm,
                          const float* I, const float* qf, float* a, float* jv, float* part,
                          const AttPartials& ap) {
+  if (!split_span_ok(u, ap.u_ns, (size_t)nB * A) ||
+      !split_span_ok(zm, ap.z_ns, (size_t)nB * (ap.SL ? ap.SL : S)))
+    return kSplitStateError;
   const int nc = att_chunks(nB);
   hipLaunchKernelGGL(k_att_score_part, dim3(nc, nB), dim3(256), (size_t)4 * S * sizeof(float), st, nB,
                      A, S, P, u, ws, part, ap);
@@ -1348,6 +1365,7 @@ hipError_t att_bwd_split(hipStream_t st, int nB, int M, int A, int S, const floa
                          const float* dj, const float* a, const float* da_lin, const float* ws,
                          float* T_to_dS, float* dz, float* du, float* dwsp, const float* Psrc,
                          const float* u, float* part, int da_ns, int SL, const float* da_add) {
+  if (!split_span_ok(da_lin, da_ns, (size_t)nB * (SL ? SL : S))) return kSplitStateError;
   const int nc = att_chunks(nB);
   hipLaunchKernelGGL(k_att_da_part, dim3(nc, nB), dim3(256), (size_t)4 * S * sizeof(float), st, M, S, I,
                      dj, part);
@@ -1694,6 +1712,7 @@ hipError_t ce_fwd(hipStream_t st, int nB, int K, int M, const float* logits,
                   const int32_t* labels, const float* mf, const float* wd, const float* bd,
                   float* dl, float* lossrow, int32_t* argmax, float* dopred, const float* part,
                   int nsplit, const float* bias, float* logits_out, int Bper) {
+  if (!split_span_ok(part, nsplit, (size_t)nB * K)) return kSplitStateError;
   hipLaunchKernelGGL(k_ce_fwd, dim3(nB), dim3(256), 0, st, nB, K, M, logits, labels, mf, wd, bd,
                      dl, lossrow, argmax, dopred, part, nsplit, bias, logits_out,
                      Bper > 0 ? Bper : nB);
@@ -1879,6 +1898,8 @@ __global__ void k_splitk_reduce_acc1(size_t n, int splits, const float* __restri
 }
 hipError_t splitk_reduce_acc(hipStream_t st, size_t n, int splits, const float* slab,
                              size_t slab_stride, float* dst) {
+  // split 0 is read unconditionally: at least one partial, each of n floats at pitch slab_stride
+  if (splits < 1 || slab_stride < n || !split_span_ok(slab, splits, slab_stride)) return kSplitStateError;
   const bool v4 = (n % 4 == 0) && (slab_stride % 4 == 0) && (((uintptr_t)dst & 15) == 0) &&
                   (((uintptr_t)slab & 15) == 0);
   if (v4)
@@ -1919,6 +1940,7 @@ __global__ void k_lin_reduce_epilogue(int M, int N, int splits, const float* __r
 }
 hipError_t lin_reduce_epilogue(hipStream_t st, int M, int N, int splits, const float* slab,
                                float* C, long ldc, const LinOpts& o) {
+  if (splits < 1 || !split_span_ok(slab, splits, (size_t)M * N)) return kSplitStateError;
   hipLaunchKernelGGL(k_lin_reduce_epilogue, dim3(grid_for((size_t)M * N)), dim3(256), 0, st, M, N,
                      splits, slab, C, ldc, o);
   return hipGetLastError();

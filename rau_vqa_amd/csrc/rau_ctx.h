@@ -165,7 +165,7 @@ struct rau_ctx {
   // dZ holds dI (gradient at i_embed's OUTPUT); the tanh derivative is applied by its consumers
   float *dpre, *dhn, *dg4, *dcn[2], *dhp[2], *dj, *da_lin, *dz, *du, *dwsp, *dZ,
       *dqt, *dQD, *dq, *slab, *slab2, *slab3, *coltmp3, *tmpS, *coltmp2, *dbi_part;
-  size_t slab3_floats = 0;
+  size_t slab3_floats = 0, slab2_floats = 0;
   float *dG1, *dG2, *dwe, *edc[2][2];
   size_t slab_floats = 0;
   // module-level entry points (rau_modules.hip); allocated on first use
@@ -218,7 +218,7 @@ inline bool side_split(const rau_ctx* ctx) {
   if (ctx->side_split_env >= 0) return ctx->side_split_env != 0;
   return chain_bound(ctx);
 }
-// The recurrence's skinny GEMMs with 32-deep stages (skinny_dma32.hip) under the same predicate
+// The recurrence's skinny GEMMs with 32-deep stages (skinny_dma.hip, NH = 2) under the same predicate
 // (RAU_SKINNY_DEEP=0|1 overrides): set for the calling thread at every step-level entry point.
 inline void set_skinny_policy(const rau_ctx* ctx) {
   static const int env = [] { const char* e = std::getenv("RAU_SKINNY_DEEP"); return e ? (std::atoi(e) != 0 ? 1 : 0) : -1; }();
@@ -312,6 +312,9 @@ static inline bool prof_marker(const char* n) {
       hipEventRecord(pr_.b, rstream);                                                     \
       ctx->precs.push_back(pr_);                                                          \
     }                                                                                     \
+    if (e_ == kSplitStateError)   /* a consumer of split-K partials refused a stale span */ \
+      return fail(RAU_ERR_STATE, "kernel %s: split-K partials outside their workspace, "  \
+                  "nothing launched (%s:%d)", cname, __FILE__, __LINE__);                  \
     if (e_ != hipSuccess)                                                                 \
       return fail(RAU_ERR_DEVICE, "kernel %s: %s (%s:%d)", cname, hipGetErrorString(e_),  \
                   __FILE__, __LINE__);                                                    \

@@ -91,6 +91,23 @@ extern "C" {
 const char* rau_last_error(void) { return g_err; }
 int rau_abi_version(void) { return RAU_ABI_VERSION; }
 
+// ---- diagnostics: host-side predicates, no device touched (include/rau.h, last section)
+int rau_split_guard_check(size_t ws_floats, size_t offset, int nsplit, size_t per_split_floats) {
+  // a stand-in workspace in host memory: the check is pointer arithmetic only, nothing is dereferenced
+  static thread_local float anchor[1];
+  const float* base = anchor;
+  split_ws_register(base, ws_floats);
+  const bool ok = split_span_ok(base + offset, nsplit, per_split_floats);
+  split_ws_unregister(base);
+  if (!ok)
+    return fail(RAU_ERR_STATE, "split-K partials [%zu + %d x %zu) outside a workspace of %zu floats: "
+                               "nothing would be launched", offset, nsplit, per_split_floats, ws_floats);
+  return RAU_OK;
+}
+int rau_enc_ws_coresident(int batch, int blocks_per_cu, int n_cus) {
+  return (enc_ws_ok(batch, 512) && enc_ws_coresident(batch, blocks_per_cu, n_cus)) ? 1 : 0;
+}
+
 void rau_default_config(rau_config* cfg) {
   std::memset(cfg, 0, sizeof(*cfg));
   cfg->B = 100;   // opt.batch_size default, SS:48
@@ -372,9 +389,14 @@ int rau_create(const rau_config* cfg, rau_ctx** out) {
     // 3.16 / 3.52 / 4.26 without; evaluate-mode forward 14.3 / 26.8 / 45.9 k vs 10.8 / 20.8 / 40.4 k QA/s.
     // Every workgroup reads all h rows of its sample half each step, so the traffic grows with B while
     // the weights it avoids re-reading do not: training contexts up to 32 samples, inference up to 64.
-    ctx->enc_ws_train = enc_ws_ok(B, Rq) && (e ? std::atoi(e) != 0 : B <= 32);
+    // Its workgroups wait on each other's progress counters, so the whole grid must be resident at
+    // once: asked of THIS device (a CPX partition or a reduced-CU device says no and keeps the
+    // launch-per-step path).  If a bounded wait still gives up at run time (several contexts
+    // competing for the CUs), persist_check() below turns the path off for the ctx.
+    const bool fits = enc_ws_ok(B, Rq) && enc_ws_fits_device(B);
+    ctx->enc_ws_train = fits && (e ? std::atoi(e) != 0 : B <= 32);
     if (const char* ss = std::getenv("RAU_SIDE_SPLIT")) ctx->side_split_env = std::atoi(ss) != 0;
-    ctx->enc_ws = enc_ws_ok(B, Rq) && (e ? std::atoi(e) != 0 : B <= 64);
+    ctx->enc_ws = fits && (e ? std::atoi(e) != 0 : B <= 64);
     float* f = nullptr;
     CK(dalloc(ctx, &f, 16));
     ctx->ws_cnt = reinterpret_cast<unsigned*>(f);
@@ -433,6 +455,7 @@ int rau_create(const rau_config* cfg, rau_ctx** out) {
                           conv_wgrad_slab_floats(H * B, M, D, S));
     if (ctx->bf16) sl2 = std::max(sl2, wgrad16_slab_floats(H * B, M, D, S));
     CK(dalloc(ctx, &ctx->slab2, sl2));
+    ctx->slab2_floats = sl2;
     const int rowsH = H * B, rowsT = T * B;
     const int shapes[][3] = {{K, M, rowsH},      {M, R, rowsH},      {4 * R, M, rowsH},
                              {4 * R, R, rowsH},  {M, S, rowsH},      {S, R, rowsH},
@@ -456,6 +479,10 @@ int rau_create(const rau_config* cfg, rau_ctx** out) {
       ctx->slab3_floats = sl3;
       CK(dalloc(ctx, &ctx->slab3, sl3));
     }
+    // every consumer of K-split partials checks the span it is about to read against these (split_guard.hip)
+    split_ws_register(ctx->slab, ctx->slab_floats);
+    split_ws_register(ctx->slab2, ctx->slab2_floats);
+    split_ws_register(ctx->slab3, ctx->slab3_floats);
   }
   {
     const int widest = std::max({4 * R, 4 * Rq, K, M, S, A, Q});
@@ -495,6 +522,9 @@ void rau_destroy(rau_ctx* ctx) {
   if (ctx->st2) hipStreamSynchronize(ctx->st2);
   if (ctx->st3) hipStreamSynchronize(ctx->st3);
   for (auto& g : ctx->graphs) hipGraphExecDestroy(g.second);
+  split_ws_unregister(ctx->slab);
+  split_ws_unregister(ctx->slab2);
+  split_ws_unregister(ctx->slab3);
   for (void* p : ctx->allocs) hipFree(p);
   if (ctx->hopw_h) hipHostFree(ctx->hopw_h);
   for (auto& r : ctx->precs) {
@@ -845,7 +875,12 @@ int rau_set_batch_async(rau_ctx* ctx, int slot, const float* feats, const int32_
   const size_t TB = (size_t)c.T * c.B, nf = (size_t)c.B * c.D * c.S;
   const bool copies = (feats && feats != s.feats_h) || (tokens && tokens != s.tokens_h) ||
                       (lens && lens != s.lens_p) || (labels && labels != s.labels_h);
-  if (copies && s.upload_pending) {   // staging still being read by the previous upload of this slot
+  (void)copies;
+  // The slot's previous upload may not have left its pinned staging yet: index_batch below rewrites the
+  // pinned index arrays in every case, and the memcpys rewrite the rest, so wait for it either way.
+  // (A caller that refills the staging IN PLACE must call rau_batch_slot(slot) before every refill:
+  // that call performs the same wait before the caller's own writes -- include/rau.h.)
+  if (s.upload_pending) {
     HIPC(hipEventSynchronize(s.uploaded));
     s.upload_pending = false;
   }
@@ -1902,21 +1937,33 @@ int rau_wait_grads(rau_ctx* ctx, int group, void* hip_stream) {
 }
 
 // ================================================================ results
+// The persistent encoder's error word, read after a host synchronisation of the ctx stream: a bounded
+// wait on a sibling workgroup's progress counter gave up (its siblings were not all resident: another
+// process or context held the CUs).  THAT step's results are invalid and the call says so -- once:
+// the word is cleared and the ctx falls back to the launch-per-step encoder for the rest of its life,
+// so repeating the step succeeds instead of failing forever.
+static int persist_check(rau_ctx* ctx) {
+  if (!(ctx->persist_used && ctx->perr_h && *ctx->perr_h)) return RAU_OK;
+  *ctx->perr_h = 0;
+  hipMemsetAsync(ctx->perr_d, 0, sizeof(int), ctx->st);
+  hipStreamSynchronize(ctx->st);
+  ctx->enc_ws = ctx->enc_ws_train = false;
+  ctx->persist_used = false;
+  ctx->fwd_done = false;
+  return fail(RAU_ERR_DEVICE, "persistent encoder: a bounded wait on another workgroup's progress counter gave up; "
+                              "the results of that step are invalid -- repeat it: this context now uses the "
+                              "launch-per-step encoder");
+}
 int rau_sync(rau_ctx* ctx) {
   NEED(ctx, "null ctx");
   HIPC(hipStreamSynchronize(ctx->st));
-  if (ctx->persist_used && ctx->perr_h && *ctx->perr_h)
-    return fail(RAU_ERR_DEVICE, "persistent encoder: a bounded wait on another workgroup's progress counter gave up "
-                                "(results of that step are invalid; RAU_ENC_WS=0 selects the launch-per-step path)");
-  return RAU_OK;
+  return persist_check(ctx);
 }
 static int d2h(rau_ctx* ctx, void* host, const void* dev, size_t bytes) {
   NEED(ctx && host, "null argument");
   HIPC(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, ctx->st));
   HIPC(hipStreamSynchronize(ctx->st));
-  if (ctx->persist_used && ctx->perr_h && *ctx->perr_h)   // same check as rau_sync: never hand back such results as OK
-    return fail(RAU_ERR_DEVICE, "persistent encoder: a bounded wait gave up (results of that step are invalid)");
-  return RAU_OK;
+  return persist_check(ctx);   // same check as rau_sync: never hand back such results as OK
 }
 int rau_get_losses(rau_ctx* ctx, float* losses) {
   NEED(ctx, "null ctx");

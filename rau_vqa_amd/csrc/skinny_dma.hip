@@ -1,16 +1,16 @@
-// Split-K partial products of the recurrence's Linear GEMMs (LSTM gates, hop projections, their
-// input gradients): C[M,N] = A[M,K] W^T (W stored [N][K]) or A[M,K] W (W stored [K][N]), M = batch
-// (<= 256), N 512..2048, K 512..2048.  Reference ops: model/DeepLSTM.lua:29-65 (i2h / h2h Linear),
-// train_vqa_RAU_SS.lua:448-462, 581-596 (encoder forward / backward through time).
+// skinny_dma.hip -- split-K partial products of the recurrence's Linear GEMMs (LSTM gates, hop
+// projections, their input gradients): C[M,N] = A[M,K] W^T (W stored [N][K]) or A[M,K] W (W stored
+// [K][N]), M = batch (<= 256), N 512..2048, K 512..2048.  Reference ops: model/DeepLSTM.lua:29-65
+// (i2h / h2h Linear), train_vqa_RAU_SS.lua:448-462, 581-596 (encoder forward / backward through time).
 //
 // These launches sit on the step's critical path, ~100 per step, 14 us alone / 28 us in
 // the step with the register-staged 64x64x16 single-stage tile of gemm_core.h (one global round
 // trip and two barriers per 16-deep K-step; every XCD fetching all of W through the fabric).  Here:
 //  * operands go HBM/L2 -> LDS by DMA (global_load_lds_dwordx4) into a ring of KNST stages, one
-//    barrier per stage, fragments of stage s+1 read while stage s's MFMAs run.  KNST = 2 (16 KB):
-//    in the step a 4-slot ring (32 KB) measures the same and an 8-slot ring (64 KB) +0.5 ms -- the
-//    workgroups must fit next to the resident bulk tiles, and the request queue of the bulk
-//    kernels' own DMA, not this kernel's prefetch depth, sets the latency a stage sees;
+//    barrier per stage, fragments of stage s+1 read while stage s's MFMAs run.  KNST = 2: in the
+//    step a 4-slot ring measures the same and an 8-slot ring +0.5 ms -- the workgroups must fit next
+//    to the resident bulk tiles, and the request queue of the bulk kernels' own DMA, not this
+//    kernel's prefetch depth, sets the latency a stage sees;
 //  * work item g = (problem, K split, tile column, tile row) in that order, dealt to the XCDs in
 //    contiguous runs (workgroup L -> XCD L & 7 -> items [ (L & 7) * per, ... )), so that one XCD
 //    works on one K slice (or a column range of it): each L2 fetches its slice of W once;
@@ -18,6 +18,17 @@
 //    conflict-free is applied on the GLOBAL side (which 16 bytes a lane fetches), not the LDS side.
 // Output: raw partial sums to the slab [split][M][N]; lin_reduce_epilogue / the LSTM cell kernels
 // add them in split order (deterministic), exactly as for the tile this replaces.
+//
+// ONE kernel template on the stage depth (NH = 16-deep halves per stage):
+//  * NH = 1, 16-deep stages: 16 KB of LDS, 36 registers -- the f32 256-sample step, where the bulk
+//    stream is the longer path and the recurrence's footprint beside the bulk tiles is what counts;
+//  * NH = 2, 32-deep stages: a stage is 128 bytes of every [row][k] operand row (whole lines, 8
+//    pieces under an 8-column XOR swizzle) and two MFMA k-groups, so a workgroup passes half as many
+//    waits and barriers per K; 32 KB and 90 registers.  Stand-alone 10-18 % faster on the recurrence's
+//    shapes (tools/linbench); in the step it pays where the recurrence is the longer path (bf16 mode
+//    -1.1 %, 64-sample contexts -1.9 %, evaluate-mode forward +1.5-3.5 %) and costs the f32 256-sample
+//    step 0.9 %, so the step-level entry points choose per calling thread (skinny_dma_set_deep, from
+//    chain_bound() in rau_ctx.h; K % 64 != 0 keeps NH = 1).
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
@@ -35,9 +46,6 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* glb_ptr_t;
 
 constexpr int KT = 64;            // tile rows and columns
-constexpr int KBK = 16;           // K-step per stage
-constexpr int KPART = KT * KBK;   // floats per operand per stage (4 KB)
-constexpr int KSTAGE = 2 * KPART; // 8 KB
 constexpr int KNST = 2;           // ring slots (power of two)
 
 struct SkinnyParams {
@@ -58,13 +66,54 @@ __device__ __forceinline__ void lds_read32(float& dst, uint32_t addr) {
   asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF) : "memory");
 }
 
-// 16-byte column swizzle of the [row][16 k] image (64-byte rows): the four rows a ds_read_b128
-// lane group takes on one 64-byte bank quarter get four different columns
-__device__ __forceinline__ int kc_swz(int row) { return (-((row & 15) >> 2)) & 3; }
+// 16-byte column swizzle of the [row][16 NH k] image.  NH = 1 (64-byte rows): the four rows a
+// ds_read_b128 lane group takes on one 64-byte bank quarter get four different columns.  NH = 2
+// (128-byte rows, 8 pieces): piece p of row r sits in column p ^ ((r >> 1) & 7), so the sixteen rows a
+// lane group takes at one k-group hit sixteen different 16-byte bank groups.
+template <int NH>
+__device__ __forceinline__ int kc_swz(int row) {
+  return NH == 1 ? ((-((row & 15) >> 2)) & 3) : ((row >> 1) & 7);
+}
+
+// "s_waitcnt lgkmcnt(0)" that every fragment register of `set` depends on
+template <bool BRC, int NH>
+__device__ __forceinline__ void frags_landed(f32x4 (&af)[2][NH], f32x4 (&bq)[2][NH], float (&bs)[2][4 * NH]) {
+  if constexpr (NH == 1) {
+    if constexpr (!BRC)
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[0][0]), "+v"(af[1][0]), "+v"(bq[0][0]), "+v"(bq[1][0]) : : "memory");
+    else
+      asm volatile("s_waitcnt lgkmcnt(0)"
+                   : "+v"(af[0][0]), "+v"(af[1][0]), "+v"(bs[0][0]), "+v"(bs[0][1]), "+v"(bs[0][2]), "+v"(bs[0][3]),
+                     "+v"(bs[1][0]), "+v"(bs[1][1]), "+v"(bs[1][2]), "+v"(bs[1][3])
+                   :
+                   : "memory");
+  } else {
+    if constexpr (!BRC)
+      asm volatile("s_waitcnt lgkmcnt(0)"
+                   : "+v"(af[0][0]), "+v"(af[0][1]), "+v"(af[1][0]), "+v"(af[1][1]),
+                     "+v"(bq[0][0]), "+v"(bq[0][1]), "+v"(bq[1][0]), "+v"(bq[1][1])
+                   :
+                   : "memory");
+    else
+      asm volatile("s_waitcnt lgkmcnt(0)"
+                   : "+v"(af[0][0]), "+v"(af[0][1]), "+v"(af[1][0]), "+v"(af[1][1]),
+                     "+v"(bs[0][0]), "+v"(bs[0][1]), "+v"(bs[0][2]), "+v"(bs[0][3]),
+                     "+v"(bs[0][4]), "+v"(bs[0][5]), "+v"(bs[0][6]), "+v"(bs[0][7]),
+                     "+v"(bs[1][0]), "+v"(bs[1][1]), "+v"(bs[1][2]), "+v"(bs[1][3]),
+                     "+v"(bs[1][4]), "+v"(bs[1][5]), "+v"(bs[1][6]), "+v"(bs[1][7])
+                   :
+                   : "memory");
+  }
+}
 
 // BRC = false: W stored [N][K] (k contiguous);  true: W stored [K][N] (n contiguous)
-template <bool BRC>
+// NH: 16-deep halves per stage (1 or 2)
+template <bool BRC, int NH>
 __global__ __launch_bounds__(256) void k_skinny_dma(const SkinnyParams P) {
+  constexpr int KBK = 16 * NH;          // K-step per stage
+  constexpr int KPART = KT * KBK;       // floats per operand per stage (4 / 8 KB)
+  constexpr int KSTAGE = 2 * KPART;
+  constexpr int PPR = 4 * NH;           // 16-byte pieces per [row][k] operand row
   RAU_CHAIN_PRIO();
   __shared__ __attribute__((aligned(16))) float smem[KNST * KSTAGE];
   const int tid = threadIdx.x, l = tid & 63;
@@ -90,51 +139,62 @@ __global__ __launch_bounds__(256) void k_skinny_dma(const SkinnyParams P) {
   if (nst > P.nst) nst = P.nst;
   if (nst <= 0) return;
 
-  // ---- DMA sources: one 16-byte piece of each operand per lane and stage
-  const char *ga, *gb;
+  // ---- DMA sources: NH 16-byte pieces of each operand per lane and stage (pieces tid + 256 j)
+  const char *ga[NH], *gb[NH];
   long stepb;
-  {
-    const int p = tid, row = p >> 2, c = (p & 3) ^ kc_swz(row);
+#pragma unroll
+  for (int j = 0; j < NH; ++j) {
+    const int p = tid + 256 * j, row = p / PPR, c = (p % PPR) ^ kc_swz<NH>(row);
     int r = m0 + row;
     if (r > P.M - 1) r = P.M - 1;            // rows past M: a duplicate, never stored
-    ga = reinterpret_cast<const char*>(P.A[prob] + (long)r * P.lda + (long)s0 * KBK + c * 4);
+    ga[j] = reinterpret_cast<const char*>(P.A[prob] + (long)r * P.lda + (long)s0 * KBK + c * 4);
     if (!BRC) {
       int n = n0 + row;
       if (n > PN - 1) n = PN - 1;
-      gb = reinterpret_cast<const char*>(P.B[prob] + (long)n * P.ldb + (long)s0 * KBK + c * 4);
+      gb[j] = reinterpret_cast<const char*>(P.B[prob] + (long)n * P.ldb + (long)s0 * KBK + c * 4);
       stepb = KBK * 4;
     } else {
       const int k = p >> 4, cc = (p & 15) ^ (((k >> 2) & 1) << 2);
-      gb = reinterpret_cast<const char*>(P.B[prob] + ((long)s0 * KBK + k) * P.ldb + n0 + cc * 4);
+      gb[j] = reinterpret_cast<const char*>(P.B[prob] + ((long)s0 * KBK + k) * P.ldb + n0 + cc * 4);
       stepb = (long)KBK * P.ldb * 4;
     }
   }
   int issued = 0;
-  auto issue = [&]() {   // next stage, into ring slot issued % 4
+  auto issue = [&]() {   // next stage, into ring slot issued % KNST
     float* dst = smem + (issued & (KNST - 1)) * KSTAGE + w * 256;
-    __builtin_amdgcn_global_load_lds((glb_ptr_t)ga, (lds_ptr_t)dst, 16, 0, 0);
-    __builtin_amdgcn_global_load_lds((glb_ptr_t)gb, (lds_ptr_t)(dst + KPART), 16, 0, 0);
-    ga += KBK * 4;
-    gb += stepb;
+#pragma unroll
+    for (int j = 0; j < NH; ++j) {
+      __builtin_amdgcn_global_load_lds((glb_ptr_t)ga[j], (lds_ptr_t)(dst + j * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((glb_ptr_t)gb[j], (lds_ptr_t)(dst + KPART + j * 1024), 16, 0, 0);
+      ga[j] += KBK * 4;
+      gb[j] += stepb;
+    }
     ++issued;
   };
 
-  // ---- fragment addresses (bytes, stage 0).  Lane (r = l & 15, kk = l >> 4) of MFMA e (0..3) of
-  // a stage holds k = 4 kk + e: one ds_read_b128 per 16-row block covers the stage for [row][k]
-  // operands; [k][n] operands take a ds_read_b32 per MFMA and block.
+  // ---- fragment addresses (bytes, stage 0).  Lane (r = l & 15, kk = l >> 4): MFMA e (0..3) of the
+  // stage's half h holds k = 16 h + 4 kk + e: one ds_read_b128 per 16-row block and half covers it
+  // for [row][k] operands (piece kk + 4 h of the row); [k][n] operands take a ds_read_b32 per MFMA
+  // and block.
   const int fr = l & 15, kk = l >> 4;
   const uint32_t lds0 = (uint32_t)(size_t)(lds_ptr_t)smem;
-  uint32_t fa[2], fb[2];
+  uint32_t fa[2][NH], fb[2][NH];   // [block][half]
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int ra = wm * 32 + i * 16 + fr;
-    fa[i] = lds0 + (uint32_t)(ra * 64 + ((kk ^ kc_swz(ra)) << 4));
+#pragma unroll
+    for (int h = 0; h < NH; ++h)
+      fa[i][h] = lds0 + (uint32_t)(ra * (KBK * 4) + (((kk + 4 * h) ^ kc_swz<NH>(ra)) << 4));
     if (!BRC) {
       const int rb = wn * 32 + i * 16 + fr;
-      fb[i] = lds0 + (uint32_t)(KPART * 4 + rb * 64 + ((kk ^ kc_swz(rb)) << 4));
+#pragma unroll
+      for (int h = 0; h < NH; ++h)
+        fb[i][h] = lds0 + (uint32_t)(KPART * 4 + rb * (KBK * 4) + (((kk + 4 * h) ^ kc_swz<NH>(rb)) << 4));
     } else {
       const int nb = (wn * 32 + i * 16 + fr) ^ ((kk & 1) << 4);
-      fb[i] = lds0 + (uint32_t)(KPART * 4 + (4 * kk * 64 + nb) * 4);
+#pragma unroll
+      for (int h = 0; h < NH; ++h)
+        fb[i][h] = lds0 + (uint32_t)(KPART * 4 + (4 * kk * 64 + nb) * 4) + h * (16 * 64 * 4);
     }
   }
 
@@ -144,45 +204,38 @@ __global__ __launch_bounds__(256) void k_skinny_dma(const SkinnyParams P) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // [set][block]; element e = MFMA e's value.  [k][n] operands: scalars, so that each ds_read_b32
-  // lands in the register the MFMA reads (no compiler-made copy ahead of the wait)
-  f32x4 af[2][2], bq[2][2];
-  float bs[2][2][4];
+  // [set][block][half]; element e = MFMA e's value.  [k][n] operands: scalars, so that each
+  // ds_read_b32 lands in the register the MFMA reads (no compiler-made copy ahead of the wait)
+  f32x4 af[2][2][NH], bq[2][2][NH];
+  float bs[2][2][4 * NH];
 
   auto read_frags = [&](int set, int slot) {
     const uint32_t so = (uint32_t)slot * (KSTAGE * 4);
-    lds_read128<0>(af[set][0], fa[0] + so);
-    lds_read128<0>(af[set][1], fa[1] + so);
-    if constexpr (!BRC) {
-      lds_read128<0>(bq[set][0], fb[0] + so);
-      lds_read128<0>(bq[set][1], fb[1] + so);
-    } else {
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        lds_read32<0>(bs[set][j][0], fb[j] + so);
-        lds_read32<256>(bs[set][j][1], fb[j] + so);
-        lds_read32<512>(bs[set][j][2], fb[j] + so);
-        lds_read32<768>(bs[set][j][3], fb[j] + so);
+    for (int h = 0; h < NH; ++h) {
+      lds_read128<0>(af[set][0][h], fa[0][h] + so);
+      lds_read128<0>(af[set][1][h], fa[1][h] + so);
+      if constexpr (!BRC) {
+        lds_read128<0>(bq[set][0][h], fb[0][h] + so);
+        lds_read128<0>(bq[set][1][h], fb[1][h] + so);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          lds_read32<0>(bs[set][j][4 * h + 0], fb[j][h] + so);
+          lds_read32<256>(bs[set][j][4 * h + 1], fb[j][h] + so);
+          lds_read32<512>(bs[set][j][4 * h + 2], fb[j][h] + so);
+          lds_read32<768>(bs[set][j][4 * h + 3], fb[j][h] + so);
+        }
       }
     }
   };
-  // wait until the stage with `later` stages issued after it has landed (this wave's pieces)
-  auto wait_landed = [&](int later) {
-    if (later > KNST - 2) later = KNST - 2;
-    switch (later) {
-      case 6: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
-      case 5: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
-      case 4: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
-      case 3: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
-      case 2: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
-      case 1: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
-      default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-    }
-  };
+  // this wave's pieces of every issued stage but the newest have landed (a two-slot ring: the stage
+  // about to be read is always the oldest one in flight)
+  auto wait_landed = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
 
-  // ---- prologue: three stages in flight, stage 0's fragments in set 0
-  for (int s = 0; s < KNST - 1 && s < nst; ++s) issue();
-  wait_landed(issued - 1);
+  // ---- prologue: stage 0 in flight, then its fragments in set 0 with stage 1 on its way
+  issue();
+  wait_landed();
   __builtin_amdgcn_s_barrier();
   if (issued < nst) issue();
   read_frags(0, 0);
@@ -190,20 +243,9 @@ __global__ __launch_bounds__(256) void k_skinny_dma(const SkinnyParams P) {
   auto body = [&](auto set_tag, int s) {
     constexpr int set = decltype(set_tag)::value;
     const bool more = s + 1 < nst;
-    if (more) wait_landed(issued - 1 - (s + 1));
+    if (more) wait_landed();
     // fragments of stage s are in registers (every consumer below depends on this wait)
-    if constexpr (!BRC)
-      asm volatile("s_waitcnt lgkmcnt(0)"
-                   : "+v"(af[set][0]), "+v"(af[set][1]), "+v"(bq[set][0]), "+v"(bq[set][1])
-                   :
-                   : "memory");
-    else
-      asm volatile("s_waitcnt lgkmcnt(0)"
-                   : "+v"(af[set][0]), "+v"(af[set][1]), "+v"(bs[set][0][0]), "+v"(bs[set][0][1]),
-                     "+v"(bs[set][0][2]), "+v"(bs[set][0][3]), "+v"(bs[set][1][0]),
-                     "+v"(bs[set][1][1]), "+v"(bs[set][1][2]), "+v"(bs[set][1][3])
-                   :
-                   : "memory");
+    frags_landed<BRC, NH>(af[set], bq[set], bs[set]);
     __builtin_amdgcn_sched_barrier(0);
     // stage s+1 is visible to all; every wave is done with stage s's slot
     __builtin_amdgcn_s_barrier();
@@ -212,13 +254,15 @@ __global__ __launch_bounds__(256) void k_skinny_dma(const SkinnyParams P) {
     if (more) read_frags(set ^ 1, (s + 1) & (KNST - 1));
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int e = 0; e < 4; ++e)
+    for (int h = 0; h < NH; ++h)
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int e = 0; e < 4; ++e)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(
-              af[set][i][e], BRC ? bs[set][j][e] : bq[set][j][e], acc[i][j], 0, 0, 0);
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(
+                af[set][i][h][e], BRC ? bs[set][j][4 * h + e] : bq[set][j][h][e], acc[i][j], 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
   };
 #pragma unroll 1
@@ -246,18 +290,17 @@ __global__ __launch_bounds__(256) void k_skinny_dma(const SkinnyParams P) {
 
 }  // namespace
 
-// Which form the calling thread's launches take: 32-deep stages (skinny_dma32.hip) where the caller
-// says the recurrence is the longer path and K allows it, else this file's 16-deep stages.
+// Which form the calling thread's launches take: 32-deep stages where the caller says the recurrence
+// is the longer path and K allows it, else 16-deep stages.
 static thread_local int g_deep = 0;
 void skinny_dma_set_deep(int on) { g_deep = on; }
-static bool use_deep(int K) { return g_deep && K % 64 == 0; }
+static int stage_depth(int K) { return (g_deep && K % 64 == 0) ? 32 : 16; }
 
 bool skinny_dma_ok(int M, int K, long lda, long ldb, bool brc, int nprob, const int* N,
                    const float* const* A, const float* const* B) {
-  static const bool off = std::getenv("RAU_SKINNY_DMA_OFF") != nullptr;
-  if (!off && use_deep(K)) return skinny_dma32_ok(M, K, lda, ldb, brc, nprob, N, A, B);
+  static const bool off = std::getenv("RAU_SKINNY_DMA_OFF") != nullptr;   // A/B knob
   if (off || M < 1 || nprob < 1 || nprob > 3) return false;
-  if (K % (2 * KBK) != 0 || (lda & 3) || (ldb & 3)) return false;
+  if (K % (2 * stage_depth(K)) != 0 || (lda & 3) || (ldb & 3)) return false;
   for (int p = 0; p < nprob; ++p) {
     if (N[p] < 1) return false;
     if (brc && (N[p] % KT) != 0) return false;     // [K][N] rows are read 64 columns at a time
@@ -268,8 +311,7 @@ bool skinny_dma_ok(int M, int K, long lda, long ldb, bool brc, int nprob, const 
 
 // K splits: about one workgroup per CU (256), an even number of K-steps per split
 int skinny_dma_splits(int M, int K, int tiles_all, size_t cols_all, size_t slab_floats) {
-  if (use_deep(K)) return skinny_dma32_splits(M, K, tiles_all, cols_all, slab_floats);
-  const int nk = K / KBK;
+  const int nk = K / stage_depth(K);
   int s = (256 + tiles_all / 2) / tiles_all;   // 160 .. 512 measured equal in the step
   if (s < 1) s = 1;
   if (s > nk / 2) s = nk / 2;
@@ -282,10 +324,11 @@ int skinny_dma_splits(int M, int K, int tiles_all, size_t cols_all, size_t slab_
 hipError_t skinny_dma(hipStream_t st, bool brc, int nprob, int M, int K, const float* const* A,
                       long lda, const float* const* B, long ldb, const int* N, float* slab,
                       const long* off, int splits) {
-  if (use_deep(K)) return skinny_dma32(st, brc, nprob, M, K, A, lda, B, ldb, N, slab, off, splits);
+  const int depth = stage_depth(K);
+  if (splits < 1 || nprob < 1 || nprob > 3 || K % (2 * depth) != 0) return hipErrorInvalidValue;
   SkinnyParams P{};
   P.M = M; P.K = K; P.nprob = nprob; P.splits = splits;
-  const int nk = K / KBK;
+  const int nk = K / depth;
   int per = (nk + splits - 1) / splits;
   per += per & 1;
   P.nst = per;
@@ -298,9 +341,14 @@ hipError_t skinny_dma(hipStream_t st, bool brc, int nprob, int M, int K, const f
   P.tiles_m = (M + KT - 1) / KT;
   P.tiles_n = (nmax + KT - 1) / KT;
   P.lda = lda; P.ldb = ldb; P.slab = slab;
-  const int grid = nprob * splits * P.tiles_m * P.tiles_n;
-  if (brc) hipLaunchKernelGGL(k_skinny_dma<true>, dim3(grid), dim3(256), 0, st, P);
-  else hipLaunchKernelGGL(k_skinny_dma<false>, dim3(grid), dim3(256), 0, st, P);
+  const dim3 grid(nprob * splits * P.tiles_m * P.tiles_n), block(256);
+  if (depth == 32) {
+    if (brc) hipLaunchKernelGGL((k_skinny_dma<true, 2>), grid, block, 0, st, P);
+    else hipLaunchKernelGGL((k_skinny_dma<false, 2>), grid, block, 0, st, P);
+  } else {
+    if (brc) hipLaunchKernelGGL((k_skinny_dma<true, 1>), grid, block, 0, st, P);
+    else hipLaunchKernelGGL((k_skinny_dma<false, 1>), grid, block, 0, st, P);
+  }
   return hipGetLastError();
 }
 

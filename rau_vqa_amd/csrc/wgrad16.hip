@@ -302,13 +302,9 @@ hipError_t wgrad16(hipStream_t st, int nB, int ra, int rb, int S, const void* A1
   P.A = static_cast<const uint16_t*>(A16); P.a_bs = a_bs;
   P.B = static_cast<const uint16_t*>(B16); P.b_bs = b_bs;
   P.slab = slab;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad16),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, HLDS);
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
+  static const hipError_t attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad16),
+                                                         hipFuncAttributeMaxDynamicSharedMemorySize, HLDS);
+  if (attr_err != hipSuccess) return attr_err;
   const int tiles = P.tiles_a * P.tiles_b;
   hipLaunchKernelGGL(k_wgrad16, dim3(8 * ((P.splits + 7) / 8) * tiles), dim3(256), HLDS, st, P);
   hipError_t e = hipGetLastError();

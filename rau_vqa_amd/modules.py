@@ -181,8 +181,10 @@ def _feval(rau, feats, x, x_len, y, hop_w):
 class DevTensor:
     """Dense row-major float32 device tensor: {ptr, size, rau}; views share memory."""
 
-    def __init__(self, rau, ptr: int, size, owned=False):
+    def __init__(self, rau, ptr: int, size, owned=False, base=None):
         self.rau, self.ptr, self.size, self.owned = rau, int(ptr), tuple(size), owned
+        # a view keeps its owner alive: the owner's finalizer frees the memory the view points into
+        self._base = base
 
     def __del__(self):
         # owned memory goes back to the context when the tensor is collected (views own nothing);
@@ -215,7 +217,7 @@ class DevTensor:
 
     def row(self, k):                 # 0-based here (Lua: 1-based), view
         cols = self.numel() // self.size[0]
-        return DevTensor(self.rau, self.ptr + 4 * k * cols, (cols,))
+        return DevTensor(self.rau, self.ptr + 4 * k * cols, (cols,), base=self._base or self)
 
     def __getitem__(self, k):
         return self.row(k)
@@ -330,6 +332,8 @@ def adam(x, dx, lr, beta1=0.9, beta2=0.999, epsilon=1e-8, state=None):
     device vector (x, dx = rau.flat(group)); state is a dict holding m, v (DevTensors, created on
     first use) and t -- the Python twin of bindings/rau.lua's RAU.adam, so that SS:770-772 runs
     unchanged above the C ABI."""
+    if state is None:
+        raise TypeError("adam: pass a dict as `state` (it carries m, v and t between calls)")
     if "m" not in state:
         state["t"] = 0
         state["m"] = DevTensor.zeros(x.rau, x.numel())
@@ -343,6 +347,8 @@ def adam_statements(x, dx, lr, beta1=0.9, beta2=0.999, epsilon=1e-8, state=None)
     """The same update written as the reference's five tensor statements, one rau_dev_* call each
     (what RAU.Tensor's mul / add / addcmul / sqrt / addcdiv give a script that keeps its own adam)."""
     import math
+    if state is None:
+        raise TypeError("adam_statements: pass a dict as `state` (it carries m, v, tmp and t between calls)")
     if "m" not in state:
         state["t"] = 0
         state["m"] = DevTensor.zeros(x.rau, x.numel())

@@ -33,7 +33,7 @@ def test_library_exports_every_declared_symbol():
 def test_abi_version_and_defaults():
     from rau_vqa_amd import _lib
     l = _lib.lib()
-    assert l.rau_abi_version() == 4
+    assert l.rau_abi_version() == 5
     cfg = _lib.RauConfig()
     l.rau_default_config(C.byref(cfg))
     # the reference's hard-coded locals, SS:202-229, and opt.batch_size default SS:48

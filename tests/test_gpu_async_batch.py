@@ -70,6 +70,53 @@ def test_alternating_async_uploads_equal_synchronous_set_batch():
     m.close()
 
 
+def test_uploads_overlap_running_steps_without_any_host_sync():
+    """the test above reads results after every step, so an upload never actually runs
+    beside a step.  Here N steps go out back to back through alternating slots with NO host
+    synchronisation in between (gradients accumulate over all of them: one zero_grads at the start),
+    each next batch -- 19 MB of features -- enqueued for upload while the previous steps are still
+    executing; only the final accumulated gradients and the last step's outputs are read.  They must
+    equal, bit for bit, the same N steps fed by the synchronous rau_set_batch.  Exercises the
+    consumed / uploaded event ordering with the host running ahead of the device."""
+    d = dict(B=48, T=9, V=300, E=200, Rq=64, D=512, S=196, M=128, A=64, R=64, K=1000, H=3)
+    N = 6
+    batches = [synth.make_batch(d["B"], d["T"], d["V"], d["D"], d["S"], d["K"], seed=40 + s, lens="ragged")
+               for s in range(N)]
+    hop_w = np.full(d["H"], float(d["H"]), np.float32)
+
+    def run(m, feed):
+        m.zero_grads()
+        for i in range(N):
+            feed(m, i)
+            m.set_dropout_seed(91, i)
+            m.forward()
+            m.backward(hop_w)
+        out = m.outputs()                                  # first host synchronisation of the run
+        g = m.get_grads()
+        return {**out, **{"g_" + k: v for k, v in g.items()}}
+
+    m = make(d)
+    want = run(m, lambda m, i: m.set_batch(**batches[i]))
+
+    def feed_async(m, i):
+        if i == 0:
+            m.set_batch_async(0, **batches[0])
+        m.use_batch(i & 1)
+        if i + 1 < N:
+            k = (i + 1) & 1
+            if i % 2 == 0:                                 # in place: rau_batch_slot before EVERY refill
+                v = m.batch_slot(k)
+                for key in ("feats", "tokens", "lens", "labels"):
+                    v[key][...] = np.asarray(batches[i + 1][key]).reshape(v[key].shape)
+                m.set_batch_async(k)
+            else:
+                m.set_batch_async(k, **batches[i + 1])
+    got = run(m, feed_async)
+    bad = [k for k in want if not np.array_equal(want[k], got[k])]
+    assert not bad, f"asynchronously fed steps differ from the synchronous ones in {bad}"
+    m.close()
+
+
 def test_async_upload_argument_and_state_errors():
     d = dict(DIMS, B=4, H=1)
     m = make(d)

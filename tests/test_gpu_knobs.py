@@ -10,37 +10,40 @@ import pytest
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
+# (environment, batch, dims of tests/knob_check.py: "" generic, "ws" Rq = 512 (reaches enc_ws.hip),
+#  "wg" A = M = D = 128 (reaches wgrad_dma.hip), "bf16" M = D = 256 (reaches wgrad16.hip / dgrad16.hip))
 KNOBS = [
-    ({}, 72), ({}, 24),                                     # defaults on both sides of the 64-sample switch
-    ({"RAU_CONV_WIDE": "0"}, 72),                           # round-2 tilings everywhere
-    ({"RAU_CONV_WIDE": "7"}, 72),                           # + the attention dgrad on the wide tiling
-    ({"RAU_CONV_WIDE": "7", "RAU_CONV_WIDE_PER_CU": "22"}, 72),
-    ({"RAU_CONV_WIDE_PER_CU": "82"}, 72),                   # forward convs on the eight-wave form of the wide tile
-    ({"RAU_CONV_WIDE": "0", "RAU_CONV_SAMPLE": "15"}, 72),  # per-sample tiling for all four convs
-    ({"RAU_CONV_WIDE": "0", "RAU_CONV_SAMPLE": "0"}, 72),   # flattened-column tiling for all
-    ({"RAU_HOP_GROUPS": "1,3", "RAU_BWD_GROUPS": "2,2"}, 72),
-    ({"RAU_ATT_WAVES_FWD": "16", "RAU_ATT_WAVES_BWD": "8"}, 72),
-    ({"RAU_ATT_WAVES_FWD": "4", "RAU_ATT_WAVES_BWD": "4"}, 72),
-    ({"RAU_ATT_DMA_OFF": "1"}, 72),
-    ({"RAU_WGRAD_DMA_OFF": "1"}, 72),
-    ({"RAU_SKINNY_DMA_OFF": "1"}, 72),
-    ({"BF16": "1"}, 12),                                    # bf16 mode, wgrad16.hip on ...
-    ({"BF16": "1", "RAU_WGRAD16_OFF": "1"}, 12),            # ... and off (round-2 tile)
-    ({"RAU_ATT_SPLIT": "1", "RAU_ATT_CHUNKS": "4"}, 72),
-    ({"RAU_ATT_FUSED": "1"}, 24),
-    ({"RAU_ENC_WS": "0"}, 24),
-    ({"RAU_SKINNY_DEEP": "1"}, 72),                         # 32-deep stages for the skinny GEMMs at any shape
-    ({"RAU_SKINNY_DEEP": "0"}, 24),                         # ... and 16-deep where 32 would be chosen
-    ({"RAU_SIDE_SPLIT": "1"}, 72),                          # the chain's non-recurrent GEMMs on the side stream
-    ({"RAU_SIDE_SPLIT": "0"}, 24),                          # ... and kept on the chain where they would be split
+    ({}, 72, ""), ({}, 24, ""),                                 # defaults on both sides of the 64-sample switch
+    ({"RAU_CONV_WIDE": "0"}, 72, ""),                           # round-2 tilings everywhere
+    ({"RAU_CONV_WIDE_PER_CU": "2"}, 72, ""),                    # two wide workgroups per CU
+    ({"RAU_CONV_WIDE": "0", "RAU_CONV_SAMPLE": "15"}, 72, ""),  # per-sample tiling for all four convs
+    ({"RAU_CONV_WIDE": "0", "RAU_CONV_SAMPLE": "0"}, 72, ""),   # flattened-column tiling for all
+    ({"RAU_HOP_GROUPS": "1,3", "RAU_BWD_GROUPS": "2,2"}, 72, ""),
+    ({"RAU_ATT_WAVES_FWD": "16", "RAU_ATT_WAVES_BWD": "8"}, 72, ""),
+    ({"RAU_ATT_DMA_OFF": "1"}, 72, ""),
+    ({}, 72, "wg"),                                             # LDS-DMA f32 conv weight gradients on ...
+    ({"RAU_WGRAD_DMA_OFF": "1"}, 72, "wg"),                     # ... and off (register-staged tile)
+    ({"RAU_SKINNY_DMA_OFF": "1"}, 72, ""),
+    ({"BF16": "1"}, 12, "bf16"),                                # bf16 mode, wgrad16.hip on ...
+    ({"BF16": "1", "RAU_WGRAD16_OFF": "1"}, 12, "bf16"),        # ... and off (round-2 tile)
+    ({"RAU_ATT_SPLIT": "1", "RAU_ATT_CHUNKS": "4"}, 72, ""),
+    ({"RAU_ATT_FUSED": "1"}, 24, ""),
+    ({}, 32, "ws"),                                             # persistent encoder selected by shape ...
+    ({"RAU_ENC_WS": "0"}, 32, "ws"),                            # ... and forced off at the same shape
+    ({"RAU_ENC_WS": "1"}, 80, "ws"),                            # ... and forced on where it is not chosen
+    ({"RAU_SKINNY_DEEP": "1"}, 72, ""),                         # 32-deep stages for the skinny GEMMs at any shape
+    ({"RAU_SKINNY_DEEP": "0"}, 24, ""),                         # ... and 16-deep where 32 would be chosen
+    ({"RAU_SIDE_SPLIT": "1"}, 72, ""),                          # the chain's non-recurrent GEMMs on the side stream
+    ({"RAU_SIDE_SPLIT": "0"}, 24, ""),                          # ... and kept on the chain where they would be split
 ]
 
 
-@pytest.mark.parametrize("env,batch", KNOBS, ids=[" ".join(f"{k}={v}" for k, v in e.items()) + f" B={b}"
-                                                  for e, b in KNOBS])
-def test_knob_setting_keeps_parity(env, batch):
+@pytest.mark.parametrize("env,batch,kind", KNOBS,
+                         ids=[" ".join(f"{k}={v}" for k, v in e.items()) + f" B={b} {kd}".rstrip()
+                              for e, b, kd in KNOBS])
+def test_knob_setting_keeps_parity(env, batch, kind):
     e = dict(os.environ, **env)
-    args = [str(batch)] + (["bf16"] if env.get("BF16") else [])
+    args = [str(batch)] + ([kind] if kind else [])
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "knob_check.py")] + args,
                          env=e, cwd=ROOT, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]

@@ -56,3 +56,44 @@ def test_shard_batch_even_split():
     assert np.array_equal(np.concatenate([p["tokens"] for p in parts], axis=1), b["tokens"])
     with pytest.raises(ValueError):
         shard_batch(b, 0, 3)
+
+
+def test_split_guard_fails_closed():
+    """consumers of split-K partial sums (lin_reduce_epilogue, the LSTM cell
+    kernels, the attention kernels, the criterion head, splitk_reduce_acc) read slab[split][..]
+    with no bound of their own; their launchers check the span against the registered workspace
+    first and return RAU_ERR_STATE instead of launching.  The same check, through the C ABI, on a
+    workspace of the real size (16 * B * 4R floats at B = 256) with good and corrupted state."""
+    from rau_vqa_amd import _lib
+    l = _lib.lib()
+    B, R4 = 256, 2048
+    ws = 16 * B * R4
+    per = B * R4                       # one partial of the attention-LSTM gate GEMM
+    OK, ERR_STATE = 0, -3
+    assert l.rau_split_guard_check(ws, 0, 4, per) == OK
+    assert l.rau_split_guard_check(ws, ws // 2, 8, per) == OK            # second half, exactly full
+    assert l.rau_split_guard_check(ws, 0, 0, per) == OK                  # no partials: nothing is read
+    # a stale split count (one more than fits), a stale offset, a count from another shape
+    assert l.rau_split_guard_check(ws, ws // 2, 9, per) == ERR_STATE
+    assert b"nothing would be launched" in l.rau_last_error()
+    assert l.rau_split_guard_check(ws, ws - per + 1, 1, per) == ERR_STATE
+    assert l.rau_split_guard_check(ws, ws, 1, per) == ERR_STATE          # one past the end
+    assert l.rau_split_guard_check(ws, 0, 17, per) == ERR_STATE
+    assert l.rau_split_guard_check(ws, 0, -1, per) == ERR_STATE          # garbage count
+    assert l.rau_split_guard_check(ws, 0, 5000, 1) == ERR_STATE          # above the library's split cap
+    assert l.rau_split_guard_check(ws, 0, 1, 0) == ERR_STATE             # degenerate partial size
+
+
+def test_persistent_encoder_needs_its_whole_grid_resident():
+    """enc_ws.hip's workgroups wait on progress counters of OTHER workgroups of
+    the same launch, so rau_create only selects it when every one of them can be resident at once --
+    counted at ONE workgroup per CU, because in the step each CU also holds a bulk tile."""
+    from rau_vqa_amd import _lib
+    l = _lib.lib()
+    assert l.rau_enc_ws_coresident(64, 2, 256) == 1      # MI355X, SPX: 192 workgroups on 256 CUs
+    assert l.rau_enc_ws_coresident(32, 1, 256) == 1
+    assert l.rau_enc_ws_coresident(16, 1, 96) == 1       # B = 16: one sample half, 96 workgroups
+    assert l.rau_enc_ws_coresident(64, 2, 128) == 0      # a 128-CU partition: 192 do not fit at one per CU
+    assert l.rau_enc_ws_coresident(64, 1, 32) == 0       # CPX partition
+    assert l.rau_enc_ws_coresident(64, 0, 256) == 0      # the occupancy query says it does not fit at all
+    assert l.rau_enc_ws_coresident(24, 2, 256) == 0      # not a shape the kernel takes

@@ -1,4 +1,9 @@
-cd /root/repo
+#!/bin/bash
+# the weight-stationary encoder on / off at B = 16 / 32 / 64: training step and inference (development tool)
+R="$(cd "$(dirname "$0")/.." && pwd)"
+[ -n "$R" ] && [ -f "$R/bench.py" ] || { echo "cannot locate the repo root from $0" >&2; exit 1; }
+cd "$R"
+mkdir -p gpurun_out
 for B in 16 32 64; do
 for ws in 1 0; do
 RAU_ENC_WS=$ws python3 bench.py --batch $B --variant MS --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | python3 -c "

@@ -1,4 +1,9 @@
-cd /root/repo
+#!/bin/bash
+# shader clock and package power sampled while the bench loop runs (development tool)
+R="$(cd "$(dirname "$0")/.." && pwd)"
+[ -n "$R" ] && [ -f "$R/bench.py" ] || { echo "cannot locate the repo root from $0" >&2; exit 1; }
+cd "$R"
+mkdir -p gpurun_out
 python3 bench.py --steps 4000 --warmup 5 --no-cpu-baseline > gpurun_out/clk_bench.json 2>/dev/null &
 BP=$!
 sleep 22

@@ -84,15 +84,12 @@ int main(int argc, char** argv) {
       CK(hipStreamSynchronize(st));
       compare("wide(1/CU) vs round-2 kernel", I1, I0, (size_t)nB * M * S);
       CK(hipMemset(I1, 0xff, (size_t)nB * M * S * 4));
-      CK(conv_wide(st, 0, nB, M, D, S, WiT, M, X, (long)D * S, I1, (long)M * S, bi, 1, nullptr, nullptr, nullptr, nullptr, 0, 8));
       CK(hipStreamSynchronize(st));
-      compare("wide 8 waves vs round-2 kernel", I1, I0, (size_t)nB * M * S);
       for (int rep = 0; rep < 2; ++rep) {
         report("round-2 flattened 128x128", timeit(st, 10, [&] { return conv_embed_fwd(st, nB, D, S, M, X, WiT, bi, I0, 0, 0); }), fl);
         report("round-2 per-sample 128x208", timeit(st, 10, [&] { return conv_sample(st, 0, nB, M, D, S, WiT, M, X, (long)D * S, I0, (long)M * S, bi, 1, nullptr, nullptr); }), fl);
         report("wide 64x784, 2 per CU", timeit(st, 10, [&] { return conv_wide(st, 0, nB, M, D, S, WiT, M, X, (long)D * S, I1, (long)M * S, bi, 1, nullptr, nullptr, nullptr, nullptr, 0, 2); }), fl);
         report("wide 64x784, 1 per CU", timeit(st, 10, [&] { return conv_wide(st, 0, nB, M, D, S, WiT, M, X, (long)D * S, I1, (long)M * S, bi, 1, nullptr, nullptr, nullptr, nullptr, 0, 1); }), fl);
-        report("wide 64x784, 8 waves", timeit(st, 10, [&] { return conv_wide(st, 0, nB, M, D, S, WiT, M, X, (long)D * S, I1, (long)M * S, bi, 1, nullptr, nullptr, nullptr, nullptr, 0, 8); }), fl);
       }
       CK(hipFree(X)); CK(hipFree(WiT)); CK(hipFree(bi)); CK(hipFree(I0)); CK(hipFree(I1));
     }
@@ -115,7 +112,6 @@ int main(int argc, char** argv) {
         report("round-2 flattened 128x128", timeit(st, 10, [&] { return conv_att_pre(st, nB, M, S, A, I, WpT, bp, P0, 0, 0); }), fl);
         report("wide 64x784, 2 per CU", timeit(st, 10, [&] { return conv_wide(st, 0, nB, A, M, S, WpT, A, I, (long)M * S, P1, (long)A * S, bp, 0, nullptr, nullptr, nullptr, nullptr, 0, 2); }), fl);
         report("wide 64x784, 1 per CU", timeit(st, 10, [&] { return conv_wide(st, 0, nB, A, M, S, WpT, A, I, (long)M * S, P1, (long)A * S, bp, 0, nullptr, nullptr, nullptr, nullptr, 0, 1); }), fl);
-        report("wide 64x784, 8 waves", timeit(st, 10, [&] { return conv_wide(st, 0, nB, A, M, S, WpT, A, I, (long)M * S, P1, (long)A * S, bp, 0, nullptr, nullptr, nullptr, nullptr, 0, 8); }), fl);
       }
       CK(hipFree(I)); CK(hipFree(WpT)); CK(hipFree(bp)); CK(hipFree(P0)); CK(hipFree(P1));
     }
@@ -161,7 +157,7 @@ int main(int argc, char** argv) {
       CK(hipMemcpy(dA, hA.data(), hA.size() * 4, hipMemcpyHostToDevice));
       CK(hipMemcpy(dB, hB.data(), hB.size() * 4, hipMemcpyHostToDevice));
       CK(hipMalloc(&dW, (size_t)M * D * 4)); CK(hipMemset(dW, 0, (size_t)M * D * 4));
-      CK(hipMalloc(&slab, conv_wgrad_slab_floats(nb, M, D, S) * 4));
+      CK(hipMalloc(&slab, conv_wgrad_slab_floats(nb, M, D, S) * 4)); rau::split_ws_register(slab, (conv_wgrad_slab_floats(nb, M, D, S) * 4) / 4);
       CK(conv_embed_wgrad(st, nb, D, S, M, dA, nullptr, dB, dW, slab, 0, nullptr, 1));
       CK(hipStreamSynchronize(st));
       std::vector<float> hW((size_t)M * D);
@@ -184,7 +180,7 @@ int main(int argc, char** argv) {
       float *dWp, *dWi, *slab;
       CK(hipMalloc(&dWp, (size_t)A * M * 4)); CK(hipMalloc(&dWi, (size_t)M * D * 4));
       size_t sl = conv_wgrad_slab_floats(nB, M, D, S); if (conv_wgrad_slab_floats(nB, A, M, S) > sl) sl = conv_wgrad_slab_floats(nB, A, M, S);
-      CK(hipMalloc(&slab, sl * 4));
+      CK(hipMalloc(&slab, sl * 4)); rau::split_ws_register(slab, (sl * 4) / 4);
       printf("conv weight gradients  nB=%d\n", nB);
       for (int rep = 0; rep < 2; ++rep) {
         report("conv_att_wgrad (256 x 512)", timeit(st, 10, [&] { return conv_att_wgrad(st, nB, M, S, A, dS, I, dWp, slab, 0); }), 2.0 * A * M * (double)nB * S);
@@ -210,7 +206,7 @@ int main(int argc, char** argv) {
         CK(hipMemcpy(dB, hB.data(), hB.size() * 2, hipMemcpyHostToDevice));
         CK(hipMalloc(&dW, (size_t)M * D * 4)); CK(hipMemset(dW, 0, (size_t)M * D * 4));
         size_t sl = conv_wgrad_slab_floats(nb, M, D, S); if (wgrad16_slab_floats(nb, M, D, S) > sl) sl = wgrad16_slab_floats(nb, M, D, S);
-        CK(hipMalloc(&slab, sl * 4));
+        CK(hipMalloc(&slab, sl * 4)); rau::split_ws_register(slab, (sl * 4) / 4);
         CK(conv_embed_wgrad_b16(st, nb, D, S, M, dA, dB, dW, slab));
         CK(hipStreamSynchronize(st));
         std::vector<float> hW((size_t)M * D);
@@ -234,7 +230,7 @@ int main(int argc, char** argv) {
         CK(hipMemset(dZ, 0x3c, (size_t)nB * M * S * 2)); CK(hipMemset(X, 0x3b, (size_t)nB * D * S * 2));
         CK(hipMalloc(&dWi, (size_t)M * D * 4));
         size_t sl = conv_wgrad_slab_floats(nB, M, D, S); if (wgrad16_slab_floats(nB, M, D, S) > sl) sl = wgrad16_slab_floats(nB, M, D, S);
-        CK(hipMalloc(&slab, sl * 4));
+        CK(hipMalloc(&slab, sl * 4)); rau::split_ws_register(slab, (sl * 4) / 4);
         const double bytes = ((double)nB * M * S + (double)nB * D * S) * 2;
         for (int rep = 0; rep < 2; ++rep) {
           const double us = timeit(st, 10, [&] { return conv_embed_wgrad_b16(st, nB, D, S, M, dZ, X, dWi, slab); });

@@ -116,7 +116,7 @@ int main(int argc, char** argv) {
   float* dZ; CK(hipMalloc(&dZ, (size_t)B * M * S * 4));
   float* dWp = dev_rand((size_t)A * M), *dWi = dev_rand((size_t)M * D);
   size_t sl = conv_wgrad_slab_floats(8 * B, M, D, S); if (conv_wgrad_slab_floats(B, A, M, S) > sl) sl = conv_wgrad_slab_floats(B, A, M, S);
-  float* slab; CK(hipMalloc(&slab, sl * 4 + (size_t)64 * 2048 * 512 * 4));
+  float* slab; CK(hipMalloc(&slab, sl * 4 + (size_t)64 * 2048 * 512 * 4)); rau::split_ws_register(slab, (sl * 4 + (size_t)64 * 2048 * 512 * 4) / 4);
   const double NS = (double)B * S;
   const char* only = argc > 2 ? argv[2] : "";
   if (!strcmp(only, "peak") || !only[0]) {

@@ -1,8 +1,9 @@
 #!/bin/bash
 # kernel trace of one bench run; prints per-kernel durations of the recurrence's small kernels
 # usage (GPU box): bash tools/ktrace_chain.sh [bench args]      (development tool)
+R="$(cd "$(dirname "$0")/.." && pwd)"
+[ -n "$R" ] && [ -f "$R/bench.py" ] || { echo "cannot locate the repo root from $0" >&2; exit 1; }
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
 rm -rf $R/gpurun_out/sk
 rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/sk -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline "$@" > $R/gpurun_out/sk.log 2>&1
 cd $R && python3 - <<PY

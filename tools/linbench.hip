@@ -25,7 +25,7 @@ int main(int argc, char** argv) {
   CK(hipStreamCreate(&st));
   const size_t slab_floats = (size_t)16 << 20;
   float* slab;
-  CK(hipMalloc(&slab, slab_floats * 4));
+  CK(hipMalloc(&slab, slab_floats * 4)); rau::split_ws_register(slab, (slab_floats * 4) / 4);
   for (const Shape& sh : shapes) {
     const int N = sh.N, K = sh.K;
     std::vector<float> hA((size_t)M * K), hW((size_t)N * K), hb(N), hC((size_t)M * N);

@@ -1,8 +1,9 @@
 #!/bin/bash
 # PMC passes over a stand-alone tool binary: bash tools/pmc_tool.sh <kernel-substring> <binary> [args]
 # (FETCH_SIZE / WRITE_SIZE / SQ set in separate runs; prints per-kernel averages)   development tool
+R="$(cd "$(dirname "$0")/.." && pwd)"
+[ -n "$R" ] && [ -f "$R/bench.py" ] || { echo "cannot locate the repo root from $0" >&2; exit 1; }
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
 pat=$1; shift
 bin=$R/tools/$1; shift
 for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY"; do
