@@ -113,6 +113,119 @@ def cpu_baseline_cxx(cfgd, budget_s=12.0):
             "sample": f"{n} fwd+bwd steps at batch {sh.B} (C++ oracle, OpenMP f32, {dt:.1f}s)"}
 
 
+def roofline_objects(prof, nprof, dtype, shape):
+    """`roofline` (dominant bulk kernel) and `bulk_kernels` (all five conv classes) from a HIP-event
+    profile of `nprof` steps (rau_prof_*: events on the stream each kernel is launched on).
+    shape = (batch, D, dtype) selects the committed PMC pass the `traffic` figure is read from."""
+    # dominant kernel = the bulk-GEMM class with the most measured device time in THIS run
+    bulk = {k: prof[k] for k in BULK_CLASSES if k in prof and prof[k]["launches"]}
+    dom_name = max(bulk, key=lambda k: bulk[k]["ms"])
+    dom = bulk[dom_name]
+    avg_ms = dom["ms"] / dom["launches"]
+    flops_per_launch = dom["flops"] / dom["launches"]
+    bytes_per_launch = dom["bytes"] / dom["launches"]
+    tfl = flops_per_launch / (avg_ms * 1e-3) / 1e12
+    gbs = bytes_per_launch / (avg_ms * 1e-3) / 1e9
+    # HBM bytes per launch of that kernel: NOT measured by this run -- taken from the newest committed
+    # PMC passes of the same command (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs,
+    # FETCH_SIZE doubled per the gfx950 correction) when one exists for this kernel and shape
+    traffic, traffic_src = None, None
+    for rnd in ("r04", "r03", "r02", "r01"):
+        tag = {(256, 512, "f32"): rnd, (256, 2048, "bf16"): rnd + "_bf16"}.get(shape)
+        pmc = os.path.join(ROOT, "profiles", f"{tag}_pmc_{dom_name}.json")
+        if tag and os.path.exists(pmc):
+            traffic = json.load(open(pmc))["hbm_bytes_per_launch"]
+            traffic_src = f"profiles/{tag}_pmc_{dom_name}.json (separate rocprofv3 --pmc passes)"
+            break
+    mfma_peak = MFMA_F32_PEAK_TFLOPS if dtype == "f32" else MFMA_BF16_PEAK_TFLOPS
+    both = {"mfma_frac": tfl / mfma_peak, "hbm_frac": gbs / HBM_PEAK_GBS,
+            "mfma_tflops": tfl, "hbm_gbs_algorithmic": gbs}
+    if dtype == "f32":   # f32 MFMA-bound (SURVEY 8d)
+        roof = {"bound": "mfma", "achieved": tfl, "peak": mfma_peak, "unit": "TFLOP/s",
+                "frac": tfl / mfma_peak}
+    else:                # bf16 operands: HBM-bound; algorithmic bytes = operands read
+        roof = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": gbs / HBM_PEAK_GBS}
+    roof.update({"traffic": traffic, "traffic_source": traffic_src, "kernel": dom_name,
+                 "avg_launch_ms": avg_ms, "launches_per_step": dom["launches"] / nprof,
+                 "flops_per_launch": flops_per_launch, "bytes_per_launch": bytes_per_launch, **both})
+    # the same two fractions for every bulk class (which one is "dominant" can flip by run)
+    bulk_kernels = {
+        k: {"ms_per_step": round(v["ms"] / nprof, 4),
+            "mfma_frac": round(v["flops"] / (v["ms"] * 1e-3) / 1e12 / mfma_peak, 4),
+            "hbm_frac": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+        for k, v in bulk.items()}
+    return {"roofline": roof, "bulk_kernels": bulk_kernels}
+
+
+WORKLOADS = {("SS", 512, "f32"): "configs[1]", ("ResNet", 2048, "bf16"): "configs[2]",
+             ("MS", 512, "f32"): "configs[3]", ("Full", 2048, "f32"): "configs[4]",
+             ("Full", 2048, "bf16"): "configs[4] (bf16 operands)"}
+
+
+def other_config(name, base_cfgd, device_id, *, batch, D, dtype, variant, steps, warmup=3, note=""):
+    """One more BASELINE.json config on the driver's clock: its own context, the
+    same step (zero grads + forward + backward, train mode, Philox masks per step, inputs resident in
+    HBM), timed over `steps` steps between host synchronisations, then a 3-step HIP-event profile for
+    its own roofline object.  Single GPU; the headline line is not affected (it was timed before)."""
+    import torch
+    from rau_vqa_amd import synth
+    from rau_vqa_amd.model import RAU, Config, hop_weights
+    cfgd = dict(base_cfgd, B=batch, D=D)
+    cfg = Config(device_id=device_id, dtype=dtype, **cfgd)
+    m = RAU(cfg)
+    try:
+        m.init_uniform(seed=123)
+        m.set_batch(**synth.make_batch(cfg.B, cfg.T, cfg.V, cfg.D, cfg.S, cfg.K, seed=123, lens="full"))
+        m.training()
+        hop_w = hop_weights(variant, cfg.H, 0)
+
+        def step(i):
+            m.set_dropout_seed(123, i)
+            m.zero_grads()
+            m.forward()
+            m.backward(hop_w)
+
+        def fence():
+            m.sync()
+            torch.cuda.synchronize()
+        for i in range(warmup):
+            step(i)
+        fence()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            step(warmup + i)
+        fence()
+        dt = time.perf_counter() - t0
+        assert np.all(np.isfinite(m.losses()))
+        m.prof_reset()
+        m.prof_enable(True)
+        nprof = 3
+        for i in range(nprof):
+            step(1000 + i)
+        m.sync()
+        prof = m.prof()
+        m.prof_enable(False)
+        fmap = f"14x14x{cfg.D}"
+        out = {"metric": f"QA-pairs/sec fwd+bwd, Ours_{variant} 8-step RAU, batch {cfg.B}, {fmap}",
+               "value": cfg.B * steps / dt, "unit": "QA-pairs/s", "ms_per_step": dt / steps * 1e3,
+               "steps": steps, "warmup": warmup, "dtype": dtype, "n_gpus": 1,
+               "config": {"workload": f"Ours_{variant} 8-step RAU fwd+bwd, {fmap}, "
+                                      f"{WORKLOADS.get((variant, D, dtype), 'not a BASELINE config')}{note}",
+                          "batch_per_gpu": cfg.B, "T": cfg.T, "feature_map": fmap, "hops": cfg.H,
+                          "hop_weights": variant,
+                          "arithmetic": "f32 operands, f32 MFMA accumulate" if dtype == "f32"
+                                        else "bf16-rounded conv-GEMM operands, f32 accumulate; rest f32",
+                          "launch": "eager, 3 streams"}}
+        out.update(roofline_objects(prof, nprof, dtype, (batch, D, dtype)))
+        gf_per_qa = {512: 3.656, 2048: 8.588}.get(D)
+        if gf_per_qa:
+            out["step_tflops_useful"] = gf_per_qa * cfg.B * steps / dt / 1e3
+        return out
+    finally:
+        m.close()
+
+
 def self_launch(args):
     """--gpus N > 1 without a rendezvous in the environment: start the ranks as a child
     torch.distributed.run (never an exec, and before anything here has touched the GPU),
@@ -150,7 +263,14 @@ def main():
     ap.add_argument("--graph", action="store_true",
                     help="replay each step as one hipGraph launch (rau_graph_step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--quick", action="store_true",
+                    help="A/B sweeps: the timed steps and the 3-step kernel profile only (no update, H2D, "
+                         "inference, other_configs or CPU-baseline legs)")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the other_configs legs (configs[2], the configs[3] shard) of the default run")
     args = ap.parse_args()
+    if args.quick:
+        args.no_cpu_baseline = args.no_other_configs = True
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -285,47 +405,7 @@ def main():
         prof = m.prof()
         m.prof_enable(False)
         m_prof[0] = False
-        # dominant kernel = the bulk-GEMM class with the most measured device time in THIS run
-        bulk = {k: prof[k] for k in BULK_CLASSES if k in prof and prof[k]["launches"]}
-        dom_name = max(bulk, key=lambda k: bulk[k]["ms"])
-        dom = bulk[dom_name]
-        avg_ms = dom["ms"] / dom["launches"]
-        flops_per_launch = dom["flops"] / dom["launches"]
-        bytes_per_launch = dom["bytes"] / dom["launches"]
-        tfl = flops_per_launch / (avg_ms * 1e-3) / 1e12
-        gbs = bytes_per_launch / (avg_ms * 1e-3) / 1e9
-        # HBM bytes per launch of that kernel: NOT measured by this run -- taken from the committed
-        # PMC passes of the same command (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs,
-        # FETCH_SIZE doubled per the gfx950 correction) when one exists for this kernel and shape
-        traffic, traffic_src = None, None
-        shape = (args.batch, args.D, args.dtype)
-        for rnd in ("r03", "r02", "r01"):
-            tag = {(256, 512, "f32"): rnd, (256, 2048, "bf16"): rnd + "_bf16"}.get(shape)
-            pmc = os.path.join(ROOT, "profiles", f"{tag}_pmc_{dom_name}.json")
-            if tag and os.path.exists(pmc):
-                traffic = json.load(open(pmc))["hbm_bytes_per_launch"]
-                traffic_src = f"profiles/{tag}_pmc_{dom_name}.json (separate rocprofv3 --pmc passes)"
-                break
-        mfma_peak = MFMA_F32_PEAK_TFLOPS if args.dtype == "f32" else MFMA_BF16_PEAK_TFLOPS
-        both = {"mfma_frac": tfl / mfma_peak, "hbm_frac": gbs / HBM_PEAK_GBS,
-                "mfma_tflops": tfl, "hbm_gbs_algorithmic": gbs}
-        if args.dtype == "f32":   # f32 MFMA-bound
-            extra["roofline"] = {"bound": "mfma", "achieved": tfl, "peak": mfma_peak,
-                                 "unit": "TFLOP/s", "frac": tfl / mfma_peak}
-        else:                     # bf16 operands: HBM-bound; algorithmic bytes = operands read
-            extra["roofline"] = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS,
-                                 "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS}
-        extra["roofline"].update({"traffic": traffic, "traffic_source": traffic_src,
-                                  "kernel": dom_name, "avg_launch_ms": avg_ms,
-                                  "launches_per_step": dom["launches"] / nprof,
-                                  "flops_per_launch": flops_per_launch,
-                                  "bytes_per_launch": bytes_per_launch, **both})
-        # the same two fractions for every bulk class (which one is "dominant" can flip by run)
-        extra["bulk_kernels"] = {
-            k: {"ms_per_step": round(v["ms"] / nprof, 4),
-                "mfma_frac": round(v["flops"] / (v["ms"] * 1e-3) / 1e12 / mfma_peak, 4),
-                "hbm_frac": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
-            for k, v in bulk.items()}
+        extra.update(roofline_objects(prof, nprof, args.dtype, (args.batch, args.D, args.dtype)))
         tot = sum(v["ms"] for v in prof.values())
         extra["kernel_classes_ms_per_step"] = {
             k: round(v["ms"] / nprof, 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}
@@ -334,82 +414,97 @@ def main():
         gf_per_qa = {512: 3.656, 2048: 8.588}.get(args.D)
         if gf_per_qa:
             extra["step_tflops_useful"] = gf_per_qa * cfg.B * world * args.steps / dt / 1e3
-        # update cost, reported separately (not part of the metric)
-        fence()
-        t1 = time.perf_counter()
-        for i in range(5):
-            step(2000 + i)
-            m.update(step_t=i)
-        fence()
-        extra["step_incl_update_ms"] = (time.perf_counter() - t1) / 5 * 1e3
-        h2d_ms = h2d_leg()
-        if h2d_ms is not None:
-            extra["step_incl_h2d_ms"] = h2d_ms
-            extra["h2d_bytes_per_step"] = int(cfg.B * cfg.D * cfg.S * 4)
-        # inference (predict_result, SS:633-705: evaluate mode, forward only, i_embed / ifeatproj
-        # hoisted out of the hop loop), reported separately
-        m.evaluate()
-        for i in range(2):
-            m.forward()
-        fence()
-        t2 = time.perf_counter()
-        for i in range(10):
-            m.forward()
-        fence()
-        inf_s = (time.perf_counter() - t2) / 10
-        extra["inference_qa_per_s"] = cfg.B / inf_s
-        # Roofline of the evaluate-mode forward (i_embed / ifeatproj once, encoder, H hops).  Per QA pair:
-        # FLOPs = convs + encoder + hops (Linears + attention), bytes = X read, I and P written once and
-        # read once per hop (f32).  At the reference's sizes the MFMA floor (0.41 GFLOP/QA / 157 TFLOP/s)
-        # is 3.5x the HBM floor, so the bound is the matrix pipe, not HBM (SURVEY 8f next-2 assumed HBM).
-        def inference_roofline(c, secs):
-            fl = (2.0 * c.S * (c.M * c.D + c.A * c.M)
-                  + c.T * (2.0 * 4 * c.Rq * c.E + 3 * 2.0 * 4 * c.Rq * c.Rq)
-                  + 2.0 * c.Q * c.M
-                  + c.H * (2.0 * c.R * (c.M + c.S + 4 * c.R) + 2.0 * c.M * c.A + 2.0 * c.S * c.M
-                           + 2.0 * c.M * 4 * c.R + 2.0 * c.R * c.M + 2.0 * c.M * c.K
-                           + 2.0 * c.S * (c.A + c.M))) * c.B
-            by = 4.0 * c.B * c.S * (c.D + c.M + c.A + c.H * (c.M + c.A))
-            t_mfma, t_hbm = fl / (MFMA_F32_PEAK_TFLOPS * 1e12), by / (HBM_PEAK_GBS * 1e9)
-            return {"bound": "mfma" if t_mfma >= t_hbm else "hbm",
-                    "achieved": fl / secs / 1e12, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": fl / secs / 1e12 / MFMA_F32_PEAK_TFLOPS,
-                    "flops_per_batch": fl, "algorithmic_bytes_per_batch": by,
-                    "hbm_gbs_algorithmic": by / secs / 1e9, "hbm_frac": by / secs / 1e9 / HBM_PEAK_GBS}
-        extra["inference"] = {"qa_per_s": cfg.B / inf_s, "batch": cfg.B, "ms_per_batch": inf_s * 1e3,
-                              "roofline": inference_roofline(cfg, inf_s),
-                              "note": "whole evaluate-mode forward, wall time over 10 batches; at this batch the "
-                                      "27 encoder steps and 8 hops (~90 dependent launches) bound it"}
-        m.training()
-        # the same forward at a serving batch (the recurrences' launch chain does not grow with the batch)
-        if world == 1 and args.dtype == "f32" and not args.graph and args.batch == 256:
-            from dataclasses import replace
-            cfg_b = replace(cfg, B=1024)
-            mb = RAU(cfg_b)
-            mb.set_params(m.get_params())
-            mb.set_batch(**synth.make_batch(cfg_b.B, cfg.T, cfg.V, cfg.D, cfg.S, cfg.K, seed=5, lens="full"))
-            mb.evaluate()
-            for i in range(2):
-                mb.forward()
-            mb.sync()
-            t4 = time.perf_counter()
+        if not args.quick:
+            # update cost, reported separately (not part of the metric)
+            fence()
+            t1 = time.perf_counter()
             for i in range(5):
-                mb.forward()
-            mb.sync()
-            inf_b = (time.perf_counter() - t4) / 5
-            mb.close()
-            extra["inference_b1024"] = {"qa_per_s": cfg_b.B / inf_b, "batch": cfg_b.B,
-                                        "ms_per_batch": inf_b * 1e3,
-                                        "roofline": inference_roofline(cfg_b, inf_b)}
-        m.training()
+                step(2000 + i)
+                m.update(step_t=i)
+            fence()
+            extra["step_incl_update_ms"] = (time.perf_counter() - t1) / 5 * 1e3
+            h2d_ms = h2d_leg()
+            if h2d_ms is not None:
+                extra["step_incl_h2d_ms"] = h2d_ms
+                extra["h2d_bytes_per_step"] = int(cfg.B * cfg.D * cfg.S * 4)
+            # inference (predict_result, SS:633-705: evaluate mode, forward only, i_embed / ifeatproj
+            # hoisted out of the hop loop), reported separately
+            m.evaluate()
+            for i in range(2):
+                m.forward()
+            fence()
+            t2 = time.perf_counter()
+            for i in range(10):
+                m.forward()
+            fence()
+            inf_s = (time.perf_counter() - t2) / 10
+            extra["inference_qa_per_s"] = cfg.B / inf_s
+            # Roofline of the evaluate-mode forward (i_embed / ifeatproj once, encoder, H hops).  Per QA pair:
+            # FLOPs = convs + encoder + hops (Linears + attention), bytes = X read, I and P written once and
+            # read once per hop (f32).  At the reference's sizes the MFMA floor (0.41 GFLOP/QA / 157 TFLOP/s)
+            # is 3.5x the HBM floor, so the bound is the matrix pipe, not HBM (SURVEY 8f next-2 assumed HBM).
+            def inference_roofline(c, secs):
+                fl = (2.0 * c.S * (c.M * c.D + c.A * c.M)
+                      + c.T * (2.0 * 4 * c.Rq * c.E + 3 * 2.0 * 4 * c.Rq * c.Rq)
+                      + 2.0 * c.Q * c.M
+                      + c.H * (2.0 * c.R * (c.M + c.S + 4 * c.R) + 2.0 * c.M * c.A + 2.0 * c.S * c.M
+                               + 2.0 * c.M * 4 * c.R + 2.0 * c.R * c.M + 2.0 * c.M * c.K
+                               + 2.0 * c.S * (c.A + c.M))) * c.B
+                by = 4.0 * c.B * c.S * (c.D + c.M + c.A + c.H * (c.M + c.A))
+                t_mfma, t_hbm = fl / (MFMA_F32_PEAK_TFLOPS * 1e12), by / (HBM_PEAK_GBS * 1e9)
+                return {"bound": "mfma" if t_mfma >= t_hbm else "hbm",
+                        "achieved": fl / secs / 1e12, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": fl / secs / 1e12 / MFMA_F32_PEAK_TFLOPS,
+                        "flops_per_batch": fl, "algorithmic_bytes_per_batch": by,
+                        "hbm_gbs_algorithmic": by / secs / 1e9, "hbm_frac": by / secs / 1e9 / HBM_PEAK_GBS}
+            extra["inference"] = {"qa_per_s": cfg.B / inf_s, "batch": cfg.B, "ms_per_batch": inf_s * 1e3,
+                                  "roofline": inference_roofline(cfg, inf_s),
+                                  "note": "whole evaluate-mode forward, wall time over 10 batches; at this batch the "
+                                          "27 encoder steps and 8 hops (~90 dependent launches) bound it"}
+            m.training()
+            # the same forward at a serving batch (the recurrences' launch chain does not grow with the batch)
+            if world == 1 and args.dtype == "f32" and not args.graph and args.batch == 256:
+                from dataclasses import replace
+                cfg_b = replace(cfg, B=1024)
+                mb = RAU(cfg_b)
+                mb.set_params(m.get_params())
+                mb.set_batch(**synth.make_batch(cfg_b.B, cfg.T, cfg.V, cfg.D, cfg.S, cfg.K, seed=5, lens="full"))
+                mb.evaluate()
+                for i in range(2):
+                    mb.forward()
+                mb.sync()
+                t4 = time.perf_counter()
+                for i in range(5):
+                    mb.forward()
+                mb.sync()
+                inf_b = (time.perf_counter() - t4) / 5
+                mb.close()
+                extra["inference_b1024"] = {"qa_per_s": cfg_b.B / inf_b, "batch": cfg_b.B,
+                                            "ms_per_batch": inf_b * 1e3,
+                                            "roofline": inference_roofline(cfg_b, inf_b)}
+            m.training()
+        # the other single-GPU workloads of BASELINE.json on the same clock (the headline's timed region
+        # is over): configs[2] and the 64-sample strong-scaling shard of configs[3] (512 samples / 8 GPUs)
+        headline_run = ((args.dtype, args.D, args.variant, args.batch) == ("f32", 512, "SS", 256)
+                        and world == 1 and not args.graph and not args.global_batch)
+        if headline_run and not args.no_other_configs:
+            extra["other_configs"] = {
+                "configs[2]": other_config("configs[2]", cfgd, local_rank, batch=256, D=2048, dtype="bf16",
+                                           variant="ResNet", steps=10),
+                "configs[3] shard": other_config("configs[3] shard", cfgd, local_rank, batch=64, D=512,
+                                                 dtype="f32", variant="MS", steps=20,
+                                                 note=" -- one rank's 64-sample shard of the 512-sample "
+                                                      "global batch at 8 GPUs, without the gradient all-reduce"),
+            }
         if world == 1 and not args.no_cpu_baseline:
-            extra["cpu_baseline"] = cpu_baseline(cfgd)
-            extra["cpu_baseline_cxx"] = cpu_baseline_cxx(cfgd)
+            extra["cpu_baseline"] = cpu_baseline(cfgd, budget_s=12.0)
+            extra["cpu_baseline_cxx"] = cpu_baseline_cxx(cfgd, budget_s=8.0)
     elif world > 1:
         # keep ranks in lock-step with rank 0's extra (collective-carrying) steps
         for i in range(3):
             step(1000 + i)
         fence()
+    if rank != 0 and world > 1 and not args.quick:
         for i in range(5):
             step(2000 + i)
             m.update(step_t=i)
@@ -437,9 +532,7 @@ def main():
                   f"{' per GPU' if world > 1 else ''}, {fmap}")
         if headline and world == 1:
             metric = "QA-pairs/sec fwd+bwd, Ours_SS 8-step RAU, batch 256, 14x14x512"
-        cfgs = {("SS", 512, "f32"): "configs[1]", ("ResNet", 2048, "bf16"): "configs[2]",
-                ("MS", 512, "f32"): "configs[3]", ("Full", 2048, "f32"): "configs[4]",
-                ("Full", 2048, "bf16"): "configs[4] (bf16 operands)"}
+        cfgs = WORKLOADS
         line = {"metric": metric,
                 "value": qa, "unit": "QA-pairs/s", "n_gpus": world, "steps": args.steps,
                 "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,

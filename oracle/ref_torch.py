@@ -170,19 +170,25 @@ def multimodal(sh, P, q, feats4d, prev_c, prev_h, mq, mx, mmf, bf16=False):
 
 
 def step(sh, params, feats, tokens, lens, labels, masks=None, hop_w=None,
-         backward=True, dtype=torch.float64, bf16=False, bf16_nudge=0.0):
+         backward=True, dtype=torch.float64, bf16=False, bf16_nudge=0.0, per_sample_abs=False):
     """One feval forward(+backward), SS:428-596.  Same I/O convention as oracle.step.
     bf16_nudge (with bf16=True): flip the rounding of every GEMM operand that lies within that
-    relative distance of a bf16 rounding boundary (tests/test_gpu_bf16.py derives its bar from it)."""
+    relative distance of a bf16 rounding boundary (tests/test_gpu_bf16.py derives its bar from it).
+    per_sample_abs: also return gabs_{embed,rnn,mult} = sum_b |g_b|, g_b the gradient of sample b's
+    share of the loss (B extra backward passes): the UN-CANCELLED magnitude of every gradient element
+    over the batch sum -- the scale a rounding error has to be read against where the sum itself
+    nearly cancels (a bias gradient summing dz over a 2-position softmax, whose rows sum to zero)."""
     global _NUDGE
     _NUDGE = float(bf16_nudge) if bf16 else 0.0
     try:
-        return _step(sh, params, feats, tokens, lens, labels, masks, hop_w, backward, dtype, bf16)
+        return _step(sh, params, feats, tokens, lens, labels, masks, hop_w, backward, dtype, bf16,
+                     per_sample_abs)
     finally:
         _NUDGE = 0.0
 
 
-def _step(sh, params, feats, tokens, lens, labels, masks, hop_w, backward, dtype, bf16):
+def _step(sh, params, feats, tokens, lens, labels, masks, hop_w, backward, dtype, bf16,
+          per_sample_abs=False):
     t = lambda a: torch.as_tensor(a).to(dtype)
     flat = {k: t(params[k]).clone().requires_grad_(backward) for k in ("embed", "rnn", "mult")}
     Emb = flat["embed"].view(sh.V, sh.E)
@@ -211,6 +217,7 @@ def _step(sh, params, feats, tokens, lens, labels, masks, hop_w, backward, dtype
     out = {"losses": [], "argmax": [], "logits": [], "dopred": [], "att": [],
            "att_c": [], "att_h": []}
     total = 0.0
+    rows = torch.zeros(B, dtype=dtype)
     y = None if labels is None else torch.as_tensor(labels).long() - 1
     for hop in range(sh.H):
         score, dp, a, c, h = multimodal(
@@ -228,8 +235,20 @@ def _step(sh, params, feats, tokens, lens, labels, masks, hop_w, backward, dtype
             loss = F.cross_entropy(score, y)           # CrossEntropyCriterion, SS:518
             out["losses"].append(loss.detach())
             total = total + float(hop_w[hop]) * loss   # dpred:mul(w), SS:569
+            if per_sample_abs:                         # the same loss, one term per sample
+                rows = rows + float(hop_w[hop]) * F.cross_entropy(score, y, reduction="none") / B
     res = {k: torch.stack(v).numpy() for k, v in out.items() if v}
     res["q"] = q.detach().numpy()
+    if backward and per_sample_abs:
+        keys = ("embed", "rnn", "mult")
+        acc = {k: torch.zeros_like(flat[k]) for k in keys}
+        for b in range(B):
+            gs = torch.autograd.grad(rows[b], [flat[k] for k in keys], retain_graph=True, allow_unused=True)
+            for k, g in zip(keys, gs):
+                if g is not None:
+                    acc[k] += g.abs()
+        for k in keys:
+            res["gabs_" + k] = acc[k].numpy()
     if backward:
         total.backward()
         res["g_embed"] = flat["embed"].grad.numpy()

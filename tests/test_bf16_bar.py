@@ -1,0 +1,59 @@
+"""Why tests/test_gpu_bf16.py scales its 'vs exact' bar for gradients by the UN-CANCELLED magnitude
+ -- checked on the CPU, no device involved: the rounding-EMULATING restatement
+(oracle/ref_torch.py bf16=True) against the exact one on the shape of soak seed 2023
+(gpurun_out/soak_bf16b.log of round 3: 'attbymemory.linear.bias: 0.1126' against a fixed 3e-2).
+The emulation alone reproduces that figure, so the soak failure was the bar, not the device."""
+import numpy as np
+
+from oracle import ref_torch as RT
+from tests import util
+
+DIMS = dict(B=82, T=1, V=42, E=28, Rq=24, D=32, S=2, M=132, A=80, R=44, K=16, H=3)
+
+
+def _mult_slice(sh, name, bias):
+    off = 0
+    for n, o, i in RT.mult_specs(sh):
+        if n == name:
+            return slice(off + o * i, off + o * i + o) if bias else slice(off, off + o * i)
+        off += o * i + o
+    raise KeyError(name)
+
+
+def test_soak_seed_2023_is_cancellation_not_a_device_error():
+    sh = util.shapes(DIMS)
+    batch, params, masks = util.make_problem(sh, lens="ragged", scale=0.3)
+    hop_w = np.full(sh.H, float(sh.H), np.float32)
+    args = (sh, params, batch["feats"], batch["tokens"], batch["lens"], batch["labels"], masks, hop_w)
+    emu = RT.step(*args, bf16=True)
+    exact = RT.step(*args, per_sample_abs=True)
+    sl = _mult_slice(sh, "att_mem", bias=True)            # attbymemory.linear.bias, [S] = 2 elements
+    g, ge, gabs = exact["g_mult"][sl], emu["g_mult"][sl], exact["gabs_mult"][sl]
+    # a 2-way softmax: dz rows sum to zero, so the two bias-gradient elements are exact opposites
+    assert abs(g[0] + g[1]) < 1e-12 * np.abs(g).max()
+    # ... and each is a sum over (sample, hop) terms that cancels by two orders of magnitude
+    assert gabs.max() > 100 * np.abs(g).max()
+    err = np.abs(ge - g).max()
+    assert 0.09 < err / np.abs(g).max() < 0.14            # round 3's 0.1126 'failure', with no device in sight
+    assert err / gabs.max() < 1.5e-3                      # an ordinary bf16 rounding error of the TERMS
+    # every gradient tensor of the group against the bar the GPU test applies (1.5e-2 of the un-cancelled scale)
+    off = 0
+    for n, o, i in RT.mult_specs(sh):
+        for s2 in (slice(off, off + o * i), slice(off + o * i, off + o * i + o)):
+            x, e, ab = exact["g_mult"][s2], emu["g_mult"][s2], exact["gabs_mult"][s2]
+            scale = max(np.abs(x).max(), ab.max())
+            if scale > 1e-12:
+                assert np.abs(e - x).max() / scale < 1.5e-2, n
+        off += o * i + o
+
+
+def test_per_sample_magnitudes_sum_to_the_gradient():
+    """gabs = sum_b |g_b| with sum_b g_b = g: an upper bound of |g| element-wise, equal where all
+    samples pull the same way."""
+    sh = util.shapes(util.SMALL)
+    batch, params, masks = util.make_problem(sh, scale=0.5)
+    hop_w = np.full(sh.H, float(sh.H), np.float32)
+    r = RT.step(sh, params, batch["feats"], batch["tokens"], batch["lens"], batch["labels"], masks, hop_w,
+                per_sample_abs=True)
+    for k in ("embed", "rnn", "mult"):
+        assert np.all(r["gabs_" + k] >= np.abs(r["g_" + k]) * (1 - 1e-9) - 1e-15), k

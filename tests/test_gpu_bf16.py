@@ -11,9 +11,17 @@ several 1e-4 of the result (round 2's soak: 5.1e-4 and 7.1e-4 on seeds 855 / 859
 operand within NUDGE = 6e-7 (relative) of a boundary rounded the other way, upwards and downwards
 (ref_torch.step(bf16_nudge=+-NUDGE): operands further from a boundary keep their rounding bit
 for bit), and a tensor may differ from the plain emulation by TOL_BASE + SAFETY x the larger of the
-two shifts.  (2) Against the exact fp64 oracle: 3e-2 -- the size of the bf16 rounding itself (about
-1e-3 on these shapes), i.e. the mode is a precision trade, not a different computation.  Answer
-indices: exact wherever the emulated oracle's top-2 margin is decisive.
+two shifts.  (2) Against the exact fp64 oracle -- the mode is a precision trade of the size of the
+bf16 rounding itself, not a different computation: outputs within 3e-2 of their max norm; every
+gradient tensor within TOL_EXACT_GRAD = 1.5e-2 (about 4 x 2^-8: two chained rounded GEMMs) of its
+UN-CANCELLED magnitude max(max |g|, max sum_b |g_b|), g_b = sample b's share of the gradient
+(ref_torch.step(per_sample_abs=True)).  Round 3 held gradients to 3e-2 of max |g| instead, which
+passes or fails by the choice of seed: a gradient that is a near-cancelling sum -- the attbymemory
+bias over a 2-position map, whose softmax-Jacobian rows sum to zero -- carries the rounding error of
+its TERMS (soak seed 2023: max |g| 1.7e-2 against 2.8 un-cancelled, error 1.9e-3 = 0.113 of the one,
+6.6e-4 of the other; tests/test_bf16_bar.py reproduces those numbers without a device: the emulation
+alone differs from the exact oracle by that much).  Measured on the committed shapes: <= 5.3e-3.
+Answer indices: exact wherever the emulated oracle's top-2 margin is decisive.
 """
 import numpy as np
 import pytest
@@ -26,7 +34,8 @@ pytestmark = pytest.mark.gpu
 TOL_BASE = 2e-4       # accumulation order alone (measured <= 6e-5 on the committed shapes)
 NUDGE = 6e-7          # 2x the measured f32 error (~3e-7) of the intermediate tensors that get rounded
 SAFETY = 2.0          # flips are independent: the device may take any subset of the two nudged runs' flips
-TOL_EXACT = 3e-2
+TOL_EXACT = 3e-2        # outputs, relative to their max norm
+TOL_EXACT_GRAD = 1.5e-2  # gradients, relative to the un-cancelled magnitude (module docstring)
 
 
 def run(dims, scale, mode="train", lens="ragged"):
@@ -39,7 +48,7 @@ def run(dims, scale, mode="train", lens="ragged"):
     emu = RT.step(*args, bf16=True)
     emu_up = RT.step(*args, bf16=True, bf16_nudge=NUDGE)
     emu_dn = RT.step(*args, bf16=True, bf16_nudge=-NUDGE)
-    exact = RT.step(*args)
+    exact = RT.step(*args, per_sample_abs=True)
     cfg = Config(**{k: getattr(sh, k) for k in
                     ("B", "T", "V", "E", "Rq", "D", "S", "M", "A", "R", "K", "H",
                      "p_we", "p_rnn", "p_q", "p_x", "p_mf")}, dtype="bf16")
@@ -81,8 +90,21 @@ def run(dims, scale, mode="train", lens="ragged"):
         if not e < tol:
             bad[k] = (e, tol)
     assert not bad, f"vs emulated oracle, (error, derived bar): {bad}"
-    bad = {k: err(dev[k], t_ex[k]) for k in dev if not err(dev[k], t_ex[k]) < TOL_EXACT}
-    assert not bad, f"vs exact oracle above {TOL_EXACT}: {bad}"
+    # (2) vs the exact oracle: outputs against their max norm, gradients against the un-cancelled
+    # magnitude of the batch sum
+    t_abs = tensors({k: exact[k] for k in util.OUT_KEYS}, {grp: exact["gabs_" + grp] for grp in layouts})
+    bad = {}
+    for k in dev:
+        if k in util.OUT_KEYS:
+            e, tol = err(dev[k], t_ex[k]), TOL_EXACT
+        else:
+            scale = max(float(np.max(np.abs(t_ex[k]))), float(np.max(t_abs[k])))
+            e = float(np.max(np.abs(dev[k] - t_ex[k]))) / scale if scale > 1e-12 else \
+                float(np.max(np.abs(dev[k] - t_ex[k])))
+            tol = TOL_EXACT_GRAD
+        if not e < tol:
+            bad[k] = (e, tol)
+    assert not bad, f"vs exact oracle, (error, bar): {bad}"
     print(f"bf16: widest derived bar {widest:.2e}")
     ok, _, _ = util.argmax_margin_ok(emu["logits"], got["argmax"], emu["argmax"], margin=5e-3)
     assert ok
@@ -110,6 +132,15 @@ def test_bf16_dgrad16_tile_shapes():
     dS and Wp); two row tiles per sample, odd sample count."""
     dims = dict(B=5, T=4, V=40, E=16, Rq=32, D=64, S=196, M=256, A=64, R=32, K=52, H=2)
     run(dims, 0.1)
+
+
+def test_bf16_near_cancelling_bias_gradient_soak_seed_2023():
+    """The shape of round 3's one un-triaged soak failure (tools/soak_bf16.py seed 2023): a
+    2-position map, 82 samples -- the attbymemory bias gradient is a sum of terms that cancel to
+    1/170 of their magnitude, so its error relative to max |g| is 0.11 although every term carries
+    an ordinary bf16 rounding error.  Held to the bar scaled by the un-cancelled magnitude."""
+    dims = dict(B=82, T=1, V=42, E=28, Rq=24, D=32, S=2, M=132, A=80, R=44, K=16, H=3)
+    run(dims, 0.3)
 
 
 def test_bf16_7x7_feature_map_s49():

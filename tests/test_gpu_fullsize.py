@@ -309,14 +309,17 @@ def test_config3_ms_weights_sample_sharding_identity(per_rank):
         assert util.rel_err(g_big[k], acc[k]) < 2e-5, k
 
 
-def test_config4_full_gating_d2048_b128_graph_equals_eager():
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_config4_full_gating_d2048_b128_graph_equals_eager(dtype):
     """configs[4]: Ours_Full joint loss, 8 hops, global batch 1024 over 8 GPUs = 128 per rank,
     14x14x2048, "hipGraph-captured step loop": the captured step replays bit for bit what the
     eager three-stream step computes, at epoch 0 (all hops weighted) and at epoch 20 (hops 4..8
-    gated off, Full:414-426,587-589 -- another graph shape)."""
+    gated off, Full:414-426,587-589 -- another graph shape).  BASELINE.md 2.1 lists this config with
+    bf16 operands / f32 accumulate: both arithmetic modes are replayed (the bf16 one captures other
+    kernels -- dgrad16, wgrad16, the bf16-storing dropout pass -- and the side-stream split)."""
     from rau_vqa_amd.model import hop_weights
     dims = dict(FULL, B=128, D=2048)
-    m = make(dims)
+    m = make(dims, dtype=dtype)
     m.init_uniform(seed=123)
     batch = synth.make_batch(128, 26, FULL["V"], 2048, 196, 1000, lens="ragged")
     m.set_batch(**batch)
@@ -363,3 +366,50 @@ def test_answer_index_parity_1k_samples_train_mode():
         total += got_idx.size
     m.close()
     assert mism == 0, f"{mism} decided answer indices differ (of {total}, {undecided} undecided)"
+
+
+def test_answer_index_parity_1k_samples_bf16_d2048():
+    """north_star's 1000-sample answer-index set in the configs[2] arithmetic: RAU_BF16 mode, 14x14x2048,
+    evaluate mode, 4 x 250, against the rounding-EMULATING restatement (oracle/ref_torch.py bf16=True).
+    Which rows are decidable is DERIVED per row, not chosen: the emulation is run three times -- plain,
+    and with every GEMM operand within 6e-7 (relative) of a bf16 rounding boundary rounded the other
+    way, upwards and downwards (the operands whose rounding the device's own f32 error can flip,
+    tests/test_gpu_bf16.py) -- and a row counts as decided when the three runs name the same answer and
+    its top-2 margin exceeds twice the largest logit shift of that row between the runs plus the f32
+    margin of the f32-mode tests (1e-5).  Decided rows must match exactly; both counts are printed."""
+    import torch
+    from oracle import ref_torch
+    NUDGE = 6e-7
+    dims = dict(FULL, B=250, D=2048)
+    sh = util.shapes(dims)
+    m = make(dims, dtype="bf16")
+    m.init_uniform(seed=123)
+    params = m.get_params()
+    m.evaluate()
+    mism = undecided = total = 0
+    worst = 0.0
+    for chunk in range(4):
+        batch = synth.make_batch(250, 26, FULL["V"], 2048, 196, 1000, seed=323 + chunk, lens="ragged")
+        m.set_batch(**batch)
+        m.forward()
+        got_idx, got_lg = m.argmax(), m.logits()
+        runs = []
+        for nudge in (0.0, NUDGE, -NUDGE):
+            r = ref_torch.step(sh, params, batch["feats"], batch["tokens"], batch["lens"], batch["labels"],
+                               None, backward=False, dtype=torch.float32, bf16=True, bf16_nudge=nudge)
+            runs.append((np.asarray(r["logits"], np.float64), np.asarray(r["argmax"])))
+        (lg, am), (lg_u, am_u), (lg_d, am_d) = runs
+        worst = max(worst, util.rel_err(got_lg, lg))
+        shift = np.maximum(np.abs(lg_u - lg).max(-1), np.abs(lg_d - lg).max(-1))     # [H, B]
+        srt = np.sort(lg, axis=-1)
+        gap = srt[..., -1] - srt[..., -2]
+        decided = (am == am_u) & (am == am_d) & (gap > 2.0 * shift + 1e-5 * np.maximum(1.0, np.abs(srt[..., -1])))
+        mism += int(np.sum((got_idx != am) & decided))
+        undecided += int(np.sum(~decided))
+        total += got_idx.size
+    m.close()
+    print(f"bf16 D=2048 answer indices: {total - undecided} decided, {undecided} undecided of {total}; "
+          f"device vs emulation logits {worst:.2e}")
+    assert worst < 2e-3
+    assert mism == 0, f"{mism} decided answer indices differ (of {total}, {undecided} undecided)"
+    assert undecided < total // 20, f"{undecided} of {total} rows undecidable: the criterion decides nothing"

@@ -18,11 +18,19 @@ def _mk(sh, params, dtype="f32"):
     return m
 
 
-@pytest.mark.parametrize("dims", [util.SMALL, util.MEDIUM])
-def test_graph_step_matches_eager_bitwise(dims):
+# bf16 mode takes other kernels (dgrad16 / wgrad16 / the bf16-storing dropout and attention-backward
+# forms) and the side-stream split of the chain's non-recurrent GEMMs; BF16_TILES has the widths
+# dgrad16.hip (M % 128, A % 32) and wgrad16.hip (M, D % 256) accept on a 14x14 map.
+BF16_TILES = dict(B=12, T=6, V=60, E=64, Rq=64, D=256, S=196, M=256, A=64, R=64, K=200, H=3)
+
+
+@pytest.mark.parametrize("dims,dtype", [(util.SMALL, "f32"), (util.MEDIUM, "f32"),
+                                        (util.SMALL, "bf16"), (util.MEDIUM, "bf16"), (BF16_TILES, "bf16")],
+                         ids=["small-f32", "medium-f32", "small-bf16", "medium-bf16", "tiles-bf16"])
+def test_graph_step_matches_eager_bitwise(dims, dtype):
     sh = util.shapes(dims)
     _, params, _ = util.make_problem(sh, scale=0.3)
-    eager, graph = _mk(sh, params), _mk(sh, params)
+    eager, graph = _mk(sh, params, dtype), _mk(sh, params, dtype)
     rng = np.random.default_rng(3)
     for it in range(5):
         lens = "ragged" if it % 2 else np.full(sh.B, max(1, sh.T - it), np.int32)

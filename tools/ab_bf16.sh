@@ -4,7 +4,7 @@
 cd "$(dirname "$0")/.."
 mkdir -p gpurun_out
 out=gpurun_out/ab_bf16.log; : > $out
-run() { echo "== $*" >> $out; timeout -k 10 240 env "$@" python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --dtype bf16 --D 2048 --variant ResNet 2>/dev/null | python3 -c "
+run() { echo "== $*" >> $out; timeout -k 10 240 env "$@" python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-other-configs --dtype bf16 --D 2048 --variant ResNet 2>/dev/null | python3 -c "
 import sys, json
 for l in sys.stdin:
     l = l.strip()

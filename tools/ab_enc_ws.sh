@@ -6,7 +6,7 @@ cd "$R"
 mkdir -p gpurun_out
 for B in 16 32 64; do
 for ws in 1 0; do
-RAU_ENC_WS=$ws python3 bench.py --batch $B --variant MS --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | python3 -c "
+RAU_ENC_WS=$ws python3 bench.py --batch $B --variant MS --steps 20 --warmup 5 --no-cpu-baseline --no-other-configs 2>/dev/null | python3 -c "
 import sys, json
 for l in sys.stdin:
     l = l.strip()

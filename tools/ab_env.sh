@@ -5,7 +5,7 @@ cd "$(dirname "$0")/.."
 mkdir -p gpurun_out
 out=gpurun_out/ab_env.log
 : > $out
-run() { echo "== $*" >> $out; timeout -k 10 240 env $* python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline ${BENCH_ARGS} 2>/dev/null | python3 -c "
+run() { echo "== $*" >> $out; timeout -k 10 240 env $* python3 bench.py --steps 20 --warmup 5 --quick ${BENCH_ARGS} 2>/dev/null | python3 -c "
 import sys, json
 for l in sys.stdin:
     l = l.strip()

@@ -9,7 +9,7 @@ out=gpurun_out/ab_modes.log
 run() { # label, bench args, env...
   label=$1; args=$2; shift 2
   echo "== $label [$*]" >> $out
-  timeout -k 10 240 env "$@" python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline $args 2>/dev/null | python3 -c "
+  timeout -k 10 240 env "$@" python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-other-configs $args 2>/dev/null | python3 -c "
 import sys, json
 for l in sys.stdin:
     l = l.strip()

@@ -4,7 +4,7 @@ cd "$(dirname "$0")/.."
 mkdir -p gpurun_out
 out=gpurun_out/ab_wide.log
 : > $out
-run() { echo "== $*" >> $out; env "$@" python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | python3 -c "
+run() { echo "== $*" >> $out; env "$@" python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-other-configs 2>/dev/null | python3 -c "
 import sys, json
 for l in sys.stdin:
     l = l.strip()

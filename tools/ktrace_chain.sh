@@ -5,7 +5,7 @@ R="$(cd "$(dirname "$0")/.." && pwd)"
 [ -n "$R" ] && [ -f "$R/bench.py" ] || { echo "cannot locate the repo root from $0" >&2; exit 1; }
 cd /tmp && export TMPDIR=/tmp
 rm -rf $R/gpurun_out/sk
-rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/sk -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline "$@" > $R/gpurun_out/sk.log 2>&1
+rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/sk -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-other-configs "$@" > $R/gpurun_out/sk.log 2>&1
 cd $R && python3 - <<PY
 import csv, glob, collections
 f = glob.glob("gpurun_out/sk/**/*kernel_trace.csv", recursive=True)[0]

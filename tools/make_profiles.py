@@ -137,7 +137,7 @@ for cls, by_wg in traffic.items():
     pmc_json[cls] = {
         "kernel": cls,
         "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace --output-format csv -- "
-                   "python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline (two separate passes)",
+                   "python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-other-configs (two separate passes)",
         "launch_shapes": launches,
         "hbm_bytes_per_launch": avg,
         "algorithmic_bytes_per_launch": alg,

@@ -60,7 +60,7 @@ for cls, rr in by_cls.items():
     n = sum(r[3] for r in rr)
     json.dump({"kernel": cls,
                "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace --output-format csv -- python3 "
-                          "bench.py --dtype bf16 --D 2048 --variant ResNet --no-cpu-baseline --steps 2 --warmup 1 "
+                          "bench.py --dtype bf16 --D 2048 --variant ResNet --no-cpu-baseline --no-other-configs --steps 2 --warmup 1 "
                           "(two separate passes)",
                "launch_shapes": [{"kernel_name": r[1], "workgroups": r[2], "dispatches": r[3], "avg_us": r[4],
                                   "hbm_bytes": r[5], "algorithmic_bytes": r[6]} for r in rr],

@@ -4,7 +4,7 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 cd $R
-A="--dtype bf16 --D 2048 --variant ResNet --no-cpu-baseline"
+A="--dtype bf16 --D 2048 --variant ResNet --no-cpu-baseline --no-other-configs"
 rm -rf gpurun_out/b16_kt gpurun_out/b16_f gpurun_out/b16_w gpurun_out/b16_sq
 python3 bench.py $A > gpurun_out/b16_bench_line.json 2> gpurun_out/b16_bench_line.err; echo "bench rc=$?"
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/b16_kt -- python3 bench.py $A --steps 20 --warmup 3 > gpurun_out/b16_kt.log 2>&1; echo "kt rc=$?"
