@@ -145,6 +145,9 @@ hipError_t conv_att_dgrad_dz(hipStream_t st, int nB, int M, int S, int A, const 
   if (bf16 == 1 && dgrad16_ok(M, A, S, M))
     return dgrad16(st, nB, M, A, S, Wp, M, dS, (long)A * S, dZ, (long)M * S, dj, a, I, rs, dz16, ds16);
   if (ds16) return hipErrorInvalidValue;
+  // f32 output on the shapes dgrad_dma.hip takes: per-sample tiles fed by LDS-DMA (round 4)
+  if (!dz16 && dgrad_dma_ok(M, A, S, M))
+    return dgrad_dma(st, nB, M, A, S, Wp, M, dS, (long)A * S, dZ, (long)M * S, dj, a, I, rs);
   // one sample per tile (the wide tiling with this epilogue is a concluded negative in the step:
   // DESIGN.md section 8; tools/convbench keeps it for the stand-alone comparison)
   return conv_sample(st, 2, nB, M, A, S, Wp, M, dS, (long)A * S, dZ, (long)M * S, nullptr, 0, dj, a, I, rs,

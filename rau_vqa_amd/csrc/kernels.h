@@ -17,6 +17,12 @@ void split_ws_register(const float* base, size_t floats);
 void split_ws_unregister(const float* base);
 bool split_span_ok(const float* slab, long nsplit, size_t per_split_floats);
 
+// Wave priority the recurrence's kernels raise themselves to (s_setprio; common.h RAU_CHAIN_PRIO = 3).
+// The launchers that take it per launch (skinny_dma, lstm_fwd_multi) read this thread-local setting:
+// rau_forward lowers it for the encoder's kernels where the bulk stream is the longer path.
+void chain_prio_set(int prio);   // 0..3, calling thread; default 3
+int chain_prio_get();
+
 // ------------------------------------------------------------ GEMM (gemm_lin.hip)
 struct LinOpts {
   const float* bias = nullptr;    // + bias[n]
@@ -131,6 +137,12 @@ bool dgrad16_ok(int M, int K, int S, long w_rs);
 hipError_t dgrad16(hipStream_t st, int nB, int M, int K, int S, const float* Wt, long w_rs,
                    const void* X, long x_bs, void* C, long c_bs, const float* dj, const float* av,
                    const float* Y, float* rs, int c16, int x16 = 0 /* X stored as bf16 */);
+// f32 mode, 14 x 14 maps, M % 128 == 0, K % 16 == 0 (dgrad_dma.hip, round 4): the same product and epilogue on
+// per-sample tiles with both operands staged by LDS-DMA; bitwise the results of conv_sample's EPI 2
+bool dgrad_dma_ok(int M, int K, int S, long w_rs);
+hipError_t dgrad_dma(hipStream_t st, int nB, int M, int K, int S, const float* Wt, long w_rs,
+                     const float* X, long x_bs, float* C, long c_bs, const float* dj, const float* av,
+                     const float* Y, float* rs);
 // dWp += sum dS I^T in RAU_BF16 mode with dS stored as bf16 (att_bwd_fused's dS16), I f32
 hipError_t conv_att_wgrad_ds16(hipStream_t st, int nB, int M, int S, int A, const void* dS16,
                                const float* I, float* dWp, float* slab);
@@ -213,7 +225,7 @@ struct LstmFwdCell {
   float* c; long c_rs; float* h; long h_rs; float* tanhc;
   float* drop_out; const uint32_t* mask; size_t mask_e0; float mscale;
 };
-struct LstmFwdCells { int n; LstmFwdCell c[2]; };
+struct LstmFwdCells { int n; LstmFwdCell c[2]; int prio = 3; /* set by the launcher from chain_prio_get() */ };
 hipError_t lstm_fwd_multi(hipStream_t st, int order, int nB, int R, const LstmFwdCells& cells);
 // One LSTM cell step as ONE launch (lstm_fused.hip): recurrent gate GEMM on f32 MFMA with the
 // cell's pointwise half as its epilogue.  Up to two independent cells per launch (the encoder's

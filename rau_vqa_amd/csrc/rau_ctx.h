@@ -289,6 +289,30 @@ static inline bool prof_marker(const char* n) {
     if (std::strcmp(n, m) == 0) return true;
   return false;
 }
+// Measurement hook of the DEVELOPMENT build only (make dev -> librau_dev.so, -DRAU_DEV_HOOKS; the shipped
+// library compiles it to `false`): RAU_DEV_SKIP=class1,class2,.. drops every launch of the named kernel
+// classes.  Timing only -- the numerics of such a run are meaningless -- used for the per-class
+// sensitivity tables (tools/dev_skip.sh, profiles/r04_forward_gap.md).  Consumers of split-K partials
+// whose producer was skipped see a count of 0 or fail closed (split_guard.hip), never read out of bounds.
+#ifdef RAU_DEV_HOOKS
+static inline bool rau_dev_skipped(const char* cname) {
+  static const std::string list = [] { const char* e = std::getenv("RAU_DEV_SKIP"); return std::string(e ? e : ""); }();
+  if (list.empty()) return false;
+  size_t pos = 0;
+  const std::string n(cname);
+  while (pos <= list.size()) {
+    const size_t c = list.find(',', pos);
+    const std::string tok = list.substr(pos, c == std::string::npos ? std::string::npos : c - pos);
+    if (tok == n) return true;
+    if (c == std::string::npos) break;
+    pos = c + 1;
+  }
+  return false;
+}
+#define RAU_DEV_SKIPPED(cname) rau_dev_skipped(cname)
+#else
+#define RAU_DEV_SKIPPED(cname) false
+#endif
 // Launch wrapper: counts launches/FLOPs/bytes per kernel class and, when
 // profiling is on, brackets the launch with HIP events on the ctx stream.
 #define RUN(cname, fl, by, expr) RUNS(ctx->st, cname, fl, by, expr)
@@ -307,7 +331,7 @@ static inline bool prof_marker(const char* n) {
       pr_.sid = (rstream) == ctx->st ? 0 : (rstream) == ctx->st2 ? 1 : 2; \
       hipEventRecord(pr_.a, rstream);                                                     \
     }                                                                                     \
-    hipError_t e_ = (expr);                                                               \
+    hipError_t e_ = RAU_DEV_SKIPPED(cname) ? hipSuccess : (expr);                         \
     if (pc_ >= 0) {                                                                       \
       hipEventRecord(pr_.b, rstream);                                                     \
       ctx->precs.push_back(pr_);                                                          \

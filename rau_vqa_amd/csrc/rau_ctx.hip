@@ -1357,7 +1357,11 @@ int rau_forward(rau_ctx* ctx) {
         }
         RUN("enc_step_fused", fl, 0, lstm_step_fused(st, GATES_DEEP, sp));
       }
-    } else
+    } else {
+    // RAU_ENC_PRIO=0..3 (A/B): wave priority of the encoder's forward kernels
+    static const int enc_prio = [] { const char* e = std::getenv("RAU_ENC_PRIO"); return e ? std::atoi(e) : 3; }();
+    struct PrioReset { ~PrioReset() { chain_prio_set(3); } } prio_reset;
+    chain_prio_set(enc_prio);
     for (int s = 1; s <= TL + 1; ++s) {
       if (s == t_head + 1 && t_head < TL) HIPC(hipStreamWaitEvent(st, ctx->evG, 0));   // G1 rows of token s
       const float* Ap[3];
@@ -1400,6 +1404,7 @@ int rau_forward(rau_ctx* ctx) {
         C2.drop_out = nullptr; C2.mask = nullptr; C2.mask_e0 = 0; C2.mscale = 1.f;
       }
       RUN("lstm_fwd", 0, BRq * 4.0 * 10 * cells.n, lstm_fwd_multi(st, GATES_DEEP, B, Rq, cells));
+    }
     }
   }
   return 0;
@@ -1750,8 +1755,21 @@ int rau_backward(rau_ctx* ctx, const float* hop_w) {
   // Throughput work nothing else waits for: third stream, so the encoder BPTT (the
   // long latency-bound chain) starts right after dq instead of behind ~40 launches.
   HIPC(hipEventRecord(ctx->evW, st));
+  // Where the grouped Linear weight-gradient GEMMs run.  Two MFMA-bound kernels side by side share one
+  // matrix pipe: the round-3 timeline shows the mult group's GEMM (943 us beside the bulk stream, ~500
+  // alone) and the conv weight gradient it overlaps (827 us instead of ~450) each at about half their
+  // stand-alone rate, i.e. nothing is gained by overlapping them, and the recurrence's kernels then
+  // compete with two heavy kernels instead of one.  Where the bulk stream is the longer path (f32 step,
+  // more than 64 samples) the mult group's GEMM therefore goes to the END of the bulk stream, behind the
+  // last conv gradient (round 4: 9.43 -> 9.38 ms with dgrad_dma.hip; conv_att_dgrad 0.47 -> 0.54 and
+  // conv_att_wgrad 0.57 -> 0.60 of peak in the step).  The encoder group's GEMM (after the BPTT) measured
+  // the same on either stream and stays on the third.  RAU_WG_BULK=<mask> overrides (A/B, DESIGN.md section
+  // 9): 1 = mult group on the bulk stream, 2 = encoder group too.  Not with the side-stream split (the
+  // third stream's split-K workspace would be shared).
+  static const int wg_env = [] { const char* e = std::getenv("RAU_WG_BULK"); return e ? std::atoi(e) : -1; }();
+  const int wg_bulk = side_split(ctx) ? 0 : wg_env >= 0 ? wg_env : (chain_bound(ctx) ? 0 : 1);
   auto mult_wgrads = [&]() -> int {
-    hipStream_t sw = ctx->st3;
+    hipStream_t sw = (wg_bulk & 1) ? ctx->st2 : ctx->st3;
     HIPC(hipStreamWaitEvent(sw, ctx->evW, 0));
     const int rows = HA * B;                 // active hops only
     if (rows == 0) {
@@ -1791,7 +1809,7 @@ int rau_backward(rau_ctx* ctx, const float* hop_w) {
     // behind the BPTT.
     auto enc_wgrads = [&](int t_lo, int t_hi, hipEvent_t ev) -> int {   // tokens t_lo < t <= t_hi
       if (t_hi <= t_lo) return 0;
-      hipStream_t sw = ctx->st3;
+      hipStream_t sw = (wg_bulk & 2) ? ctx->st2 : ctx->st3;
       HIPC(hipEventRecord(ev, st));
       HIPC(hipStreamWaitEvent(sw, ev, 0));
       const size_t r0 = (size_t)t_lo * B;
@@ -1862,6 +1880,7 @@ int rau_backward(rau_ctx* ctx, const float* hop_w) {
   }
   HIPC(hipEventRecord(ctx->evW3, ctx->st3));
   HIPC(hipStreamWaitEvent(st, ctx->evW3, 0));
+  if (wg_bulk) HIPC(hipEventRecord(ctx->evD, ctx->st2));   // the bulk stream got weight-gradient work behind its convs
   HIPC(hipStreamWaitEvent(st, ctx->evD, 0));  // join: every gradient is ordered on st
   HIPC(hipEventRecord(ctx->evEnd, st));
   ctx->bwd_done = true;

@@ -135,10 +135,19 @@ int main(int argc, char** argv) {
       CK(hipStreamSynchronize(st));
       compare("dZ: wide vs round-2 per-sample", Z1, Z0, (size_t)nB * M * S);
       compare("row sums", r1, r0, (size_t)nB * M);
+      if (dgrad_dma_ok(M, A, S, M)) {   // round 4: per-sample tiles fed by LDS-DMA (dgrad_dma.hip)
+        CK(hipMemset(Z1, 0xdd, (size_t)nB * M * S * 4)); CK(hipMemset(r1, 0xdd, (size_t)nB * M * 4));
+        CK(dgrad_dma(st, nB, M, A, S, Wp, M, dS, (long)A * S, Z1, (long)M * S, dj, av, I, r1));
+        CK(hipStreamSynchronize(st));
+        compare("dZ: dgrad_dma vs round-2 per-sample", Z1, Z0, (size_t)nB * M * S);
+        compare("row sums (dgrad_dma)", r1, r0, (size_t)nB * M);
+      }
       for (int rep = 0; rep < 2; ++rep) {
         report("round-2 per-sample 128x208", timeit(st, 10, [&] { return conv_sample(st, 2, nB, M, A, S, Wp, M, dS, (long)A * S, Z0, (long)M * S, nullptr, 0, dj, av, I, r0, 0); }), fl);
         report("wide 64x784, 2 per CU", timeit(st, 10, [&] { return conv_wide(st, 2, nB, M, A, S, Wp, M, dS, (long)A * S, Z1, (long)M * S, nullptr, 0, dj, av, I, r1, 0, 2); }), fl);
         report("wide 64x784, 1 per CU", timeit(st, 10, [&] { return conv_wide(st, 2, nB, M, A, S, Wp, M, dS, (long)A * S, Z1, (long)M * S, nullptr, 0, dj, av, I, r1, 0, 1); }), fl);
+        if (dgrad_dma_ok(M, A, S, M))
+          report("dgrad_dma per-sample 128x208 (RAU_DGRAD_DMA=2|3: ring depth)", timeit(st, 10, [&] { return dgrad_dma(st, nB, M, A, S, Wp, M, dS, (long)A * S, Z1, (long)M * S, dj, av, I, r1); }), fl);
       }
       CK(hipFree(dS)); CK(hipFree(Wp)); CK(hipFree(dj)); CK(hipFree(av)); CK(hipFree(I));
       CK(hipFree(Z0)); CK(hipFree(Z1)); CK(hipFree(r0)); CK(hipFree(r1));
