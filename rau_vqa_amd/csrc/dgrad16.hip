@@ -14,8 +14,10 @@
 // Tiling = gemm_sample.hip's: 128 rows x ALL positions of ONE sample per workgroup (1024 tiles per
 // hop at M = 512, B = 256; whole 784-byte rows of dS in, one contiguous block of dZ out), 4 waves x
 // (32 rows x 208 columns = 2 x 13 accumulator blocks).  K-step 32: an LDS element is the 16-byte
-// k-octet {k .. k+7} of one position (X image [4][208]) or one row (W image [4][128]), which is exactly
-// one lane's MFMA operand (lane l: position / row l & 15, octet l >> 4), read with ds_read_b128.
+// k-octet {k .. k+7} of one position (X image, 4 octets x 208) or one row (W image, 4 x 128 + padding), which
+// is exactly one lane's MFMA operand (lane l: position / row l & 15, octet l >> 4), read with ds_read_b128;
+// within an octet the elements are quad-planar (see GXQ below) so that the staging stores and the fragment
+// reads are both free of bank conflicts.
 // Both sources are k-major in memory ([k][s], [k][m]): a thread loads the same four columns of eight
 // consecutive k rows and transposes in registers.  Two stages, register-staged loads one K-step ahead,
 // one barrier per K-step.
@@ -30,9 +32,22 @@ constexpr int GS = 196, GS4 = GS / 4;          // positions per sample
 constexpr int GNCB = 13, GBN = GNCB * 16;      // 208 columns (12 zero pad columns)
 constexpr int GBM = 128;                       // rows per tile
 constexpr int GBK = 32, GKO = GBK / 8;         // K-step, octets per K-step
-constexpr int GXST = GKO * GBN;                // uint4 elements of the X image (832)
-constexpr int GWST = GKO * GBM;                // of the W image (512)
-constexpr int GSTAGE = GXST + GWST;            // 1344 x 16 B = 21.5 KB
+// LDS images, 16-byte elements (one k-octet of one position / row), QUAD-PLANAR: a staging thread holds
+// four consecutive positions (rows) of one octet, and element (octet ko, position p) sits at
+//   ko * GXP + (p & 3) * GXQ + (p >> 2)
+// so that the 64 lanes of a staging store write CONSECUTIVE 16-byte elements (round 3 stored a thread's
+// four elements side by side: lanes 64 bytes apart, a 4-way bank conflict on every store, 0.50 conflict
+// cycles per LDS cycle in the round-3 counters).  A fragment read takes lanes lr = 0..15 at
+// (lr & 3) * GXQ + 4 j + (lr >> 2): with GXQ = 52 = 4 mod 16 (GWQ = 36 = 4 mod 16) the sixteen lanes of
+// every ds_read_b128 lane group land in sixteen different 16-byte bank groups.
+constexpr int GXQ = GBN / 4;                   // 52 elements per quad plane of the X image
+constexpr int GXP = 4 * GXQ;                   // 208 per octet
+constexpr int GWQ = GBM / 4 + 4;               // 36 per quad plane of the W image (32 + 4: = 4 mod 16)
+constexpr int GWP = 4 * GWQ;                   // 144 per octet
+constexpr int GXST = GKO * GXP;                // uint4 elements of the X image (832)
+constexpr int GWST = GKO * GWP;                // of the W image (576)
+constexpr int GSTAGE = GXST + GWST;            // 1408 x 16 B = 22.5 KB
+static_assert(GXQ % 16 == 4 && GWQ % 16 == 4, "quad-plane pitch: conflict-free ds_read_b128 fragments");
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
@@ -83,10 +98,12 @@ __global__ __launch_bounds__(256, 2) void k_dgrad16(const Dgrad16Params P) {
   const uint16_t* x_ptr16 = Xb16 + (size_t)(8 * x_ko) * GS + 4 * x_q4;
   const float* w_ptr = P.Wt + (size_t)(8 * w_ko) * P.w_rs + m0 + 4 * w_mq;
 
-  // zero the pad columns [196, 208) of both X images once: no load ever writes them
+  // zero the pad positions [196, 208) of both X images once (quads 49..51 of every plane): no load ever
+  // writes them
   for (int e = tid; e < 2 * GKO * (GBN - GS); e += 256) {
     const int st = e / (GKO * (GBN - GS)), r = e % (GKO * (GBN - GS));
-    smem[st * GSTAGE + (r / (GBN - GS)) * GBN + GS + r % (GBN - GS)] = make_uint4(0u, 0u, 0u, 0u);
+    const int ko = r / (GBN - GS), p = GS + r % (GBN - GS);
+    smem[st * GSTAGE + ko * GXP + (p & 3) * GXQ + (p >> 2)] = make_uint4(0u, 0u, 0u, 0u);
   }
 
   f32x4 acc[2][GNCB];
@@ -117,29 +134,31 @@ __global__ __launch_bounds__(256, 2) void k_dgrad16(const Dgrad16Params P) {
   auto store = [&](int stage) {
     uint4* Xs = smem + stage * GSTAGE;
     uint4* Ws = Xs + GXST;
-    if (x_on) {
-      uint4* d = Xs + x_ko * GBN + 4 * x_q4;
+    if (x_on) {   // positions 4 q4 .. 4 q4 + 3 -> quad q4 of planes 0..3
+      uint4* d = Xs + x_ko * GXP + x_q4;
       if (X16) {
-        d[0] = OCTET16(rx16, 0); d[1] = OCTET16(rx16, 1); d[2] = OCTET16(rx16, 2); d[3] = OCTET16(rx16, 3);
+        d[0] = OCTET16(rx16, 0); d[GXQ] = OCTET16(rx16, 1); d[2 * GXQ] = OCTET16(rx16, 2); d[3 * GXQ] = OCTET16(rx16, 3);
       } else {
-        d[0] = OCTET(rx, x); d[1] = OCTET(rx, y); d[2] = OCTET(rx, z); d[3] = OCTET(rx, w);
+        d[0] = OCTET(rx, x); d[GXQ] = OCTET(rx, y); d[2 * GXQ] = OCTET(rx, z); d[3 * GXQ] = OCTET(rx, w);
       }
     }
     if (w_on) {
-      uint4* d = Ws + w_ko * GBM + 4 * w_mq;
-      d[0] = OCTET(rw, x); d[1] = OCTET(rw, y); d[2] = OCTET(rw, z); d[3] = OCTET(rw, w);
+      uint4* d = Ws + w_ko * GWP + w_mq;
+      d[0] = OCTET(rw, x); d[GWQ] = OCTET(rw, y); d[2 * GWQ] = OCTET(rw, z); d[3 * GWQ] = OCTET(rw, w);
     }
   };
   auto compute = [&](int stage) {
-    const uint4* Xs = smem + stage * GSTAGE + lq * GBN + lr;
-    const uint4* Ws = smem + stage * GSTAGE + GXST + lq * GBM + 32 * w + lr;
+    // position 16 j + lr -> plane lr & 3, quad 4 j + (lr >> 2); row 32 w + 16 i + lr -> plane lr & 3,
+    // quad 8 w + 4 i + (lr >> 2)
+    const uint4* Xs = smem + stage * GSTAGE + lq * GXP + (lr & 3) * GXQ + (lr >> 2);
+    const uint4* Ws = smem + stage * GSTAGE + GXST + lq * GWP + (lr & 3) * GWQ + 8 * w + (lr >> 2);
     const bf16x8 a0 = __builtin_bit_cast(bf16x8, Ws[0]);
-    const bf16x8 a1 = __builtin_bit_cast(bf16x8, Ws[16]);
+    const bf16x8 a1 = __builtin_bit_cast(bf16x8, Ws[4]);
 #pragma unroll
     for (int j = 0; j < GNCB; ++j) {
       // dS as the MFMA's A operand, Wp as its B operand: the accumulator block is C^T, a lane's four
       // registers are four CONSECUTIVE positions of one row m (16-byte / 8-byte stores)
-      const bf16x8 xb = __builtin_bit_cast(bf16x8, Xs[16 * j]);
+      const bf16x8 xb = __builtin_bit_cast(bf16x8, Xs[4 * j]);
       acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xb, a0, acc[0][j], 0, 0, 0);
       acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xb, a1, acc[1][j], 0, 0, 0);
     }

@@ -454,6 +454,23 @@ int rau_create(const rau_config* cfg, rau_ctx** out) {
     size_t sl2 = std::max(conv_wgrad_slab_floats(H * B, A, M, S),
                           conv_wgrad_slab_floats(H * B, M, D, S));
     if (ctx->bf16) sl2 = std::max(sl2, wgrad16_slab_floats(H * B, M, D, S));
+    // The grouped Linear weight-gradient GEMMs' partial slabs.  They run on the weight-gradient stream
+    // (slab3) or, where the bulk stream is the longer path, at the END of the bulk stream (rau_backward):
+    // there they take the BULK stream's workspace -- each stream owns its workspace, and two launches that
+    // share one must be ordered by their stream.  (Round 4 first moved the mult group's GEMM to the bulk
+    // stream with slab3 still in its hands while the encoder group's GEMM used slab3 on the third stream:
+    // the two ran concurrently and overwrote each other's partials; tests/test_gpu_att_variants.py caught it.)
+    size_t grp_floats = 0;
+    {
+      TnProblem pr[13];
+      int n = mult_wgrad_problems(ctx, pr);
+      for (int hh = 1; hh <= H; ++hh)
+        grp_floats = std::max(grp_floats, gemm_tn_group_slab_floats(pr, n, hh * B));
+      n = enc_wgrad_problems(ctx, 0, pr);
+      for (int tt = 1; tt <= T; ++tt)
+        grp_floats = std::max(grp_floats, gemm_tn_group_slab_floats(pr, n, tt * B));
+    }
+    sl2 = std::max(sl2, grp_floats);
     CK(dalloc(ctx, &ctx->slab2, sl2));
     ctx->slab2_floats = sl2;
     const int rowsH = H * B, rowsT = T * B;
@@ -468,14 +485,7 @@ int rau_create(const rau_config* cfg, rau_ctx** out) {
     ctx->slab_floats = sl;
     CK(dalloc(ctx, &ctx->slab, sl));
     {  // the weight-gradient stream's workspace also holds the grouped launches' partial slabs
-      TnProblem pr[13];
-      size_t sl3 = sl;
-      int n = mult_wgrad_problems(ctx, pr);
-      for (int hh = 1; hh <= H; ++hh)
-        sl3 = std::max(sl3, gemm_tn_group_slab_floats(pr, n, hh * B));
-      n = enc_wgrad_problems(ctx, 0, pr);
-      for (int tt = 1; tt <= T; ++tt)
-        sl3 = std::max(sl3, gemm_tn_group_slab_floats(pr, n, tt * B));
+      const size_t sl3 = std::max(sl, grp_floats);
       ctx->slab3_floats = sl3;
       CK(dalloc(ctx, &ctx->slab3, sl3));
     }
@@ -1781,15 +1791,18 @@ int rau_backward(rau_ctx* ctx, const float* hop_w) {
       const int np = mult_wgrad_problems(ctx, pr);
       double fl = 0;
       for (int i = 0; i < np; ++i) fl += gflop(pr[i].M, pr[i].N, rows);
-      RUNS(sw, "wgrad_gemm", fl, 0,
-           gemm_tn_group_acc(sw, pr, np, rows, ctx->slab3, ctx->slab3_floats));
+      // the workspace of the stream it runs on
+      float* ws = (wg_bulk & 1) ? ctx->slab2 : ctx->slab3;
+      const size_t ws_floats = (wg_bulk & 1) ? ctx->slab2_floats : ctx->slab3_floats;
+      RUNS(sw, "wgrad_gemm", fl, 0, gemm_tn_group_acc(sw, pr, np, rows, ws, ws_floats));
     }
+    float* ct = (wg_bulk & 1) ? ctx->coltmp2 : ctx->coltmp3;   // the column-sum scratch of the stream it runs on
     // att_score: dws = sum dz T ; dbs = sum dz.  att_i bias: sum dS.  i_embed bias: sum dZ.
-    RUNS(sw, "colsum", 0, (double)rows * A * 4, colsum_acc(sw, rows, A, ctx->dwsp, A, ctx->att_score.dW, ctx->coltmp3));
+    RUNS(sw, "colsum", 0, (double)rows * A * 4, colsum_acc(sw, rows, A, ctx->dwsp, A, ctx->att_score.dW, ct));
     HIPC(hipMemsetAsync(ctx->tmpS, 0, S * sizeof(float), sw));
-    RUNS(sw, "colsum", 0, (double)rows * S * 4, colsum_acc(sw, rows, SL, ctx->dz, S, ctx->tmpS, ctx->coltmp3));
-    RUNS(sw, "colsum", 0, S * 4.0, colsum_acc(sw, SL, 1, ctx->tmpS, 1, ctx->att_score.db, ctx->coltmp3));
-    RUNS(sw, "colsum", 0, (double)rows * A * 4, colsum_acc(sw, rows, A, ctx->du, A, ctx->att_i.db, ctx->coltmp3));
+    RUNS(sw, "colsum", 0, (double)rows * S * 4, colsum_acc(sw, rows, SL, ctx->dz, S, ctx->tmpS, ct));
+    RUNS(sw, "colsum", 0, S * 4.0, colsum_acc(sw, SL, 1, ctx->tmpS, 1, ctx->att_score.db, ct));
+    RUNS(sw, "colsum", 0, (double)rows * A * 4, colsum_acc(sw, rows, A, ctx->du, A, ctx->att_i.db, ct));
     HIPC(hipEventRecord(ctx->evM3, sw));   // with evD: the mult group's gradients are final
     return 0;
   };
@@ -1818,7 +1831,9 @@ int rau_backward(rau_ctx* ctx, const float* hop_w) {
       const int np = enc_wgrad_problems(ctx, r0, pr);
       double fl = 0;
       for (int i = 0; i < np; ++i) fl += gflop(pr[i].M, pr[i].N, nr);
-      RUNS(sw, "wgrad_gemm", fl, 0, gemm_tn_group_acc(sw, pr, np, nr, ctx->slab3, ctx->slab3_floats));
+      float* ws = (wg_bulk & 2) ? ctx->slab2 : ctx->slab3;   // the workspace of the stream it runs on
+      const size_t ws_floats = (wg_bulk & 2) ? ctx->slab2_floats : ctx->slab3_floats;
+      RUNS(sw, "wgrad_gemm", fl, 0, gemm_tn_group_acc(sw, pr, np, nr, ws, ws_floats));
       return 0;
     };
     const int hi = TL;
