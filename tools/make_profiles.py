@@ -72,7 +72,7 @@ def classify(rows):
         for pos, i in enumerate(plain):
             out[i] = ("conv_att_wgrad" if pos % 2 == 0 else "conv_embed_wgrad", None)
     for i, n in enumerate(names):
-        if n.startswith("k_conv_sample<1") or n.startswith("k_conv_sample<2") or \
+        if n.startswith("k_conv_sample<1") or n.startswith("k_conv_sample<2") or n.startswith("k_dgrad_dma") or \
                 n.startswith("k_conv_wide<2>") or n == "gemm_kernel<128, 128, 32, 1, 2, 3, 0>":
             out[i] = ("conv_att_dgrad", None)
     return out

@@ -1,9 +1,10 @@
 #!/bin/bash
 # Runs on the GPU box (gpurun): un-profiled bench line, kernel trace + stats, PMC passes.
 # The program sits directly behind `--` (python3), as the pool requires.
+R="$(cd "$(dirname "$0")/.." && pwd)"
+[ -n "$R" ] && [ -f "$R/bench.py" ] || { echo "cannot locate the repo root from $0" >&2; exit 1; }
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
-cd $R
+cd "$R"
 rm -rf gpurun_out/kt gpurun_out/pmc_f gpurun_out/pmc_w gpurun_out/pmc_sq
 python3 bench.py > gpurun_out/bench_line.json 2> gpurun_out/bench_line.err; echo "bench rc=$?"
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/kt -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-other-configs > gpurun_out/kt.log 2>&1; echo "kt rc=$?"
