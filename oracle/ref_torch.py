@@ -86,6 +86,32 @@ class _Conv1x1BF16(torch.autograd.Function):
         return dx, dW, dy.sum((0, 2)), None
 
 
+class _LinearBF16W(torch.autograd.Function):
+    """y = x W^T + b as librau's RAU_BF16 mode computes a Linear layer (BASELINE.json configs[2]: "bf16 MFMA
+    gate/classifier GEMMs"): the forward product and the input gradient dx = dy W stay exact f32 (the
+    recurrence's latency-bound skinny GEMMs), the WEIGHT gradient dW = dy^T x -- the grouped GEMM over all
+    hops / tokens, where the FLOPs are -- rounds both of its operands to bf16 and accumulates exactly; the
+    bias gradient is the column sum of the unrounded dy."""
+
+    @staticmethod
+    def forward(ctx, x, W, b):
+        ctx.save_for_backward(x, W)
+        return F.linear(x, W, b)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, W = ctx.saved_tensors
+        return dy @ W, _rb(dy).t() @ _rb(x), dy.sum(0)
+
+
+_BF16_LINEAR = False   # set by step(): Linear weight gradients with bf16-rounded operands
+
+
+def _lin(x, W, b):
+    """nn.Linear; in the bf16 emulation its weight gradient rounds its operands (see _LinearBF16W)."""
+    return _LinearBF16W.apply(x, W, b) if _BF16_LINEAR else F.linear(x, W, b)
+
+
 def _conv1x1(x3, W, b, bf16, exact_dx=False):
     """1x1 SpatialConvolution on [B, C, S] (reference SS:240, SS:247)."""
     if bf16:
@@ -111,8 +137,8 @@ def deep_lstm(sh, P, x, state, mask_mid):
         if L == 1:
             inp = _drop(outs[1], mask_mid, sh.p_rnn)
         n = "l%d" % (L + 1)
-        sums = F.linear(inp, P[n + "_i2h.W"], P[n + "_i2h.b"]) + \
-            F.linear(prev_h, P[n + "_h2h.W"], P[n + "_h2h.b"])
+        sums = _lin(inp, P[n + "_i2h.W"], P[n + "_i2h.b"]) + \
+            _lin(prev_h, P[n + "_h2h.W"], P[n + "_h2h.b"])
         sig = torch.sigmoid(sums[:, :3 * Rq])
         in_gate, forget_gate, out_gate = sig[:, :Rq], sig[:, Rq:2 * Rq], sig[:, 2 * Rq:]
         in_transform = torch.tanh(sums[:, 3 * Rq:])
@@ -125,8 +151,8 @@ def deep_lstm(sh, P, x, state, mask_mid):
 def att_lstm(sh, P, x, prev_c, prev_h):
     """model/ATTLSTM.lua:4-28 with one layer and dropout 0."""
     R = sh.R
-    gates = F.linear(x, P["lstm_i2h.W"], P["lstm_i2h.b"]) + \
-        F.linear(prev_h, P["lstm_h2h.W"], P["lstm_h2h.b"])
+    gates = _lin(x, P["lstm_i2h.W"], P["lstm_i2h.b"]) + \
+        _lin(prev_h, P["lstm_h2h.W"], P["lstm_h2h.b"])
     g = gates.view(-1, 4, R)
     in_gate = torch.sigmoid(g[:, 0])
     in_transform = torch.tanh(g[:, 1])
@@ -142,13 +168,13 @@ def multimodal(sh, P, q, feats4d, prev_c, prev_h, mq, mx, mmf, bf16=False):
     bf16=True emulates librau's RAU_BF16 mode on the two 1x1 convolutions."""
     B = q.shape[0]
     # q_embed
-    qf = torch.tanh(F.linear(_drop(q, mq, sh.p_q), P["q_proj.W"], P["q_proj.b"]) +
-                    F.linear(prev_h, P["h_proj.W"], P["h_proj.b"]))
+    qf = torch.tanh(_lin(_drop(q, mq, sh.p_q), P["q_proj.W"], P["q_proj.b"]) +
+                    _lin(prev_h, P["h_proj.W"], P["h_proj.b"]))
     # i_embed: Dropout -> 1x1 conv -> Tanh -> Reshape(M, S)
     xi = _drop(feats4d, mx, sh.p_x)
     ifeat = torch.tanh(_conv1x1(xi.reshape(B, sh.D, sh.S), P["i_embed.W"], P["i_embed.b"], bf16))
     # attbycontent
-    qatt = F.linear(qf, P["att_q.W"], P["att_q.b"]).unsqueeze(2).expand(B, sh.A, sh.S)
+    qatt = _lin(qf, P["att_q.W"], P["att_q.b"]).unsqueeze(2).expand(B, sh.A, sh.S)
     # librau dispatch: per-sample exact-f32 dgrad when 176 < S <= 208 and S % 4 == 0 (gemm_sample.hip)
     iproj = _conv1x1(ifeat, P["att_i.W"], P["att_i.b"], bf16,
                      exact_dx=(sh.S % 4 == 0 and 176 < sh.S <= 208 and sh.M % 4 == 0
@@ -157,15 +183,15 @@ def multimodal(sh, P, q, feats4d, prev_c, prev_h, mq, mx, mmf, bf16=False):
     attscore = F.conv2d(addfeat, P["att_score.W"].view(1, sh.A, 1, 1),
                         P["att_score.b"]).reshape(B, sh.S)
     # attbymemory
-    attprob = torch.softmax(attscore + F.linear(prev_h, P["att_mem.W"], P["att_mem.b"]), dim=1)
+    attprob = torch.softmax(attscore + _lin(prev_h, P["att_mem.W"], P["att_mem.b"]), dim=1)
     # attselect
     attfeat = (ifeat * attprob.unsqueeze(1).expand(B, sh.M, sh.S)).sum(2)
     # classifier
-    join_input = (qf + attfeat) + F.linear(attprob, P["feat_attprob.W"], P["feat_attprob.b"])
+    join_input = (qf + attfeat) + _lin(attprob, P["feat_attprob.W"], P["feat_attprob.b"])
     next_c, next_h = att_lstm(sh, P, join_input, prev_c, prev_h)
-    merge = _drop(join_input + F.linear(next_h, P["lstm_out.W"], P["lstm_out.b"]), mmf, sh.p_mf)
-    score = F.linear(merge, P["cls.W"], P["cls.b"])
-    do_pred = torch.sigmoid(F.linear(merge, P["do_pred.W"], P["do_pred.b"])).sum(1)
+    merge = _drop(join_input + _lin(next_h, P["lstm_out.W"], P["lstm_out.b"]), mmf, sh.p_mf)
+    score = _lin(merge, P["cls.W"], P["cls.b"])
+    do_pred = torch.sigmoid(_lin(merge, P["do_pred.W"], P["do_pred.b"])).sum(1)
     return score, do_pred, attprob, next_c, next_h
 
 
@@ -178,13 +204,15 @@ def step(sh, params, feats, tokens, lens, labels, masks=None, hop_w=None,
     share of the loss (B extra backward passes): the UN-CANCELLED magnitude of every gradient element
     over the batch sum -- the scale a rounding error has to be read against where the sum itself
     nearly cancels (a bias gradient summing dz over a 2-position softmax, whose rows sum to zero)."""
-    global _NUDGE
+    global _NUDGE, _BF16_LINEAR
     _NUDGE = float(bf16_nudge) if bf16 else 0.0
+    _BF16_LINEAR = bool(bf16)
     try:
         return _step(sh, params, feats, tokens, lens, labels, masks, hop_w, backward, dtype, bf16,
                      per_sample_abs)
     finally:
         _NUDGE = 0.0
+        _BF16_LINEAR = False
 
 
 def _step(sh, params, feats, tokens, lens, labels, masks, hop_w, backward, dtype, bf16,

@@ -14,13 +14,6 @@ constexpr int kWave = 64;  // CDNA wavefront width
 // other stream; instruction arbitration on a SIMD is by priority, then age, and the
 // bulk waves are always older.  Chain kernels therefore raise their wave priority.
 #define RAU_CHAIN_PRIO() __builtin_amdgcn_s_setprio(3)
-// the same with the level as a (wave-uniform) kernel argument: s_setprio takes an immediate
-#define RAU_CHAIN_PRIO_ARG(p)                              \
-  do {                                                     \
-    if ((p) == 3) __builtin_amdgcn_s_setprio(3);           \
-    else if ((p) == 2) __builtin_amdgcn_s_setprio(2);      \
-    else if ((p) == 1) __builtin_amdgcn_s_setprio(1);      \
-  } while (0)
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -223,6 +223,12 @@ struct LoadRC {
   template <int NPL>
   __device__ __forceinline__ void store_bf16(uint2* img, int set_stride, int tid, const Regs& R) const {
     if constexpr (K4) {
+      if (CS) {   // column sums of the UNROUNDED values: a Linear's bias gradient stays exact f32
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+          csum.x += R.v[i].x; csum.y += R.v[i].y; csum.z += R.v[i].z; csum.w += R.v[i].w;
+        }
+      }
       const int d = kr * (BT + BPAD) + c4;   // plane kr, columns c4..c4+3
       put_bf16<NPL>(img, d, set_stride, R.v[0].x, R.v[1].x, R.v[2].x, R.v[3].x);
       put_bf16<NPL>(img, d + 1, set_stride, R.v[0].y, R.v[1].y, R.v[2].y, R.v[3].y);
@@ -900,7 +906,7 @@ struct GroupParams {
   int wg0[kGroupMax + 1];
   GroupProb p[kGroupMax];
 };
-template <int BM, int BN, int BKT, int ASRC, int BSRC>
+template <int BM, int BN, int BKT, int ASRC, int BSRC, int DT = 0>
 __global__ __launch_bounds__(256, 2) void gemm_group_kernel(const GroupParams G) {
   int pi = 0;
 #pragma unroll 1
@@ -917,7 +923,7 @@ __global__ __launch_bounds__(256, 2) void gemm_group_kernel(const GroupParams G)
   P.C = q.slab; P.c_rs = q.N; P.slab_stride = (long)q.M * q.N;
   P.rs_out = q.rs_out;
   P.alpha = 1.f;
-  gemm_tile<BM, BN, BKT, ASRC, BSRC, EPI_SLAB, 0>(P, local % tiles, 0, local / tiles);
+  gemm_tile<BM, BN, BKT, ASRC, BSRC, EPI_SLAB, DT>(P, local % tiles, 0, local / tiles);
 }
 
 // ------------------------------------------------------------ host launch

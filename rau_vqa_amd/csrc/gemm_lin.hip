@@ -221,7 +221,7 @@ size_t gemm_tn_slab_floats(int M, int N, int K) {
   return (s > 1 ? (size_t)s * M * N : 0) + (size_t)s * M;
 }
 hipError_t gemm_tn_acc(hipStream_t st, int M, int N, int K, const float* A, long lda,
-                       const float* B, long ldb, float* C, long ldc, float* slab, float* dbias) {
+                       const float* B, long ldb, float* C, long ldc, float* slab, float* dbias, int bf16) {
   LinOpts o;
   o.accumulate = 1;
   const int s = tn_splits(M, N, K);
@@ -230,6 +230,10 @@ hipError_t gemm_tn_acc(hipStream_t st, int M, int N, int K, const float* A, long
   if (s <= 1) {
     GemmParams P = lin_params(M, N, K, A, lda, B, ldb, C, ldc, o);
     P.rs_out = rs;
+    if (bf16)
+      e = dbias ? launch_gemm<128, 128, BK, SRC_RC_SUM, SRC_RC, EPI_LIN, 1>(st, P, 1)
+                : launch_gemm<128, 128, BK, SRC_RC, SRC_RC, EPI_LIN, 1>(st, P, 1);
+    else
     e = dbias ? launch_gemm<128, 128, BK, SRC_RC_SUM, SRC_RC, EPI_LIN>(st, P, 1)
               : launch_gemm<128, 128, BK, SRC_RC, SRC_RC, EPI_LIN>(st, P, 1);
   } else {
@@ -237,6 +241,10 @@ hipError_t gemm_tn_acc(hipStream_t st, int M, int N, int K, const float* A, long
     GemmParams P = lin_params(M, N, K, A, lda, B, ldb, slab, N, o);
     P.slab_stride = (long)M * N;
     P.rs_out = rs;
+    if (bf16)
+      e = dbias ? launch_gemm<128, 128, BK, SRC_RC_SUM, SRC_RC, EPI_SLAB, 1>(st, P, s)
+                : launch_gemm<128, 128, BK, SRC_RC, SRC_RC, EPI_SLAB, 1>(st, P, s);
+    else
     e = dbias ? launch_gemm<128, 128, BK, SRC_RC_SUM, SRC_RC, EPI_SLAB>(st, P, s)
               : launch_gemm<128, 128, BK, SRC_RC, SRC_RC, EPI_SLAB>(st, P, s);
     if (e != hipSuccess) return e;
@@ -315,7 +323,7 @@ __global__ void k_group_reduce_acc(const GroupReduce R) {
 }
 
 hipError_t gemm_tn_group_acc(hipStream_t st, const TnProblem* pr, int np, int K, float* slab,
-                             size_t slab_floats) {
+                             size_t slab_floats, int bf16) {
   if (np < 1 || np > kGroupMax) return hipErrorInvalidValue;
   if (gemm_tn_group_slab_floats(pr, np, K) > slab_floats) return hipErrorInvalidValue;
   const int s = group_splits(pr, np, K);
@@ -344,6 +352,10 @@ hipError_t gemm_tn_group_acc(hipStream_t st, const TnProblem* pr, int np, int K,
     R.b0[i + 1] = R.b0[i] + q.M;
   }
   G.wg0[np] = wg;
+  if (bf16)   // RAU_BF16 mode: both operands rounded to bf16 while staged, f32 accumulate; bias sums stay f32
+    hipLaunchKernelGGL((gemm_group_kernel<128, 128, BK, SRC_RC_SUM, SRC_RC, 1>), dim3(wg), dim3(256), 0,
+                       st, G);
+  else
   hipLaunchKernelGGL((gemm_group_kernel<128, 128, BK, SRC_RC_SUM, SRC_RC>), dim3(wg), dim3(256), 0,
                      st, G);
   hipError_t e = hipGetLastError();

@@ -17,12 +17,6 @@ void split_ws_register(const float* base, size_t floats);
 void split_ws_unregister(const float* base);
 bool split_span_ok(const float* slab, long nsplit, size_t per_split_floats);
 
-// Wave priority the recurrence's kernels raise themselves to (s_setprio; common.h RAU_CHAIN_PRIO = 3).
-// The launchers that take it per launch (skinny_dma, lstm_fwd_multi) read this thread-local setting:
-// rau_forward lowers it for the encoder's kernels where the bulk stream is the longer path.
-void chain_prio_set(int prio);   // 0..3, calling thread; default 3
-int chain_prio_get();
-
 // ------------------------------------------------------------ GEMM (gemm_lin.hip)
 struct LinOpts {
   const float* bias = nullptr;    // + bias[n]
@@ -69,9 +63,11 @@ hipError_t gemm_nt_hetero_deferred(hipStream_t st, int nb, int M, int K, const f
 // through `slab`, which must hold gemm_tn_slab_floats(M,N,K) floats)
 size_t gemm_tn_slab_floats(int M, int N, int K);
 // dbias (optional): dbias[m] += sum_k A[k, m], from the same pass over A (Linear bias gradient)
+// bf16 != 0 (RAU_BF16 mode; BASELINE.json configs[2]: "bf16 MFMA gate/classifier GEMMs"): both operands
+// rounded to bf16 (RNE) while staged, f32 accumulate; dbias is summed from the UNROUNDED values
 hipError_t gemm_tn_acc(hipStream_t st, int M, int N, int K, const float* A, long lda,
                        const float* B, long ldb, float* C, long ldc, float* slab,
-                       float* dbias = nullptr);
+                       float* dbias = nullptr, int bf16 = 0);
 
 // All the Linear weight gradients of a parameter group as ONE grouped launch (+ one reduction):
 // C_p[M_p,N_p] += A_p[K,M_p]^T B_p[K,N_p], dbias_p[m] += sum_k A_p[k,m]; C_p dense (ldc = N_p).
@@ -80,7 +76,7 @@ struct TnProblem {
 };
 size_t gemm_tn_group_slab_floats(const TnProblem* pr, int np, int K);
 hipError_t gemm_tn_group_acc(hipStream_t st, const TnProblem* pr, int np, int K, float* slab,
-                             size_t slab_floats);
+                             size_t slab_floats, int bf16 = 0);
 
 // ----------------------------------------------------------- conv GEMMs (gemm_conv.hip)
 // I[b,m,s] = tanh(sum_d Wi[m,d] * X'[b,d,s] + bi[m])   (reference SS:238-242; X' is the
@@ -225,7 +221,7 @@ struct LstmFwdCell {
   float* c; long c_rs; float* h; long h_rs; float* tanhc;
   float* drop_out; const uint32_t* mask; size_t mask_e0; float mscale;
 };
-struct LstmFwdCells { int n; LstmFwdCell c[2]; int prio = 3; /* set by the launcher from chain_prio_get() */ };
+struct LstmFwdCells { int n; LstmFwdCell c[2]; };
 hipError_t lstm_fwd_multi(hipStream_t st, int order, int nB, int R, const LstmFwdCells& cells);
 // One LSTM cell step as ONE launch (lstm_fused.hip): recurrent gate GEMM on f32 MFMA with the
 // cell's pointwise half as its epilogue.  Up to two independent cells per launch (the encoder's

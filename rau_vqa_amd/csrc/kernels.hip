@@ -268,7 +268,7 @@ hipError_t lstm_bwd(hipStream_t st, int order, int nB, int R, const float* gates
 // Multi-cell variants (blockIdx.y = cell): same arithmetic as k_lstm_fwd / k_lstm_bwd.
 template <int ORDER>
 __global__ void k_lstm_fwd_multi(int nB, int R, LstmFwdCells cs) {
-  RAU_CHAIN_PRIO_ARG(cs.prio);
+  RAU_CHAIN_PRIO();
   using GS = GateSlots<ORDER>;
   const LstmFwdCell& C = cs.c[blockIdx.y];
   const size_t n = (size_t)nB * R;
@@ -305,13 +305,11 @@ __global__ void k_lstm_fwd_multi(int nB, int R, LstmFwdCells cs) {
     }
   }
 }
-hipError_t lstm_fwd_multi(hipStream_t st, int order, int nB, int R, const LstmFwdCells& cells_in) {
-  if (cells_in.n < 1) return hipSuccess;
-  if (cells_in.n > 2) return hipErrorInvalidValue;
-  for (int i = 0; i < cells_in.n; ++i)
-    if (!split_span_ok(cells_in.c[i].slab, cells_in.c[i].nsplit, (size_t)nB * 4 * R)) return kSplitStateError;
-  LstmFwdCells cells = cells_in;
-  cells.prio = chain_prio_get();
+hipError_t lstm_fwd_multi(hipStream_t st, int order, int nB, int R, const LstmFwdCells& cells) {
+  if (cells.n < 1) return hipSuccess;
+  if (cells.n > 2) return hipErrorInvalidValue;
+  for (int i = 0; i < cells.n; ++i)
+    if (!split_span_ok(cells.c[i].slab, cells.c[i].nsplit, (size_t)nB * 4 * R)) return kSplitStateError;
   const dim3 g(grid_for((size_t)nB * R, 256, 512), cells.n), b(256);
   if (order == GATES_ATT)
     hipLaunchKernelGGL(k_lstm_fwd_multi<GATES_ATT>, g, b, 0, st, nB, R, cells);

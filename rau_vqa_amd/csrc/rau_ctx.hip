@@ -1367,11 +1367,7 @@ int rau_forward(rau_ctx* ctx) {
         }
         RUN("enc_step_fused", fl, 0, lstm_step_fused(st, GATES_DEEP, sp));
       }
-    } else {
-    // RAU_ENC_PRIO=0..3 (A/B): wave priority of the encoder's forward kernels
-    static const int enc_prio = [] { const char* e = std::getenv("RAU_ENC_PRIO"); return e ? std::atoi(e) : 3; }();
-    struct PrioReset { ~PrioReset() { chain_prio_set(3); } } prio_reset;
-    chain_prio_set(enc_prio);
+    } else
     for (int s = 1; s <= TL + 1; ++s) {
       if (s == t_head + 1 && t_head < TL) HIPC(hipStreamWaitEvent(st, ctx->evG, 0));   // G1 rows of token s
       const float* Ap[3];
@@ -1414,7 +1410,6 @@ int rau_forward(rau_ctx* ctx) {
         C2.drop_out = nullptr; C2.mask = nullptr; C2.mask_e0 = 0; C2.mscale = 1.f;
       }
       RUN("lstm_fwd", 0, BRq * 4.0 * 10 * cells.n, lstm_fwd_multi(st, GATES_DEEP, B, Rq, cells));
-    }
     }
   }
   return 0;
@@ -1794,7 +1789,7 @@ int rau_backward(rau_ctx* ctx, const float* hop_w) {
       // the workspace of the stream it runs on
       float* ws = (wg_bulk & 1) ? ctx->slab2 : ctx->slab3;
       const size_t ws_floats = (wg_bulk & 1) ? ctx->slab2_floats : ctx->slab3_floats;
-      RUNS(sw, "wgrad_gemm", fl, 0, gemm_tn_group_acc(sw, pr, np, rows, ws, ws_floats));
+      RUNS(sw, "wgrad_gemm", fl, 0, gemm_tn_group_acc(sw, pr, np, rows, ws, ws_floats, ctx->bf16 == 1));
     }
     float* ct = (wg_bulk & 1) ? ctx->coltmp2 : ctx->coltmp3;   // the column-sum scratch of the stream it runs on
     // att_score: dws = sum dz T ; dbs = sum dz.  att_i bias: sum dS.  i_embed bias: sum dZ.
@@ -1833,7 +1828,7 @@ int rau_backward(rau_ctx* ctx, const float* hop_w) {
       for (int i = 0; i < np; ++i) fl += gflop(pr[i].M, pr[i].N, nr);
       float* ws = (wg_bulk & 2) ? ctx->slab2 : ctx->slab3;   // the workspace of the stream it runs on
       const size_t ws_floats = (wg_bulk & 2) ? ctx->slab2_floats : ctx->slab3_floats;
-      RUNS(sw, "wgrad_gemm", fl, 0, gemm_tn_group_acc(sw, pr, np, nr, ws, ws_floats));
+      RUNS(sw, "wgrad_gemm", fl, 0, gemm_tn_group_acc(sw, pr, np, nr, ws, ws_floats, ctx->bf16 == 1));
       return 0;
     };
     const int hi = TL;

@@ -73,7 +73,7 @@ int lin_wgrad(rau_ctx* ctx, Lin& l, const float* dY, const float* X, long ldx, b
   const int B = ctx->cfg.B;
   RUN("wgrad_gemm", 2.0 * l.out * l.in * B, 0,
       gemm_tn_acc(ctx->st, l.out, l.in, B, dY, ldy ? ldy : l.out, X, ldx, l.dW, l.in, ctx->slab3,
-                  bias ? l.db : nullptr));
+                  bias ? l.db : nullptr, ctx->bf16 == 1));
   return 0;
 }
 // [rows][w_src] -> [rows][w_dst] on the ctx stream (re-pitching of [.., S] tensors)

@@ -55,7 +55,6 @@ struct SkinnyParams {
   int N[3]; long off[3];          // problem p: N[p] columns, partials at slab + off[p] ([split][M][N[p]])
   long lda, ldb;
   float* slab;
-  int prio;                       // wave priority (chain_prio_get() at launch)
 };
 
 template <int OFF>
@@ -115,7 +114,7 @@ __global__ __launch_bounds__(256) void k_skinny_dma(const SkinnyParams P) {
   constexpr int KPART = KT * KBK;       // floats per operand per stage (4 / 8 KB)
   constexpr int KSTAGE = 2 * KPART;
   constexpr int PPR = 4 * NH;           // 16-byte pieces per [row][k] operand row
-  RAU_CHAIN_PRIO_ARG(P.prio);
+  RAU_CHAIN_PRIO();
   __shared__ __attribute__((aligned(16))) float smem[KNST * KSTAGE];
   const int tid = threadIdx.x, l = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -342,7 +341,6 @@ hipError_t skinny_dma(hipStream_t st, bool brc, int nprob, int M, int K, const f
   P.tiles_m = (M + KT - 1) / KT;
   P.tiles_n = (nmax + KT - 1) / KT;
   P.lda = lda; P.ldb = ldb; P.slab = slab;
-  P.prio = chain_prio_get();
   const dim3 grid(nprob * splits * P.tiles_m * P.tiles_n), block(256);
   if (depth == 32) {
     if (brc) hipLaunchKernelGGL((k_skinny_dma<true, 2>), grid, block, 0, st, P);

@@ -49,9 +49,4 @@ bool split_span_ok(const float* slab, long nsplit, size_t per_split) {
   return false;
 }
 
-// ---- per-thread wave priority of the recurrence's kernels (kernels.h)
-static thread_local int g_chain_prio = 3;
-void chain_prio_set(int prio) { g_chain_prio = prio < 0 ? 0 : prio > 3 ? 3 : prio; }
-int chain_prio_get() { return g_chain_prio; }
-
 }  // namespace rau

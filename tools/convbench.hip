@@ -11,6 +11,7 @@
 #include <cmath>
 #include "../rau_vqa_amd/csrc/kernels.h"
 #include "exp_fwd16.h"
+#include "exp_wide2.h"
 using namespace rau;
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1);} } while (0)
@@ -85,7 +86,17 @@ int main(int argc, char** argv) {
       compare("wide(1/CU) vs round-2 kernel", I1, I0, (size_t)nB * M * S);
       CK(hipMemset(I1, 0xff, (size_t)nB * M * S * 4));
       CK(hipStreamSynchronize(st));
+      if (conv_wide2_ok(M, D, S, M)) {   // round 4: 128 rows x two samples (conv_wide2.hip)
+        CK(hipMemset(I1, 0xcc, (size_t)nB * M * S * 4));
+        CK(conv_wide2(st, nB, M, D, S, WiT, M, X, (long)D * S, I1, (long)M * S, bi, 1, 1));
+        CK(hipStreamSynchronize(st));
+        compare("wide2 128x392 vs round-2 kernel", I1, I0, (size_t)nB * M * S);
+      }
       for (int rep = 0; rep < 2; ++rep) {
+        if (conv_wide2_ok(M, D, S, M)) {
+          report("wide2 128x392, 1 per CU", timeit(st, 10, [&] { return conv_wide2(st, nB, M, D, S, WiT, M, X, (long)D * S, I1, (long)M * S, bi, 1, 1); }), fl);
+          report("wide2 128x392, 2 per CU", timeit(st, 10, [&] { return conv_wide2(st, nB, M, D, S, WiT, M, X, (long)D * S, I1, (long)M * S, bi, 1, 2); }), fl);
+        }
         report("round-2 flattened 128x128", timeit(st, 10, [&] { return conv_embed_fwd(st, nB, D, S, M, X, WiT, bi, I0, 0, 0); }), fl);
         report("round-2 per-sample 128x208", timeit(st, 10, [&] { return conv_sample(st, 0, nB, M, D, S, WiT, M, X, (long)D * S, I0, (long)M * S, bi, 1, nullptr, nullptr); }), fl);
         report("wide 64x784, 2 per CU", timeit(st, 10, [&] { return conv_wide(st, 0, nB, M, D, S, WiT, M, X, (long)D * S, I1, (long)M * S, bi, 1, nullptr, nullptr, nullptr, nullptr, 0, 2); }), fl);
@@ -108,7 +119,17 @@ int main(int argc, char** argv) {
       CK(conv_wide(st, 0, nB, A, M, S, WpT, A, I, (long)M * S, P1, (long)A * S, bp, 0, nullptr, nullptr, nullptr, nullptr, 0, 2));
       CK(hipStreamSynchronize(st));
       compare("wide vs round-2 kernel", P1, P0, (size_t)nB * A * S);
+      if (conv_wide2_ok(A, M, S, A)) {
+        CK(hipMemset(P1, 0xcc, (size_t)nB * A * S * 4));
+        CK(conv_wide2(st, nB, A, M, S, WpT, A, I, (long)M * S, P1, (long)A * S, bp, 0, 1));
+        CK(hipStreamSynchronize(st));
+        compare("wide2 128x392 vs round-2 kernel", P1, P0, (size_t)nB * A * S);
+      }
       for (int rep = 0; rep < 2; ++rep) {
+        if (conv_wide2_ok(A, M, S, A)) {
+          report("wide2 128x392, 1 per CU", timeit(st, 10, [&] { return conv_wide2(st, nB, A, M, S, WpT, A, I, (long)M * S, P1, (long)A * S, bp, 0, 1); }), fl);
+          report("wide2 128x392, 2 per CU", timeit(st, 10, [&] { return conv_wide2(st, nB, A, M, S, WpT, A, I, (long)M * S, P1, (long)A * S, bp, 0, 2); }), fl);
+        }
         report("round-2 flattened 128x128", timeit(st, 10, [&] { return conv_att_pre(st, nB, M, S, A, I, WpT, bp, P0, 0, 0); }), fl);
         report("wide 64x784, 2 per CU", timeit(st, 10, [&] { return conv_wide(st, 0, nB, A, M, S, WpT, A, I, (long)M * S, P1, (long)A * S, bp, 0, nullptr, nullptr, nullptr, nullptr, 0, 2); }), fl);
         report("wide 64x784, 1 per CU", timeit(st, 10, [&] { return conv_wide(st, 0, nB, A, M, S, WpT, A, I, (long)M * S, P1, (long)A * S, bp, 0, nullptr, nullptr, nullptr, nullptr, 0, 1); }), fl);
