@@ -64,10 +64,23 @@ __device__ __forceinline__ void lds_read32(float& dst, uint32_t addr) {
   asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF) : "memory");
 }
 
-__global__ __launch_bounds__(256, 2) void k_wgrad_dma(const WgradParams P) {
-  __shared__ __attribute__((aligned(16))) float smem[GNST * GSTAGE];
+// NG = wave groups per workgroup.  NG = 1: four waves, two workgroups per CU (round 3).  NG = 2 (round 4):
+// EIGHT waves = two groups of four that split the workgroup's K range between them (group g takes the
+// stages g, g + 2, ..: the same stage count up to one, one barrier per stage for all eight waves), each with
+// its own two-stage ring and its own 128 x 128 accumulators; at the end group 1 hands its accumulators to
+// group 0 through its ring's LDS and group 0 writes ONE partial tile.  Same waves per SIMD, registers and
+// LDS per CU as two 4-wave workgroups -- and half the split-K partials: 64 splits x 8 tiles of the
+// attention weight gradient were 34 MB of slab writes + reads per launch for a 0.5 MB result (HBM bytes
+// 1.26x the algorithmic ones in the round-3/4 PMC passes), and the reduction kernel behind every launch
+// sums half as many.  The partials are still summed in a fixed order: deterministic.
+template <int NG>
+__global__ __launch_bounds__(256 * NG, 2) void k_wgrad_dma(const WgradParams P) {
+  __shared__ __attribute__((aligned(16))) float smem_all[NG * GNST * GSTAGE];
   const int tid = threadIdx.x, l = tid & 63;
-  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = NG == 1 ? 0 : wv >> 2;       // wave group
+  const int w = wv & 3;                        // wave within its group
+  float* smem = smem_all + grp * (GNST * GSTAGE);
   const int wm = w & 1, wn = w >> 1;
   // a K split's tiles sit on one XCD (they stream the same samples): workgroup L -> XCD r = L % 8,
   // q = L / 8, split = r + 8 (q / tiles), tile = q % tiles
@@ -79,7 +92,9 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_dma(const WgradParams P) {
   const int b_lo = split * P.spb;
   int b_hi = b_lo + P.spb;
   if (b_hi > P.nB) b_hi = P.nB;
-  const int nst = (b_hi - b_lo) * GNCH;
+  const int nst_all = (b_hi - b_lo) * GNCH;            // stages of this workgroup's K range
+  const int nst = (nst_all - grp + NG - 1) / NG;       // ... of this wave group: grp, grp + NG, ..
+  const int nloop = (nst_all + NG - 1) / NG;           // barrier rounds (the same for every wave)
 
   // ---- DMA slots: instruction i = w + 4 n (n = 0..6) of the stage's 28; i < 14: operand A pieces
   // [64 i, 64 i + 64), else operand B.  Piece p of a part = (row p / 7, 16-byte column p % 7).
@@ -96,11 +111,12 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_dma(const WgradParams P) {
   // MFMA groups of the stage before (a burst of seven costs the issuing wave 400-700 cycles)
   const char *ap = nullptr, *bp = nullptr;
   float* dst = nullptr;
-  auto stage_ptrs = [&](int s) {
+  auto stage_ptrs = [&](int sg) {            // sg: the group's own stage counter
+    const int s = NG * sg + grp;
     const int sb = s / GNCH, ch = s - sb * GNCH;
     ap = a0 + ((size_t)sb * P.a_bs + ch * GCH) * 4;
     bp = b0 + ((size_t)sb * P.b_bs + ch * GCH) * 4;
-    dst = smem + (s & 1) * GSTAGE;
+    dst = smem + (sg & 1) * GSTAGE;
   };
   auto issue_slot = [&](int n) {
     const int i = w + 4 * n;
@@ -132,9 +148,10 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_dma(const WgradParams P) {
     for (int n = 0; n < 7; ++n) issue_slot(n);
   }
 #pragma unroll 1
-  for (int s = 0; s < nst; ++s) {
+  for (int s = 0; s < nloop; ++s) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of stage s has landed
     __builtin_amdgcn_s_barrier();                      // everyone's has; everyone is done with stage s-1
+    if (NG > 1 && s >= nst) continue;                  // the shorter group's last round: barrier only
     const bool more = s + 1 < nst;
     if (more) stage_ptrs(s + 1);
     const uint32_t so = (uint32_t)((s & 1) * GSTAGE) * 4;
@@ -198,6 +215,29 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_dma(const WgradParams P) {
     __builtin_amdgcn_sched_barrier(0);
   }
 
+  // ---- NG = 2: group 1's accumulators to group 0 through LDS, lane-linear: 4 waves x 16 blocks x 64 lanes x
+  // 16 bytes = 64 KB, more than one ring (56 KB), so the exchange area starts at the workgroup's LDS base and
+  // runs into the second ring (nobody reads a ring after the barrier; no DMA is in flight)
+  if (NG > 1) {
+    static_assert(NG == 1 || (size_t)4 * 16 * 64 * 16 <= (size_t)NG * GNST * GSTAGE * 4, "exchange area fits");
+    __builtin_amdgcn_s_barrier();
+    f32x4* xch = reinterpret_cast<f32x4*>(smem_all);
+    if (grp == 1) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) xch[((w * 16 + i * 4 + j) << 6) + l] = acc[i][j];
+    }
+    __syncthreads();
+    if (grp == 1) return;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const f32x4 o = xch[((w * 16 + i * 4 + j) << 6) + l];
+        acc[i][j][0] += o[0]; acc[i][j][1] += o[1]; acc[i][j][2] += o[2]; acc[i][j][3] += o[3];
+      }
+  }
   // ---- partial tile to this split's slab: block (i, j), register r = C[ra0 + 4 g + r][rb0 + row]
   float* C = P.slab + (size_t)split * P.ra * P.rb;
 #pragma unroll
@@ -231,8 +271,24 @@ hipError_t wgrad_dma(hipStream_t st, int nB, int ra, int rb, int S, const float*
   P.spb = (nB + splits - 1) / splits;
   P.splits = (nB + P.spb - 1) / P.spb;
   P.A = A; P.a_bs = a_bs; P.B = B; P.b_bs = b_bs; P.slab = slab;
-  const dim3 grid(8 * ((P.splits + 7) / 8) * P.tiles_a * P.tiles_b), block(256);
-  hipLaunchKernelGGL(k_wgrad_dma, grid, block, 0, st, P);   // two per CU (one per CU measured 10.23 vs 9.70 ms/step)
+  // Wave groups per workgroup.  Two (eight waves, half the K splits, one workgroup per CU by LDS) where the
+  // output is FEW tiles and the split-K partials dominate the kernel's HBM bytes: the attention weight
+  // gradient (8 tiles: 1.26x -> 1.13x of the algorithmic bytes, time unchanged: 0.607 vs 0.601 of peak in the
+  // step).  One for the i_embed weight gradient (16 tiles, 1.12x): there the eight waves on one barrier
+  // measured slower (0.69-0.75 vs 0.73-0.79 of peak alone, 0.67 vs 0.72 in the step, step 9.45-9.51 vs
+  // 9.37-9.39 ms).  RAU_WGRAD_GROUPS=1|2 forces either form for both (A/B).
+  static const int genv = [] { const char* e = std::getenv("RAU_WGRAD_GROUPS"); return e ? std::atoi(e) : 0; }();
+  const int groups = genv == 1 || genv == 2 ? genv : (P.tiles_a * P.tiles_b <= 8 ? 2 : 1);
+  if (groups == 2 && splits >= 2) {
+    const int s2 = (splits + 1) / 2;
+    P.spb = (nB + s2 - 1) / s2;
+    P.splits = (nB + P.spb - 1) / P.spb;
+    const dim3 grid(8 * ((P.splits + 7) / 8) * P.tiles_a * P.tiles_b);
+    hipLaunchKernelGGL(k_wgrad_dma<2>, grid, dim3(512), 0, st, P);
+  } else {
+    const dim3 grid(8 * ((P.splits + 7) / 8) * P.tiles_a * P.tiles_b);
+    hipLaunchKernelGGL(k_wgrad_dma<1>, grid, dim3(256), 0, st, P);   // two per CU (one per CU measured 10.23 vs 9.70 ms/step)
+  }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   return splitk_reduce_acc(st, (size_t)ra * rb, P.splits, slab, (size_t)ra * rb, dW);

@@ -23,6 +23,12 @@ KNOBS = [
     ({"RAU_ATT_DMA_OFF": "1"}, 72, ""),
     ({}, 72, "wg"),                                             # LDS-DMA f32 conv weight gradients on ...
     ({"RAU_WGRAD_DMA_OFF": "1"}, 72, "wg"),                     # ... and off (register-staged tile)
+    ({"RAU_DGRAD_DMA": "0"}, 72, "wg"),                         # f32 attention dgrad: register-staged per-sample kernel
+    ({"RAU_DGRAD_DMA": "2"}, 72, "wg"),                         # ... dgrad_dma.hip with a ring of two stages (default three)
+    ({"RAU_WG_BULK": "0"}, 72, "wg"),                           # grouped Linear weight gradients on the third stream ...
+    ({"RAU_WG_BULK": "3"}, 72, "wg"),                           # ... and both groups at the end of the bulk stream
+    ({"RAU_WGRAD_GROUPS": "1"}, 72, "wg"),                      # conv weight gradients: four-wave workgroups for both ...
+    ({"RAU_WGRAD_GROUPS": "2"}, 72, "wg"),                      # ... and the eight-wave (two K groups) form for both
     ({"RAU_SKINNY_DMA_OFF": "1"}, 72, ""),
     ({"BF16": "1"}, 12, "bf16"),                                # bf16 mode, wgrad16.hip on ...
     ({"BF16": "1", "RAU_WGRAD16_OFF": "1"}, 12, "bf16"),        # ... and off (round-2 tile)
