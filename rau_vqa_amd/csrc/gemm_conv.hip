@@ -55,11 +55,14 @@ hipError_t conv_embed_fwd(hipStream_t st, int nB, int D, int S, int M, const flo
   return launch_gemm<128, 128, BK, SRC_RC, SRC_RC_FLAT, EPI_CONV>(st, P, 1, one_per_cu ? 30 * 1024 : 0);
 }
 
-// The forward bf16 tiles are compiled for 128 registers (four could share a CU) but take 8 KB of unused
+// The forward bf16 tiles are compiled for 128 registers (four could share a CU) but take a little unused
 // LDS so that only THREE do: with four the register file is full and every kernel of the recurrence waits
 // for a tile to retire before it can start -- in this mode the forward phase is bound by the encoder
-// (8.43 -> 8.22 ms per step at D = 2048; with 149-register tiles three per CU: 8.75).
-static int b16_fwd_pad() { return 8192; }
+// (8.43 -> 8.22 ms per step at D = 2048; with 149-register tiles three per CU: 8.75).  Round 4: the
+// quad-planar images (gemm_core.h ImgQuads) make a tile's two stages exactly 40 KB = a quarter of the CU, so
+// 1 KB of padding holds the count at three; the round-3 padding of 8 KB on top of that left the recurrence's
+// kernels 13 KB of LDS per CU and cost the step 0.3 ms (7.78-7.81 vs 7.47-7.52).
+static int b16_fwd_pad() { return 1024; }
 hipError_t conv_embed_fwd_b16(hipStream_t st, int nB, int D, int S, int M, const void* X16,
                               const void* WiT16, const float* bi, float* I) {
   GemmParams P{};

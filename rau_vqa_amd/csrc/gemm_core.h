@@ -29,12 +29,36 @@ constexpr int SPAD = 1;
 // ---- bf16-operand mode (rau_dtype RAU_BF16): operands are rounded to bf16 (RNE) while they
 // are staged into LDS, products accumulate in f32 (v_mfma_f32_32x32x16_bf16, 16x the f32 MFMA
 // rate, so these kernels become HBM-bound).  LDS image of a [BT rows][BKT k] operand tile:
-// BKT/4 planes of (BT + BPAD) 8-byte elements, element (p, r) = the four bf16 values
+// BKT/4 planes of 8-byte elements (pitch and in-plane order: Img policies below), element (p, r) = the four bf16 values
 // k = 4p..4p+3 of row r.  A lane's MFMA fragment (8 consecutive k of one row) is two
 // conflict-free ds_read_b64 from planes 2h and 2h+1.
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 constexpr int BPAD = 4;
+// Where element (plane p, row / column c) of a bf16 image sits: p * PITCH + at(c), 8-byte elements.  The
+// LOADER chooses (its staging stores must be free of bank conflicts); the fragment read -- 32 lanes taking
+// 32 consecutive rows of one plane with ds_read_b64 -- is conflict-free under both choices.
+//  * ImgRows: a plane is its rows in order.  For loaders whose 8 lanes of a row write 8 PLANES (reduction
+//    index contiguous in memory: LoadKC, LoadSC, LoadSC16): a 16-lane store group is 8 planes x 2 rows, and
+//    2 * PITCH = 4 (mod 32) dwords spreads it over all 32 banks (round 3 had PITCH = BT + 4: planes p and
+//    p + 4 on the same banks, 0.25 conflict cycles per LDS cycle in the counters).
+//  * ImgQuads: a plane is four quarter-planes, row c at (c & 3) * Q + (c >> 2).  For loaders that hold four
+//    CONSECUTIVE rows of one plane per thread (k-major sources transposed in registers: LoadRC<K4>,
+//    LoadRC16): the lanes of a store then write consecutive elements instead of elements 32 bytes apart (a
+//    2-way conflict on every store: 0.24 in the counters); Q = 8 (mod 32) keeps the read's 32 rows on 32
+//    different bank pairs.
+template <int BT> struct ImgRows {
+  static constexpr int PITCH = BT + 2;
+  static_assert(BT != 128 || (2 * PITCH) % 32 == 4, "8 planes x 2 rows of a store group on 32 different banks");
+  static __device__ __forceinline__ int at(int c) { return c; }
+};
+template <int BT> struct ImgQuads {
+  static constexpr int Q = BT / 4 + 8;
+  static constexpr int PITCH = 4 * Q;
+  static_assert(BT != 128 || Q % 32 == 8, "32 consecutive rows of a fragment read on 32 different bank pairs");
+  // (the bf16 modes only exist for 128-wide tiles; narrower instantiations never use their image)
+  static __device__ __forceinline__ int at(int c) { return (c & 3) * Q + (c >> 2); }
+};
 __device__ __forceinline__ uint2 pack_bf16x4(float a, float b, float c, float d) {
   bf16x4 v;
   v[0] = (__bf16)a; v[1] = (__bf16)b; v[2] = (__bf16)c; v[3] = (__bf16)d;
@@ -112,6 +136,7 @@ struct GemmParams {
 // Operand stored [rows][K], K contiguous.
 template <int BT, int BKT>
 struct LoadKC {
+  using Img = ImgRows<BT>;
   static constexpr int PAD = SPAD;
   static constexpr int LPR = BKT / 4;          // lanes (float4) per row
   static constexpr int RPP = 256 / LPR;        // rows per pass
@@ -155,7 +180,7 @@ struct LoadKC {
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
       const int r = tid / LPR + i * RPP;
-      put_bf16<NPL>(img, (tid % LPR) * (BT + BPAD) + r, set_stride, R.v[i].x, R.v[i].y, R.v[i].z,
+      put_bf16<NPL>(img, (tid % LPR) * Img::PITCH + r, set_stride, R.v[i].x, R.v[i].y, R.v[i].z,
                     R.v[i].w);
     }
   }
@@ -169,6 +194,7 @@ struct LoadKC {
 // its weight-gradient GEMM's dY operand).
 template <int BT, int BKT, bool FLAT, bool K4 = false, bool CS = false>
 struct LoadRC {
+  using Img = ImgQuads<BT>;
   static constexpr int PAD = LPAD;
   static constexpr int CPR = BT / 4;
   static constexpr int RPP = 256 / CPR;
@@ -229,11 +255,11 @@ struct LoadRC {
           csum.x += R.v[i].x; csum.y += R.v[i].y; csum.z += R.v[i].z; csum.w += R.v[i].w;
         }
       }
-      const int d = kr * (BT + BPAD) + c4;   // plane kr, columns c4..c4+3
+      const int d = kr * Img::PITCH + (c4 >> 2);   // plane kr, columns c4..c4+3 = quad c4/4 of the four quarter-planes
       put_bf16<NPL>(img, d, set_stride, R.v[0].x, R.v[1].x, R.v[2].x, R.v[3].x);
-      put_bf16<NPL>(img, d + 1, set_stride, R.v[0].y, R.v[1].y, R.v[2].y, R.v[3].y);
-      put_bf16<NPL>(img, d + 2, set_stride, R.v[0].z, R.v[1].z, R.v[2].z, R.v[3].z);
-      put_bf16<NPL>(img, d + 3, set_stride, R.v[0].w, R.v[1].w, R.v[2].w, R.v[3].w);
+      put_bf16<NPL>(img, d + Img::Q, set_stride, R.v[0].y, R.v[1].y, R.v[2].y, R.v[3].y);
+      put_bf16<NPL>(img, d + 2 * Img::Q, set_stride, R.v[0].z, R.v[1].z, R.v[2].z, R.v[3].z);
+      put_bf16<NPL>(img, d + 3 * Img::Q, set_stride, R.v[0].w, R.v[1].w, R.v[2].w, R.v[3].w);
     }
   }
 };
@@ -246,6 +272,7 @@ struct LoadRC {
 // layout (gradient through tanh applied while staging, at LDS-store time).
 template <int BT, int BKT, bool DT = false>
 struct LoadSC {
+  using Img = ImgRows<BT>;
   static constexpr int PAD = SPAD;
   static constexpr int LPR = 8;
   static constexpr int RPP = 256 / LPR;
@@ -332,7 +359,7 @@ struct LoadSC {
         x.w *= (1.f - R.y[i].w * R.y[i].w);
         rsum[i] += (x.x + x.y) + (x.z + x.w);
       }
-      put_bf16<NPL>(img, (kc >> 2) * (BT + BPAD) + r, set_stride, x.x, x.y, x.z, x.w);
+      put_bf16<NPL>(img, (kc >> 2) * Img::PITCH + r, set_stride, x.x, x.y, x.z, x.w);
     }
   }
 };
@@ -343,6 +370,7 @@ struct LoadSC {
 // (two v_perm_b32 per element), the sample-chunk form stores what it loaded.
 template <int BT, int BKT, bool FLAT = true>
 struct LoadRC16 {
+  using Img = ImgQuads<BT>;
   static constexpr int PAD = LPAD;
   static constexpr int CPR = BT / 4;
   static constexpr int RPP = 256 / CPR;
@@ -379,19 +407,20 @@ struct LoadRC16 {
   __device__ __forceinline__ void store_bf16(uint2* img, int, int, const Regs& R) const {
     static_assert(NPL == 1, "stored-bf16 operands exist in RAU_BF16 mode only");
     constexpr uint32_t LO = 0x05040100u, HI = 0x07060302u;   // (src1.lo16 | src0.lo16 << 16), same of hi16
-    const int d = kr * (BT + BPAD) + c4;   // plane kr, columns c4..c4+3
+    const int d = kr * Img::PITCH + (c4 >> 2);   // plane kr, columns c4..c4+3 = quad c4/4 of the four quarter-planes
     img[d] = make_uint2(__builtin_amdgcn_perm(R.v[1].x, R.v[0].x, LO),
                         __builtin_amdgcn_perm(R.v[3].x, R.v[2].x, LO));
-    img[d + 1] = make_uint2(__builtin_amdgcn_perm(R.v[1].x, R.v[0].x, HI),
-                            __builtin_amdgcn_perm(R.v[3].x, R.v[2].x, HI));
-    img[d + 2] = make_uint2(__builtin_amdgcn_perm(R.v[1].y, R.v[0].y, LO),
-                            __builtin_amdgcn_perm(R.v[3].y, R.v[2].y, LO));
-    img[d + 3] = make_uint2(__builtin_amdgcn_perm(R.v[1].y, R.v[0].y, HI),
-                            __builtin_amdgcn_perm(R.v[3].y, R.v[2].y, HI));
+    img[d + Img::Q] = make_uint2(__builtin_amdgcn_perm(R.v[1].x, R.v[0].x, HI),
+                                 __builtin_amdgcn_perm(R.v[3].x, R.v[2].x, HI));
+    img[d + 2 * Img::Q] = make_uint2(__builtin_amdgcn_perm(R.v[1].y, R.v[0].y, LO),
+                                     __builtin_amdgcn_perm(R.v[3].y, R.v[2].y, LO));
+    img[d + 3 * Img::Q] = make_uint2(__builtin_amdgcn_perm(R.v[1].y, R.v[0].y, HI),
+                                     __builtin_amdgcn_perm(R.v[3].y, R.v[2].y, HI));
   }
 };
 template <int BT, int BKT>
 struct LoadSC16 {
+  using Img = ImgRows<BT>;
   static constexpr int PAD = SPAD;
   static constexpr int LPR = 8;
   static constexpr int RPP = 256 / LPR;
@@ -432,7 +461,7 @@ struct LoadSC16 {
     static_assert(NPL == 1, "stored-bf16 operands exist in RAU_BF16 mode only");
     if (kc >= BKT) return;
 #pragma unroll
-    for (int i = 0; i < NI; ++i) img[(kc >> 2) * (BT + BPAD) + tid / LPR + i * RPP] = R.v[i];
+    for (int i = 0; i < NI; ++i) img[(kc >> 2) * Img::PITCH + tid / LPR + i * RPP] = R.v[i];
   }
 };
 
@@ -490,8 +519,10 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& P, const int bx, con
   // (split mode: three plane sets per operand = 50.7 KB per stage, so a single stage)
   constexpr int NST = DT == 2 ? 1 : (BM >= 128 ? 2 : 1);
   constexpr int NPL = DT == 2 ? 3 : 1;          // bf16 plane sets per operand (hi | hi, mid, lo)
-  // bf16 modes: BK/4 planes of (BT + BPAD) 8-byte elements per operand, plane set and stage
-  constexpr int PLA = (BM + BPAD) * (BK / 4), PLB = (BN + BPAD) * (BK / 4);   // uint2 per set
+  // bf16 modes: BK/4 planes of Img::PITCH 8-byte elements per operand (the loader's image policy), plane
+  // set and stage
+  constexpr int PPA = LAT::Img::PITCH, PPB = LBT::Img::PITCH;                // uint2 per plane
+  constexpr int PLA = PPA * (BK / 4), PLB = PPB * (BK / 4);                   // uint2 per set
   constexpr int kStage = DT ? 2 * NST * NPL * (PLA + PLB)
                             : NST * BK * LDA + NST * BK * LDB;  // floats of operand staging
   // epilogue scratch lives in the (then idle) staging area: per-row vectors,
@@ -576,8 +607,13 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& P, const int bx, con
   // bf16 mode: per 16-deep k-step, fragment = planes 4s+2h and 4s+2h+1 of the lane's row
   auto compute_bf16 = [&](int cur) {
     const int r = l & 31, h = l >> 5;
-    const uint2* as = Ab16 + cur * NPL * PLA + wm * WM + r;
-    const uint2* bs = Bb16 + cur * NPL * PLB + wn * WN + r;
+    const uint2* as = Ab16 + cur * NPL * PLA;
+    const uint2* bs = Bb16 + cur * NPL * PLB;
+    int ia[IM], jb[JN];   // in-plane index of this lane's row of fragment i / j
+#pragma unroll
+    for (int i = 0; i < IM; ++i) ia[i] = LAT::Img::at(wm * WM + i * 32 + r);
+#pragma unroll
+    for (int j = 0; j < JN; ++j) jb[j] = LBT::Img::at(wn * WN + j * 32 + r);
     if constexpr (DT == 2) {   // split operands: six products per 16-deep k-step
 #pragma unroll
       for (int s = 0; s < BK / 16; ++s) {
@@ -586,14 +622,14 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& P, const int bx, con
         for (int p = 0; p < 3; ++p) {
 #pragma unroll
           for (int i = 0; i < IM; ++i) {
-            const uint2 lo = as[p * PLA + (4 * s + 2 * h) * (BM + BPAD) + i * 32];
-            const uint2 hi = as[p * PLA + (4 * s + 2 * h + 1) * (BM + BPAD) + i * 32];
+            const uint2 lo = as[p * PLA + (4 * s + 2 * h) * PPA + ia[i]];
+            const uint2 hi = as[p * PLA + (4 * s + 2 * h + 1) * PPA + ia[i]];
             a[i][p] = __builtin_bit_cast(bf16x8, make_uint4(lo.x, lo.y, hi.x, hi.y));
           }
 #pragma unroll
           for (int j = 0; j < JN; ++j) {
-            const uint2 lo = bs[p * PLB + (4 * s + 2 * h) * (BN + BPAD) + j * 32];
-            const uint2 hi = bs[p * PLB + (4 * s + 2 * h + 1) * (BN + BPAD) + j * 32];
+            const uint2 lo = bs[p * PLB + (4 * s + 2 * h) * PPB + jb[j]];
+            const uint2 hi = bs[p * PLB + (4 * s + 2 * h + 1) * PPB + jb[j]];
             b[j][p] = __builtin_bit_cast(bf16x8, make_uint4(lo.x, lo.y, hi.x, hi.y));
           }
         }
@@ -616,14 +652,14 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& P, const int bx, con
       bf16x8 a[IM], b[JN];
 #pragma unroll
       for (int i = 0; i < IM; ++i) {
-        const uint2 lo = as[(4 * s + 2 * h) * (BM + BPAD) + i * 32];
-        const uint2 hi = as[(4 * s + 2 * h + 1) * (BM + BPAD) + i * 32];
+        const uint2 lo = as[(4 * s + 2 * h) * PPA + ia[i]];
+        const uint2 hi = as[(4 * s + 2 * h + 1) * PPA + ia[i]];
         a[i] = __builtin_bit_cast(bf16x8, make_uint4(lo.x, lo.y, hi.x, hi.y));
       }
 #pragma unroll
       for (int j = 0; j < JN; ++j) {
-        const uint2 lo = bs[(4 * s + 2 * h) * (BN + BPAD) + j * 32];
-        const uint2 hi = bs[(4 * s + 2 * h + 1) * (BN + BPAD) + j * 32];
+        const uint2 lo = bs[(4 * s + 2 * h) * PPB + jb[j]];
+        const uint2 hi = bs[(4 * s + 2 * h + 1) * PPB + jb[j]];
         b[j] = __builtin_bit_cast(bf16x8, make_uint4(lo.x, lo.y, hi.x, hi.y));
       }
 #pragma unroll
