@@ -42,11 +42,14 @@ constexpr int BPAD = 4;
 //    index contiguous in memory: LoadKC, LoadSC, LoadSC16): a 16-lane store group is 8 planes x 2 rows, and
 //    2 * PITCH = 4 (mod 32) dwords spreads it over all 32 banks (round 3 had PITCH = BT + 4: planes p and
 //    p + 4 on the same banks, 0.25 conflict cycles per LDS cycle in the counters).
-//  * ImgQuads: a plane is four quarter-planes, row c at (c & 3) * Q + (c >> 2).  For loaders that hold four
-//    CONSECUTIVE rows of one plane per thread (k-major sources transposed in registers: LoadRC<K4>,
-//    LoadRC16): the lanes of a store then write consecutive elements instead of elements 32 bytes apart (a
-//    2-way conflict on every store: 0.24 in the counters); Q = 8 (mod 32) keeps the read's 32 rows on 32
-//    different bank pairs.
+//  * ImgQuads: a plane is four quarter-planes, row c in quarter c & 3 at quad (c >> 2) ^ 4 [c & 2].  For
+//    loaders that hold four CONSECUTIVE rows of one plane per thread (k-major sources transposed in
+//    registers: LoadRC<K4>, LoadRC16): the lanes of a store then write 16 consecutive elements (permuted)
+//    instead of elements 32 bytes apart (a 2-way conflict on every store: 0.24 in the counters).  The
+//    fragment read must be conflict-free in BOTH forms hipcc emits it in: ds_read_b64 (32 lanes, 64 banks:
+//    Q = 8 (mod 32) puts the four quarters 16 banks apart) and ds_read2_b64, which it forms from two row
+//    blocks (16-lane groups, 32 banks: quarters 0 / 2 and 1 / 3 would then share banks -- 0.39 conflicts
+//    measured with the plain quad order -- so quarters 2, 3 swap the halves of every group of 8 quads).
 template <int BT> struct ImgRows {
   static constexpr int PITCH = BT + 2;
   static_assert(BT != 128 || (2 * PITCH) % 32 == 4, "8 planes x 2 rows of a store group on 32 different banks");
@@ -57,7 +60,7 @@ template <int BT> struct ImgQuads {
   static constexpr int PITCH = 4 * Q;
   static_assert(BT != 128 || Q % 32 == 8, "32 consecutive rows of a fragment read on 32 different bank pairs");
   // (the bf16 modes only exist for 128-wide tiles; narrower instantiations never use their image)
-  static __device__ __forceinline__ int at(int c) { return (c & 3) * Q + (c >> 2); }
+  static __device__ __forceinline__ int at(int c) { return (c & 3) * Q + ((c >> 2) ^ ((c & 2) << 1)); }
 };
 __device__ __forceinline__ uint2 pack_bf16x4(float a, float b, float c, float d) {
   bf16x4 v;
@@ -255,11 +258,11 @@ struct LoadRC {
           csum.x += R.v[i].x; csum.y += R.v[i].y; csum.z += R.v[i].z; csum.w += R.v[i].w;
         }
       }
-      const int d = kr * Img::PITCH + (c4 >> 2);   // plane kr, columns c4..c4+3 = quad c4/4 of the four quarter-planes
-      put_bf16<NPL>(img, d, set_stride, R.v[0].x, R.v[1].x, R.v[2].x, R.v[3].x);
-      put_bf16<NPL>(img, d + Img::Q, set_stride, R.v[0].y, R.v[1].y, R.v[2].y, R.v[3].y);
-      put_bf16<NPL>(img, d + 2 * Img::Q, set_stride, R.v[0].z, R.v[1].z, R.v[2].z, R.v[3].z);
-      put_bf16<NPL>(img, d + 3 * Img::Q, set_stride, R.v[0].w, R.v[1].w, R.v[2].w, R.v[3].w);
+      const int d = kr * Img::PITCH;   // plane kr; columns c4..c4+3 = quad c4/4 of the four quarter-planes
+      put_bf16<NPL>(img, d + Img::at(c4), set_stride, R.v[0].x, R.v[1].x, R.v[2].x, R.v[3].x);
+      put_bf16<NPL>(img, d + Img::at(c4 + 1), set_stride, R.v[0].y, R.v[1].y, R.v[2].y, R.v[3].y);
+      put_bf16<NPL>(img, d + Img::at(c4 + 2), set_stride, R.v[0].z, R.v[1].z, R.v[2].z, R.v[3].z);
+      put_bf16<NPL>(img, d + Img::at(c4 + 3), set_stride, R.v[0].w, R.v[1].w, R.v[2].w, R.v[3].w);
     }
   }
 };
@@ -407,15 +410,15 @@ struct LoadRC16 {
   __device__ __forceinline__ void store_bf16(uint2* img, int, int, const Regs& R) const {
     static_assert(NPL == 1, "stored-bf16 operands exist in RAU_BF16 mode only");
     constexpr uint32_t LO = 0x05040100u, HI = 0x07060302u;   // (src1.lo16 | src0.lo16 << 16), same of hi16
-    const int d = kr * Img::PITCH + (c4 >> 2);   // plane kr, columns c4..c4+3 = quad c4/4 of the four quarter-planes
-    img[d] = make_uint2(__builtin_amdgcn_perm(R.v[1].x, R.v[0].x, LO),
-                        __builtin_amdgcn_perm(R.v[3].x, R.v[2].x, LO));
-    img[d + Img::Q] = make_uint2(__builtin_amdgcn_perm(R.v[1].x, R.v[0].x, HI),
-                                 __builtin_amdgcn_perm(R.v[3].x, R.v[2].x, HI));
-    img[d + 2 * Img::Q] = make_uint2(__builtin_amdgcn_perm(R.v[1].y, R.v[0].y, LO),
-                                     __builtin_amdgcn_perm(R.v[3].y, R.v[2].y, LO));
-    img[d + 3 * Img::Q] = make_uint2(__builtin_amdgcn_perm(R.v[1].y, R.v[0].y, HI),
-                                     __builtin_amdgcn_perm(R.v[3].y, R.v[2].y, HI));
+    const int d = kr * Img::PITCH;   // plane kr; columns c4..c4+3 = quad c4/4 of the four quarter-planes
+    img[d + Img::at(c4)] = make_uint2(__builtin_amdgcn_perm(R.v[1].x, R.v[0].x, LO),
+                                      __builtin_amdgcn_perm(R.v[3].x, R.v[2].x, LO));
+    img[d + Img::at(c4 + 1)] = make_uint2(__builtin_amdgcn_perm(R.v[1].x, R.v[0].x, HI),
+                                          __builtin_amdgcn_perm(R.v[3].x, R.v[2].x, HI));
+    img[d + Img::at(c4 + 2)] = make_uint2(__builtin_amdgcn_perm(R.v[1].y, R.v[0].y, LO),
+                                          __builtin_amdgcn_perm(R.v[3].y, R.v[2].y, LO));
+    img[d + Img::at(c4 + 3)] = make_uint2(__builtin_amdgcn_perm(R.v[1].y, R.v[0].y, HI),
+                                          __builtin_amdgcn_perm(R.v[3].y, R.v[2].y, HI));
   }
 };
 template <int BT, int BKT>

@@ -341,6 +341,9 @@ hipError_t ce_fwd(hipStream_t st, int nB, int K, int M, const float* logits,
                   int Bper = 0 /* rows are [hop][sample]: samples per hop (label period, 1/B) */);
 hipError_t loss_reduce(hipStream_t st, int H, int nB, const float* lossrow, float* losses);
 hipError_t scale_hops(hipStream_t st, int H, size_t per_hop, const float* w_dev, float* x);
+// x_i[h][0 .. p_i) *= w[h] for three hop-major tensors in one launch
+hipError_t scale_hops3(hipStream_t st, int H, const float* w_dev, size_t p0, float* x0, size_t p1, float* x1,
+                       size_t p2, float* x2);
 hipError_t gather_q(hipStream_t st, int nB, int Rq, int T, const int32_t* lens, const float* c1,
                     const float* h1, const float* c2, const float* h2, float* q);
 hipError_t apply_mask(hipStream_t st, size_t n, size_t period, const float* x,

@@ -1740,6 +1740,24 @@ __global__ void k_scale_hops(size_t per_hop, size_t n, const float* __restrict__
        i += (size_t)gridDim.x * blockDim.x)
     x[i] *= w[i / per_hop];
 }
+// the same for up to three hop-major tensors in one launch: x_i[h][..] *= w[h]
+__global__ void k_scale_hops3(size_t p0, size_t p1, size_t p2, int H, const float* __restrict__ w,
+                              float* __restrict__ x0, float* __restrict__ x1, float* __restrict__ x2) {
+  RAU_CHAIN_PRIO();
+  const size_t n0 = p0 * H, n1 = p1 * H, n2 = p2 * H;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n0 + n1 + n2;
+       i += (size_t)gridDim.x * blockDim.x) {
+    if (i < n0) x0[i] *= w[i / p0];
+    else if (i < n0 + n1) x1[i - n0] *= w[(i - n0) / p1];
+    else x2[i - n0 - n1] *= w[(i - n0 - n1) / p2];
+  }
+}
+hipError_t scale_hops3(hipStream_t st, int H, const float* w_dev, size_t p0, float* x0, size_t p1, float* x1,
+                       size_t p2, float* x2) {
+  hipLaunchKernelGGL(k_scale_hops3, dim3(grid_for((p0 + p1 + p2) * H)), dim3(256), 0, st, p0, p1, p2, H, w_dev,
+                     x0, x1, x2);
+  return hipGetLastError();
+}
 hipError_t scale_hops(hipStream_t st, int H, size_t per_hop, const float* w_dev, float* x) {
   const size_t n = per_hop * H;
   hipLaunchKernelGGL(k_scale_hops, dim3(grid_for(n)), dim3(256), 0, st, per_hop, n, w_dev, x);

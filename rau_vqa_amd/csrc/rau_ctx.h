@@ -140,6 +140,7 @@ struct rau_ctx {
   void* WiT16 = nullptr;  // with xd16: bf16 copies of the transposed conv weights WiT, WpT
   void* WpT16 = nullptr;
   void* dS16 = nullptr;  // with xd16: the attention backward's dS as bf16 [H][B][A][S] (both consumers round it anyway)
+  bool dpre_fwd = false;    // the last forward already formed dpre / dhn of every hop (unscaled by the hop weights)
   bool ds16_step = false;   // set by rau_backward while its hop loop runs: hop_backward writes dS16, not T
   void* xd16 = nullptr;  // RAU_BF16 step path, S % 4 == 0: the same maps stored as bf16 (xd stays unwritten)
   bool I_shared = false;  // evaluate mode: i_embed output is hop-invariant, computed once
@@ -362,6 +363,8 @@ struct HopGrad {
   int dh_part_ns;
   float** dh_part_out;    // non-null: leave dh_prev as partials and report them here
   int* dh_part_ns_out;
+  hipEvent_t ev_conv_ready;  // non-null: recorded on the chain stream right behind att_bwd -- everything the
+                             // bulk stream's conv gradients of this hop read (dS, dj) exists from there on
 };
 __attribute__((visibility("hidden"))) int hop_forward(rau_ctx* ctx, int h, const float* cp,
     const float* hp, float* c_out, float* h_out, const float* Ih, const float* Pin,

@@ -1211,6 +1211,7 @@ int hop_backward(rau_ctx* ctx, int h, const float* cp, const float* Ih, const Ho
         att_bwd_split(st, B, M, A, S, Ih, djh, ah, ctx->slab, ctx->att_score.W, Th, dzh, duh,
                       ctx->dwsp + (size_t)h * B * A, ctx->I_shared ? ctx->P0 : Th,
                       ctx->u + (size_t)h * B * A, ctx->att_part, ns_a, SL, g.da_out));
+  if (g.ev_conv_ready) HIPC(hipEventRecord(g.ev_conv_ready, st));
   const size_t used = (size_t)(dhp - X);
   {  // dh_prev partials #2 = dz Wm
     int ns = 0;
@@ -1252,6 +1253,18 @@ int hop_backward(rau_ctx* ctx, int h, const float* cp, const float* Ih, const Ho
 extern "C" {
 
 // ================================================================ forward
+// The forward / backward seam (the bulk stream and the matrix pipes wait there for the chain).  RAU_SEAM=<mask>
+// (A/B; default 3): 1 = a train-mode forward with labels also forms the backward's two
+// recurrence-free head products (dpre, dhn) behind each group's criterion head on the third stream;
+// 2 = a group's conv gradients start behind att_bwd of its first hop instead of behind the hop's last launch.
+static int seam_mask() {
+  static const int m = [] { const char* e = std::getenv("RAU_SEAM"); return e ? std::atoi(e) : 3; }();
+  return m;
+}
+static bool head_dgrad_fwd(const rau_ctx* ctx) {
+  return ctx->have_labels && ctx->mode == RAU_MODE_TRAIN && (seam_mask() & 1);
+}
+
 int rau_forward(rau_ctx* ctx) {
   NEED(ctx, "null ctx");
   if (!ctx->have_batch) return fail(RAU_ERR_STATE, "rau_forward: no batch (call rau_set_batch)");
@@ -1538,6 +1551,28 @@ int rau_forward(rau_ctx* ctx) {
         if (int rc = hop_forward_head(ctx, ctx->st3, ctx->slab3, reg3, h0,
                                       std::min(head_max, h + 1 - h0), labels))
           return rc;
+      if (head_dgrad_fwd(ctx)) {
+        // The backward's first two products do not depend on the recurrence either: dpre = (dl Wc) (.) mask
+        // and dhn = dpre Wo of these hops follow their criterion head on the same (idle) stream, so the
+        // forward / backward seam -- where the bulk stream and the matrix pipes wait for the chain -- is two
+        // GEMMs shorter.  dl is not yet scaled by the hop weights (they arrive with rau_backward); both
+        // products are linear in it, so rau_backward scales dl, dpre and dhn together.
+        const int nh = h + 1 - gstart;
+        const bool trm = ctx->mode == RAU_MODE_TRAIN;
+        LinOpts o;
+        o.slab = ctx->slab3; o.slab_floats = ctx->slab3_floats;
+        o.emask = (trm && mask_p(ctx, RAU_MASK_MF) > 0.f) ? ctx->mbits[RAU_MASK_MF] : nullptr;
+        o.emask_e0 = (size_t)gstart * BM_;
+        o.emscale = 1.f / (1.f - mask_p(ctx, RAU_MASK_MF));
+        RUNS(ctx->st3, "head_dgrad", 2.0 * nh * B * M * c.K, 0,
+             gemm_nn(ctx->st3, nh * B, M, c.K, ctx->dl + (size_t)gstart * B * c.K, c.K, ctx->cls.W, M,
+                     ctx->dpre + (size_t)gstart * BM_, M, o));
+        LinOpts o2;
+        o2.slab = ctx->slab3; o2.slab_floats = ctx->slab3_floats;
+        RUNS(ctx->st3, "head_dgrad", 2.0 * nh * B * R * M, 0,
+             gemm_nn(ctx->st3, nh * B, R, M, ctx->dpre + (size_t)gstart * BM_, M, ctx->lstm_out.W, R,
+                     ctx->dhn + (size_t)gstart * BR_, R, o2));
+      }
       gstart = h + 1;
     }
   }
@@ -1546,6 +1581,7 @@ int rau_forward(rau_ctx* ctx) {
   if (ctx->have_labels)
     RUN("loss_reduce", 0, 0, loss_reduce(st, H, B, ctx->lossrow, ctx->losses_d));
   ctx->fwd_done = true;
+  ctx->dpre_fwd = head_dgrad_fwd(ctx);
   return RAU_OK;
 }
 
@@ -1601,7 +1637,11 @@ int rau_backward(rau_ctx* ctx, const float* hop_w) {
   if (!ctx->capturing) {  // (rau_graph_step uploads the weights before it launches the graph)
     if (int rc = upload_hop_weights(ctx, hop_w)) return rc;
   }
-  RUN("scale_hops", 0, (double)H * B * K * 8, scale_hops(st, H, (size_t)B * K, ctx->hopw_d, ctx->dl));
+  if (ctx->dpre_fwd)   // the forward formed dpre / dhn from the unscaled dl: scale all three
+    RUN("scale_hops", 0, (double)H * B * (K + M + R) * 8,
+        scale_hops3(st, H, ctx->hopw_d, (size_t)B * K, ctx->dl, (size_t)B * M, ctx->dpre, (size_t)B * R, ctx->dhn));
+  else
+    RUN("scale_hops", 0, (double)H * B * K * 8, scale_hops(st, H, (size_t)B * K, ctx->hopw_d, ctx->dl));
 
   // Hops behind the last one with a non-zero loss weight receive no gradient at all (zero
   // criterion gradient, zero recurrent gradient: Full/ResNet late-epoch gating, Full:587-589):
@@ -1613,7 +1653,7 @@ int rau_backward(rau_ctx* ctx, const float* hop_w) {
   // ---------------- RAU BPTT, SS:561-578
   // Off the recurrence: dpre = (dl Wc) (.) mask and dhn = dpre Wo for all active hops at once
   const uint32_t* m_mf = mk(RAU_MASK_MF);
-  if (HA > 0) {
+  if (HA > 0 && !ctx->dpre_fwd) {
     LINOPTS(o);
     o.emask = m_mf;
     o.emask_e0 = 0;
@@ -1647,6 +1687,9 @@ int rau_backward(rau_ctx* ctx, const float* hop_w) {
       g.dh_part_ns = dh_part_ns;
       g.dh_part_out = &dh_part;
       g.dh_part_ns_out = &dh_part_ns;
+      // h is the first hop of its launch group: its conv gradients may start behind att_bwd, three launches
+      // before the hop's backward is over (it matters for the first group: the forward / backward seam)
+      g.ev_conv_ready = (gsz[h] && (seam_mask() & 2)) ? ctx->evK[h] : nullptr;
       if (int rc = hop_backward(ctx, h, ctx->cc + (size_t)h * BR_,
                                 ctx->I + (ctx->I_shared ? 0 : (size_t)h * BM_ * S), g))
         return rc;
@@ -1673,10 +1716,10 @@ int rau_backward(rau_ctx* ctx, const float* hop_w) {
     // SS:579, never formed).  As soon as a hop group's chain is done its conv gradients
     // start on the bulk stream, overlapping the remaining hops and the encoder BPTT:
     // dZ = (Wp^T dS + dj (x) a)(1 - I^2); dWp += dS I^T; dWi += dZ X'^T.
-    if (gsz[h]) {   // h is the first hop of its group: the whole group's chain is done
+    if (gsz[h]) {   // h is the first hop of its group: the whole group's attention backward is done
       hipStream_t sb = ctx->st2;
-      HIPC(hipEventRecord(ctx->evK[h], st));
-      HIPC(hipStreamWaitEvent(sb, ctx->evK[h], 0));
+      if (!(seam_mask() & 2)) HIPC(hipEventRecord(ctx->evK[h], st));
+      HIPC(hipStreamWaitEvent(sb, ctx->evK[h], 0));   // recorded inside hop_backward (ev_conv_ready)
       if (!ctx->I_shared) {
         const int nH = (std::min(h + gsz[h], HA) - h) * B;   // active hops of this group
         const size_t hb = (size_t)h * B;

@@ -1,9 +1,10 @@
 #!/bin/bash
 # Same as profile_round.sh for the configs[2] workload (bf16 operands, D=2048): bench line, kernel trace,
 # SQ counters and HBM traffic.  The program sits directly behind `--` (python3).
+R="$(cd "$(dirname "$0")/.." && pwd)"
+[ -n "$R" ] && [ -f "$R/bench.py" ] || { echo "cannot locate the repo root from $0" >&2; exit 1; }
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
-cd $R
+cd "$R"
 A="--dtype bf16 --D 2048 --variant ResNet --no-cpu-baseline --no-other-configs"
 rm -rf gpurun_out/b16_kt gpurun_out/b16_f gpurun_out/b16_w gpurun_out/b16_sq
 python3 bench.py $A > gpurun_out/b16_bench_line.json 2> gpurun_out/b16_bench_line.err; echo "bench rc=$?"
