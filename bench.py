@@ -243,7 +243,7 @@ def other_config(name, base_cfgd, device_id, *, batch, D, dtype, variant, steps,
                           "batch_per_gpu": cfg.B, "T": cfg.T, "feature_map": fmap, "hops": cfg.H,
                           "hop_weights": variant,
                           "arithmetic": "f32 operands, f32 MFMA accumulate" if dtype == "f32"
-                                        else "bf16-rounded conv-GEMM operands, f32 accumulate; rest f32",
+                                        else "bf16-rounded operands in every conv and Linear GEMM, f32 accumulate; rest f32",
                           "launch": "eager, 3 streams"}}
         out.update(roofline_objects(prof, nprof, dtype, (batch, D, dtype)))
         gf_per_qa = {512: 3.656, 2048: 8.588}.get(D)
@@ -579,7 +579,7 @@ def main():
                            "hop_weights": {"SS": "SS (x nHop)", "MS": "MS (x 1)"}.get(
                                args.variant, f"{args.variant} gating, epoch {args.epoch}"),
                            "arithmetic": "f32 operands, f32 MFMA accumulate" if args.dtype == "f32"
-                                         else "bf16-rounded conv-GEMM operands, f32 accumulate; rest f32",
+                                         else "bf16-rounded operands in every conv and Linear GEMM, f32 accumulate; rest f32",
                            "dropout": "train mode, Philox masks per step and rank",
                            "launch": "hipGraph replay" if args.graph else "eager, 3 streams"},
                 "hop_loss_global": [round(float(x), 5) for x in hop_loss],

@@ -68,12 +68,17 @@ typedef enum rau_mask_site {   /* the five nn.Dropout sites on the path */
 
 typedef enum rau_dtype {
   RAU_F32 = 0,       /* f32 operands, f32 MFMA accumulate (exact fmaf chain) */
-  RAU_BF16 = 1,      /* the five 1x1-conv GEMMs (i_embed, ifeatproj and their gradients: 94-98 %
-                      * of the FLOPs) take bf16-rounded operands with f32 accumulation; all
-                      * tensors in memory, the recurrences, attention and loss stay f32
-                      * (BASELINE.json configs[2]: Ours_ResNet 14x14x2048, bf16 MFMA).  On 14x14
-                      * maps the attention input gradient (K = 256) stays exact f32: four of the
-                      * five GEMMs are rounded. */
+  RAU_BF16 = 1,      /* BASELINE.json configs[2] (Ours_ResNet 14x14x2048, "bf16 MFMA gate/classifier
+                      * GEMMs"): every GEMM on the path takes bf16-rounded operands (round to nearest
+                      * even) with f32 accumulation -- the five 1x1-conv GEMMs (i_embed, ifeatproj and
+                      * their gradients: 94-98 % of the FLOPs) and the three products of every Linear
+                      * layer (LSTM gates, hop projections, classifier: y = x W^T, dx = dy W,
+                      * dW = dy^T x).  Biases, the cell / attention / softmax / loss arithmetic and
+                      * the parameters, states and gradients in memory stay f32; the one-column
+                      * Linears (att_score, out_do_pred) are dot products in f32.  Where the 14x14
+                      * bf16 tiles do not apply (M % 128, A % 32) the attention input gradient stays
+                      * exact f32; the emulating oracle (oracle/ref_torch.py bf16=True) follows the
+                      * same rule. */
   RAU_F32S = 2       /* same five GEMMs with every f32 operand SPLIT into three bf16 terms
                       * (hi + mid + lo = all 24 significand bits) and six bf16 MFMA products per
                       * operand pair, f32 accumulate: f32-grade accuracy (dropped terms <= 2^-24

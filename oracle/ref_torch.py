@@ -18,6 +18,8 @@ experiments/Ours_SS/LstmAttCtrlGradNoiseDontSelect.lua):
 """
 from __future__ import annotations
 
+import contextlib
+
 import torch
 import torch.nn.functional as F
 
@@ -88,27 +90,41 @@ class _Conv1x1BF16(torch.autograd.Function):
 
 class _LinearBF16W(torch.autograd.Function):
     """y = x W^T + b as librau's RAU_BF16 mode computes a Linear layer (BASELINE.json configs[2]: "bf16 MFMA
-    gate/classifier GEMMs"): the forward product and the input gradient dx = dy W stay exact f32 (the
-    recurrence's latency-bound skinny GEMMs), the WEIGHT gradient dW = dy^T x -- the grouped GEMM over all
-    hops / tokens, where the FLOPs are -- rounds both of its operands to bf16 and accumulates exactly; the
-    bias gradient is the column sum of the unrounded dy."""
+    gate/classifier GEMMs"): each of its three products -- forward y = x W^T, input gradient dx = dy W,
+    weight gradient dW = dy^T x -- rounds BOTH of its operands to bf16 (round to nearest even) and
+    accumulates exactly (the device: in f32); the bias is added unrounded and the bias gradient is the
+    column sum of the unrounded dy."""
 
     @staticmethod
     def forward(ctx, x, W, b):
         ctx.save_for_backward(x, W)
-        return F.linear(x, W, b)
+        return F.linear(_rb(x), _rb(W), b)
 
     @staticmethod
     def backward(ctx, dy):
         x, W = ctx.saved_tensors
-        return dy @ W, _rb(dy).t() @ _rb(x), dy.sum(0)
+        dyr = _rb(dy)
+        return dyr @ _rb(W), dyr.t() @ _rb(x), dy.sum(0)
 
 
-_BF16_LINEAR = False   # set by step(): Linear weight gradients with bf16-rounded operands
+_BF16_LINEAR = False   # set by step(): the Linear layers' three products with bf16-rounded operands
+
+
+@contextlib.contextmanager
+def bf16_emulation(nudge=0.0):
+    """The module-granular functions below (deep_lstm, multimodal with bf16=True, ...) and their autograd
+    backward under the RAU_BF16 emulation, outside step(): tests of ONE clone with given inputs."""
+    global _NUDGE, _BF16_LINEAR
+    old = (_NUDGE, _BF16_LINEAR)
+    _NUDGE, _BF16_LINEAR = float(nudge), True
+    try:
+        yield
+    finally:
+        _NUDGE, _BF16_LINEAR = old
 
 
 def _lin(x, W, b):
-    """nn.Linear; in the bf16 emulation its weight gradient rounds its operands (see _LinearBF16W)."""
+    """nn.Linear; in the bf16 emulation its products round their operands (see _LinearBF16W)."""
     return _LinearBF16W.apply(x, W, b) if _BF16_LINEAR else F.linear(x, W, b)
 
 
@@ -191,7 +207,8 @@ def multimodal(sh, P, q, feats4d, prev_c, prev_h, mq, mx, mmf, bf16=False):
     next_c, next_h = att_lstm(sh, P, join_input, prev_c, prev_h)
     merge = _drop(join_input + _lin(next_h, P["lstm_out.W"], P["lstm_out.b"]), mmf, sh.p_mf)
     score = _lin(merge, P["cls.W"], P["cls.b"])
-    do_pred = torch.sigmoid(_lin(merge, P["do_pred.W"], P["do_pred.b"])).sum(1)
+    # (a one-column Linear: a dot product per row in the criterion head's kernel, exact f32 in every dtype)
+    do_pred = torch.sigmoid(F.linear(merge, P["do_pred.W"], P["do_pred.b"])).sum(1)
     return score, do_pred, attprob, next_c, next_h
 
 

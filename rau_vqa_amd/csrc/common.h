@@ -52,4 +52,12 @@ __device__ __forceinline__ int xcd_remap(int id, int nwg) {
   return base + (id >> 3);
 }
 
+// x rounded to bf16 (round to nearest even), as an f32 value: what a bf16 MFMA operand holds.  A product
+// of two such values is exact in f32, so an f32 MFMA on rounded operands and a bf16 MFMA differ only in
+// the order of their f32 additions.
+__device__ __forceinline__ float rb16(float x) { return (float)(__bf16)x; }
+__device__ __forceinline__ float4 rb16(const float4& v) {
+  return make_float4(rb16(v.x), rb16(v.y), rb16(v.z), rb16(v.w));
+}
+
 }  // namespace rau

@@ -97,7 +97,9 @@ __device__ __forceinline__ void wait_counter(unsigned* c, unsigned want, int* er
   }
 }
 
-template <int ORDER, bool KIND_B>
+// BF: both operands of the gate products rounded to bf16 (rau_dtype RAU_BF16, lin_bf16() in kernels.h): the
+// stationary weights once while they are loaded, the h / x2 fragments in registers in front of their MFMAs
+template <int ORDER, bool KIND_B, bool BF>
 __device__ __forceinline__ void enc_ws_body(const EncWsParams& Q, const int wg, float* smem) {
   using GS = GateSlots<ORDER>;
   const int tid = threadIdx.x, l = tid & 63;
@@ -119,7 +121,8 @@ __device__ __forceinline__ void enc_ws_body(const EncWsParams& Q, const int wg, 
     const float* wrow = W + (size_t)(qslot * ER + U0 + uw + u) * ER + 4 * g;
     sfor<32>([&](auto it) {
       constexpr int i = decltype(it)::value;
-      const float4 v = *reinterpret_cast<const float4*>(wrow + 16 * i);
+      float4 v = *reinterpret_cast<const float4*>(wrow + 16 * i);
+      if constexpr (BF) v = rb16(v);
       wreg[4 * i] = v.x; wreg[4 * i + 1] = v.y; wreg[4 * i + 2] = v.z; wreg[4 * i + 3] = v.w;
     });
   }
@@ -233,6 +236,7 @@ __device__ __forceinline__ void enc_ws_body(const EncWsParams& Q, const int wg, 
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
           }
           __builtin_amdgcn_sched_barrier(0);
+          if constexpr (BF) cur = rb16(cur);
           acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.x, wreg[4 * (I0 + ii)], acc0, 0, 0, 0);
           acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.y, wreg[4 * (I0 + ii) + 1], acc1, 0, 0, 0);
           acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.z, wreg[4 * (I0 + ii) + 2], acc0, 0, 0, 0);
@@ -324,13 +328,13 @@ __device__ __forceinline__ void enc_ws_body(const EncWsParams& Q, const int wg, 
   }
 }
 
-template <int ORDER>
+template <int ORDER, bool BF = false>
 __global__ __launch_bounds__(256, 2) void k_enc_ws(const EncWsParams Q) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   RAU_CHAIN_PRIO();
   const int nA = (ER / 16) * Q.P;
-  if ((int)blockIdx.x < nA) enc_ws_body<ORDER, false>(Q, blockIdx.x, smem);
-  else enc_ws_body<ORDER, true>(Q, blockIdx.x - nA, smem);
+  if ((int)blockIdx.x < nA) enc_ws_body<ORDER, false, BF>(Q, blockIdx.x, smem);
+  else enc_ws_body<ORDER, true, BF>(Q, blockIdx.x - nA, smem);
 }
 
 }  // namespace
@@ -345,7 +349,9 @@ int enc_ws_workgroups(int B) { return (ER / 16 + ER / 8) * (B % 32 == 0 ? 2 : 1)
 static hipError_t enc_ws_attr() {
   static const hipError_t err = [] {
     for (const void* f : {reinterpret_cast<const void*>(k_enc_ws<GATES_ATT>),
-                          reinterpret_cast<const void*>(k_enc_ws<GATES_DEEP>)}) {
+                          reinterpret_cast<const void*>(k_enc_ws<GATES_DEEP>),
+                          reinterpret_cast<const void*>(k_enc_ws<GATES_ATT, true>),
+                          reinterpret_cast<const void*>(k_enc_ws<GATES_DEEP, true>)}) {
       const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, ESMEM * 4);
       if (e != hipSuccess) return e;
     }
@@ -385,7 +391,10 @@ hipError_t enc_ws_forward(hipStream_t st, int order, EncWsParams Q) {
   e = hipMemsetAsync(Q.cnt, 0, 16 * sizeof(unsigned), st);
   if (e != hipSuccess) return e;
   const dim3 grid(enc_ws_workgroups(Q.B)), block(256);
-  if (order == GATES_ATT) hipLaunchKernelGGL(k_enc_ws<GATES_ATT>, grid, block, ESMEM * 4, st, Q);
+  if (Q.bf16) {
+    if (order == GATES_ATT) hipLaunchKernelGGL((k_enc_ws<GATES_ATT, true>), grid, block, ESMEM * 4, st, Q);
+    else hipLaunchKernelGGL((k_enc_ws<GATES_DEEP, true>), grid, block, ESMEM * 4, st, Q);
+  } else if (order == GATES_ATT) hipLaunchKernelGGL(k_enc_ws<GATES_ATT>, grid, block, ESMEM * 4, st, Q);
   else hipLaunchKernelGGL(k_enc_ws<GATES_DEEP>, grid, block, ESMEM * 4, st, Q);
   return hipGetLastError();
 }

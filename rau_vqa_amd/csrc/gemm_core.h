@@ -129,10 +129,21 @@ struct GemmParams {
   const float* v1;     // dj [sample][M]
   const float* v2;     // a  [sample][S]
   float* rs_out;       // SC_DTANH A operand: row sums of the staged operand, partial [split][M]
+  int round16;         // f32 tiles: both operands rounded to bf16 while they are staged (lin_bf16(), kernels.h)
   int dbg;             // tools/kbench only: 1 = no global loads in the loop, 2 = no barriers
 };
 
 // ---------------------------------------------------------------- loaders
+// f32 staging registers of a loader rounded to bf16 in place (GemmParams::round16; loaders whose registers
+// are float4: the Linear layers' LoadKC / LoadRC)
+template <typename Regs>
+__device__ __forceinline__ auto round_regs(Regs& R) -> decltype((void)R.v[0].x) {
+  constexpr int n = sizeof(R.v) / sizeof(R.v[0]);
+#pragma unroll
+  for (int i = 0; i < n; ++i) R.v[i] = rb16(R.v[i]);
+}
+__device__ __forceinline__ void round_regs(...) {}
+
 // Every loader: init(...), load(step) global->regs, store(lds) regs->LDS tile
 // [BKT][BT+LPAD].  BKT = K-step per LDS stage.
 
@@ -689,6 +700,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& P, const int bx, con
         LA.template store_bf16<NPL>(Ab16, PLA, tid, ra0);
         LB.template store_bf16<NPL>(Bb16, PLB, tid, rb0);
       } else {
+        if (P.round16) { round_regs(ra0); round_regs(rb0); }
         LA.store(As, tid, ra0);
         LB.store(Bs, tid, rb0);
       }
@@ -708,6 +720,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& P, const int bx, con
           LA.template store_bf16<NPL>(Ab16 + (NST == 2 ? (cur ^ 1) : 0) * NPL * PLA, PLA, tid, ra0);
           LB.template store_bf16<NPL>(Bb16 + (NST == 2 ? (cur ^ 1) : 0) * NPL * PLB, PLB, tid, rb0);
         } else {
+          if (P.round16) { round_regs(ra0); round_regs(rb0); }
           LA.store(As + (NST == 2 ? (cur ^ 1) * BK * LDA : 0), tid, ra0);
           LB.store(Bs + (NST == 2 ? (cur ^ 1) * BK * LDB : 0), tid, rb0);
         }

@@ -29,6 +29,7 @@ static GemmParams lin_params(int M, int N, int K, const float* A, long lda, cons
   P.ymul = o.ymul; P.y_rs = o.y_rs;
   P.emask = o.emask; P.emask_e0 = o.emask_e0; P.emscale = o.emscale;
   P.alpha = o.alpha;
+  P.round16 = lin_bf16();
   return P;
 }
 

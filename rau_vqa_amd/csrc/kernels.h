@@ -167,6 +167,14 @@ int skinny_dma_splits(int M, int K, int tiles_all, size_t cols_all, size_t slab_
 // 16-deep or 32-deep stages (one kernel template; 32-deep needs K % 64 == 0): chosen for the calling
 // thread by skinny_dma_set_deep, which the step-level entry points set from chain_bound() (rau_ctx.h)
 void skinny_dma_set_deep(int on);
+// rau_dtype RAU_BF16 (BASELINE.json configs[2]: "bf16 MFMA gate/classifier GEMMs"): every Linear product
+// of the calling thread's launches -- forward y = x W^T and input gradient dx = dy W through gemm_nt /
+// gemm_nn and their batched forms, whichever kernel serves them -- rounds both operands to bf16 (round to
+// nearest even) and accumulates in f32.  skinny_dma.hip does it with bf16 MFMAs; the register-staged
+// fallback tiles round while staging and keep the f32 MFMA (same products, another summation order).
+// Set at every step-level entry point from the ctx's dtype (set_skinny_policy, rau_ctx.h).
+void lin_set_bf16(int on);
+int lin_bf16();
 hipError_t skinny_dma(hipStream_t st, bool brc, int nprob, int M, int K, const float* const* A,
                       long lda, const float* const* B, long ldb, const int* N, float* slab,
                       const long* off, int splits);
@@ -235,7 +243,7 @@ struct LstmStepSide {
   float* gates; const float* c_prev; float* c; float* h; float* tanhc;
   float* drop_out; const uint32_t* mask; size_t mask_e0; float mscale;
 };
-struct LstmStepParams { int n, B, R; LstmStepSide s[2]; };
+struct LstmStepParams { int n, B, R; LstmStepSide s[2]; int bf16 = 0; /* operands of the gate products rounded to bf16 */ };
 hipError_t lstm_step_fused(hipStream_t st, int order, const LstmStepParams& P);
 // The 2-layer encoder's whole wavefront (TL + 1 steps of the same tiles) in one persistent launch with
 // a grid barrier per step (lstm_fused.hip).  Tensors are time-major [t][B][..]; slot 0 of h1/c1/h2/c2
@@ -251,6 +259,7 @@ struct EncWsParams {
   const float *Wh1, *Wi2, *Wh2, *bi2, *bh2;
   const uint32_t* mask; float mscale;
   unsigned* cnt; int* err;
+  int bf16 = 0;   // operands of the gate products rounded to bf16
 };
 bool enc_ws_ok(int B, int R);
 int enc_ws_workgroups(int B);

@@ -108,14 +108,18 @@ __device__ __forceinline__ bool gate_gemm(const LstmStepParams& P, const LstmSte
     {
       // element k = 4 kq + jj of a chunk goes to k-row (4 jj + kq): MFMA jj of a block then
       // reads rows 4 jj + (l >> 4), i.e. the same k the lane's A float4 component jj carries
-      const float4 vA = sel4(okA && kofW(T, 0) < K, rwA[j]);
-      const float4 vB = sel4(okB && kofW(T, 1) < K, rwB[j]);
+      float4 vA = sel4(okA && kofW(T, 0) < K, rwA[j]);
+      float4 vB = sel4(okB && kofW(T, 1) < K, rwB[j]);
+      if (P.bf16) { vA = rb16(vA); vB = rb16(vB); }
       ldA[0] = vA.x; ldA[4 * FLD] = vA.y; ldA[8 * FLD] = vA.z; ldA[12 * FLD] = vA.w;
       ldB[0] = vB.x; ldB[4 * FLD] = vB.y; ldB[8 * FLD] = vB.z; ldB[12 * FLD] = vB.w;
     }
     float4 a[NA];
 #pragma unroll
-    for (int i = 0; i < NA; ++i) a[i] = sel4(aok && kofA(T, i) < K, ra[j][i]);
+    for (int i = 0; i < NA; ++i) {
+      a[i] = sel4(aok && kofA(T, i) < K, ra[j][i]);
+      if (P.bf16) a[i] = rb16(a[i]);
+    }
     issue(T + FDEPTH, j);
     __syncthreads();
     // all of the step's W fragments first (one LDS latency per step, not one per MFMA pair:

@@ -224,6 +224,7 @@ inline bool side_split(const rau_ctx* ctx) {
 inline void set_skinny_policy(const rau_ctx* ctx) {
   static const int env = [] { const char* e = std::getenv("RAU_SKINNY_DEEP"); return e ? (std::atoi(e) != 0 ? 1 : 0) : -1; }();
   skinny_dma_set_deep(env >= 0 ? env : (chain_bound(ctx) ? 1 : 0));
+  lin_set_bf16(ctx->bf16 == 1);
 }
 inline float mask_p(const rau_ctx* ctx, int site) {
   return ctx->mexplicit[site] ? ctx->mp_exact[site] : ctx->mp[site];

@@ -1334,7 +1334,7 @@ int rau_forward(rau_ctx* ctx) {
     if (ws_path) {
       // both layers, all tokens: one launch, weights resident in registers (enc_ws.hip)
       EncWsParams q{};
-      q.B = B; q.R = Rq; q.TL = TL;
+      q.B = B; q.R = Rq; q.TL = TL; q.bf16 = ctx->bf16 == 1;
       q.G1 = ctx->G1; q.G2 = ctx->G2; q.h1 = ctx->h1; q.c1 = ctx->c1; q.tc1 = ctx->tc1; q.x2 = ctx->x2;
       q.h2 = ctx->h2; q.c2 = ctx->c2; q.tc2 = ctx->tc2;
       q.Wh1 = ctx->h2h[0].W; q.Wi2 = ctx->i2h[1].W; q.Wh2 = ctx->h2h[1].W;
@@ -1349,7 +1349,7 @@ int rau_forward(rau_ctx* ctx) {
       for (int s = 1; s <= TL + 1; ++s) {
         if (s == t_head + 1 && t_head < TL) HIPC(hipStreamWaitEvent(st, ctx->evG, 0));   // G1 rows of token s
         LstmStepParams sp{};
-        sp.B = B; sp.R = Rq;
+        sp.B = B; sp.R = Rq; sp.bf16 = ctx->bf16 == 1;
         double fl = 0;
         if (s <= TL) {  // layer-1 cell t = s: G1[t] + h1[t-1] W_h2h1^T
           LstmStepSide& C1 = sp.s[sp.n++];

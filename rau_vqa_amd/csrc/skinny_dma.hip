@@ -42,6 +42,9 @@ namespace rau {
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* glb_ptr_t;
 
@@ -106,10 +109,30 @@ __device__ __forceinline__ void frags_landed(f32x4 (&af)[2][NH], f32x4 (&bq)[2][
   }
 }
 
+// The 4 NH reduction indices a lane holds of one 16-row block and stage, rounded to bf16 (RNE) and packed
+// as one operand of v_mfma_f32_16x16x{16,32}_bf16.  Both operands of a product hold the same indices in the
+// same order (k = 16 h + 4 (l >> 4) + e at position 4 h + e), which is all the instruction asks for.
+template <int NH>
+__device__ __forceinline__ auto pack_k(const float (&v)[4 * NH]) {
+  if constexpr (NH == 1) {
+    bf16x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = (__bf16)v[e];
+    return o;
+  } else {
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (__bf16)v[e];
+    return o;
+  }
+}
+
 // BRC = false: W stored [N][K] (k contiguous);  true: W stored [K][N] (n contiguous)
 // NH: 16-deep halves per stage (1 or 2)
-template <bool BRC, int NH>
-__global__ __launch_bounds__(256) void k_skinny_dma(const SkinnyParams P) {
+// BF: both operands rounded to bf16 in registers, bf16 MFMA with f32 accumulation (rau_dtype RAU_BF16: the
+//     recurrence's gate / projection GEMMs, BASELINE.json configs[2]); the staging is the f32 one unchanged
+template <bool BRC, int NH, bool BF>
+__global__ __launch_bounds__(256, BF ? 4 : 1) void k_skinny_dma(const SkinnyParams P) {
   constexpr int KBK = 16 * NH;          // K-step per stage
   constexpr int KPART = KT * KBK;       // floats per operand per stage (4 / 8 KB)
   constexpr int KSTAGE = 2 * KPART;
@@ -253,16 +276,41 @@ __global__ __launch_bounds__(256) void k_skinny_dma(const SkinnyParams P) {
     if (issued < nst) issue();
     if (more) read_frags(set ^ 1, (s + 1) & (KNST - 1));
     __builtin_amdgcn_sched_barrier(0);
+    if constexpr (!BF) {
 #pragma unroll
-    for (int h = 0; h < NH; ++h)
+      for (int h = 0; h < NH; ++h)
 #pragma unroll
-      for (int e = 0; e < 4; ++e)
+        for (int e = 0; e < 4; ++e)
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+          for (int i = 0; i < 2; ++i)
 #pragma unroll
-          for (int j = 0; j < 2; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(
-                af[set][i][h][e], BRC ? bs[set][j][4 * h + e] : bq[set][j][h][e], acc[i][j], 0, 0, 0);
+            for (int j = 0; j < 2; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(
+                  af[set][i][h][e], BRC ? bs[set][j][4 * h + e] : bq[set][j][h][e], acc[i][j], 0, 0, 0);
+    } else {
+      float va[2][4 * NH], vb[2][4 * NH];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int h = 0; h < NH; ++h)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            va[i][4 * h + e] = af[set][i][h][e];
+            vb[i][4 * h + e] = BRC ? bs[set][i][4 * h + e] : bq[set][i][h][e];
+          }
+      const auto a0 = pack_k<NH>(va[0]), a1 = pack_k<NH>(va[1]), b0 = pack_k<NH>(vb[0]), b1 = pack_k<NH>(vb[1]);
+      if constexpr (NH == 1) {
+        acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, a0), __builtin_bit_cast(s16x4, b0), acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, a0), __builtin_bit_cast(s16x4, b1), acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, a1), __builtin_bit_cast(s16x4, b0), acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, a1), __builtin_bit_cast(s16x4, b1), acc[1][1], 0, 0, 0);
+      } else {
+        acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b1, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b0, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b1, acc[1][1], 0, 0, 0);
+      }
+    }
     __builtin_amdgcn_sched_barrier(0);
   };
 #pragma unroll 1
@@ -293,7 +341,10 @@ __global__ __launch_bounds__(256) void k_skinny_dma(const SkinnyParams P) {
 // Which form the calling thread's launches take: 32-deep stages where the caller says the recurrence
 // is the longer path and K allows it, else 16-deep stages.
 static thread_local int g_deep = 0;
+static thread_local int g_bf16 = 0;
 void skinny_dma_set_deep(int on) { g_deep = on; }
+void lin_set_bf16(int on) { g_bf16 = on; }
+int lin_bf16() { return g_bf16; }
 static int stage_depth(int K) { return (g_deep && K % 64 == 0) ? 32 : 16; }
 
 bool skinny_dma_ok(int M, int K, long lda, long ldb, bool brc, int nprob, const int* N,
@@ -342,13 +393,20 @@ hipError_t skinny_dma(hipStream_t st, bool brc, int nprob, int M, int K, const f
   P.tiles_n = (nmax + KT - 1) / KT;
   P.lda = lda; P.ldb = ldb; P.slab = slab;
   const dim3 grid(nprob * splits * P.tiles_m * P.tiles_n), block(256);
-  if (depth == 32) {
-    if (brc) hipLaunchKernelGGL((k_skinny_dma<true, 2>), grid, block, 0, st, P);
-    else hipLaunchKernelGGL((k_skinny_dma<false, 2>), grid, block, 0, st, P);
-  } else {
-    if (brc) hipLaunchKernelGGL((k_skinny_dma<true, 1>), grid, block, 0, st, P);
-    else hipLaunchKernelGGL((k_skinny_dma<false, 1>), grid, block, 0, st, P);
-  }
+  auto go = [&](auto brc_t, auto nh_t, auto bf_t) {
+    hipLaunchKernelGGL((k_skinny_dma<decltype(brc_t)::value, decltype(nh_t)::value, decltype(bf_t)::value>),
+                       grid, block, 0, st, P);
+  };
+  auto by_bf = [&](auto brc_t, auto nh_t) {
+    if (g_bf16) go(brc_t, nh_t, std::true_type{});
+    else go(brc_t, nh_t, std::false_type{});
+  };
+  auto by_nh = [&](auto brc_t) {
+    if (depth == 32) by_bf(brc_t, std::integral_constant<int, 2>{});
+    else by_bf(brc_t, std::integral_constant<int, 1>{});
+  };
+  if (brc) by_nh(std::true_type{});
+  else by_nh(std::false_type{});
   return hipGetLastError();
 }
 

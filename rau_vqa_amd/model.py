@@ -37,7 +37,7 @@ class Config:
     p_x: float = 0.5
     p_mf: float = 0.5
     device_id: int = 0
-    dtype: str = "f32"      # "f32" | "bf16" (bf16-rounded conv-GEMM operands) | "f32s" (3 x bf16 split)
+    dtype: str = "f32"      # "f32" | "bf16" (bf16-rounded operands in every conv and Linear GEMM) | "f32s" (convs: 3 x bf16 split)
 
     @property
     def Q(self) -> int:

@@ -2,7 +2,10 @@
  -- checked on the CPU, no device involved: the rounding-EMULATING restatement
 (oracle/ref_torch.py bf16=True) against the exact one on the shape of soak seed 2023
 (gpurun_out/soak_bf16b.log of round 3: 'attbymemory.linear.bias: 0.1126' against a fixed 3e-2).
-The emulation alone reproduces that figure, so the soak failure was the bar, not the device."""
+The emulation alone reproduces that kind of figure, so the soak failure was the bar, not the device.
+(Round 3's arithmetic rounded the conv operands only and gave 0.1126 of max |g| on this shape; with every
+Linear product rounded as well -- round 4 -- the same tensor is off by 0.30 of max |g| and still by less
+than 2e-3 of its un-cancelled magnitude.)"""
 import numpy as np
 
 from oracle import ref_torch as RT
@@ -34,8 +37,8 @@ def test_soak_seed_2023_is_cancellation_not_a_device_error():
     # ... and each is a sum over (sample, hop) terms that cancels by two orders of magnitude
     assert gabs.max() > 100 * np.abs(g).max()
     err = np.abs(ge - g).max()
-    assert 0.09 < err / np.abs(g).max() < 0.14            # round 3's 0.1126 'failure', with no device in sight
-    assert err / gabs.max() < 1.5e-3                      # an ordinary bf16 rounding error of the TERMS
+    assert 0.09 < err / np.abs(g).max() < 0.5             # far above a 3e-2 'vs exact' bar, with no device in sight
+    assert err / gabs.max() < 3e-3                        # an ordinary bf16 rounding error of the TERMS
     # every gradient tensor of the group against the bar the GPU test applies (1.5e-2 of the un-cancelled scale)
     off = 0
     for n, o, i in RT.mult_specs(sh):

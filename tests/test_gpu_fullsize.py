@@ -372,14 +372,14 @@ def test_answer_index_parity_1k_samples_bf16_d2048():
     """north_star's 1000-sample answer-index set in the configs[2] arithmetic: RAU_BF16 mode, 14x14x2048,
     evaluate mode, 4 x 250, against the rounding-EMULATING restatement (oracle/ref_torch.py bf16=True).
     Which rows are decidable is DERIVED per row, not chosen: the emulation is run three times -- plain,
-    and with every GEMM operand within 6e-7 (relative) of a bf16 rounding boundary rounded the other
+    and with every GEMM operand within 2e-6 (relative) of a bf16 rounding boundary rounded the other
     way, upwards and downwards (the operands whose rounding the device's own f32 error can flip,
     tests/test_gpu_bf16.py) -- and a row counts as decided when the three runs name the same answer and
     its top-2 margin exceeds twice the largest logit shift of that row between the runs plus the f32
     margin of the f32-mode tests (1e-5).  Decided rows must match exactly; both counts are printed."""
     import torch
     from oracle import ref_torch
-    NUDGE = 6e-7
+    NUDGE = 2e-6
     dims = dict(FULL, B=250, D=2048)
     sh = util.shapes(dims)
     m = make(dims, dtype="bf16")
@@ -387,7 +387,7 @@ def test_answer_index_parity_1k_samples_bf16_d2048():
     params = m.get_params()
     m.evaluate()
     mism = undecided = total = 0
-    worst = 0.0
+    worst = flip = 0.0
     for chunk in range(4):
         batch = synth.make_batch(250, 26, FULL["V"], 2048, 196, 1000, seed=323 + chunk, lens="ragged")
         m.set_batch(**batch)
@@ -400,6 +400,7 @@ def test_answer_index_parity_1k_samples_bf16_d2048():
             runs.append((np.asarray(r["logits"], np.float64), np.asarray(r["argmax"])))
         (lg, am), (lg_u, am_u), (lg_d, am_d) = runs
         worst = max(worst, util.rel_err(got_lg, lg))
+        flip = max(flip, util.rel_err(lg_u, lg), util.rel_err(lg_d, lg))
         shift = np.maximum(np.abs(lg_u - lg).max(-1), np.abs(lg_d - lg).max(-1))     # [H, B]
         srt = np.sort(lg, axis=-1)
         gap = srt[..., -1] - srt[..., -2]
@@ -409,7 +410,10 @@ def test_answer_index_parity_1k_samples_bf16_d2048():
         total += got_idx.size
     m.close()
     print(f"bf16 D=2048 answer indices: {total - undecided} decided, {undecided} undecided of {total}; "
-          f"device vs emulation logits {worst:.2e}")
-    assert worst < 2e-3
+          f"device vs emulation logits {worst:.2e}, nudged emulations vs plain {flip:.2e}")
+    # the derived bar of tests/test_gpu_bf16.py: accumulation order + 3 x what flipping the near-boundary
+    # roundings does to the emulation itself (the recurrence's operands are rounded too: a flip moves every
+    # later state, so device and emulation differ by a draw of the mode's rounding noise)
+    assert worst < 2e-4 + 3.0 * flip
     assert mism == 0, f"{mism} decided answer indices differ (of {total}, {undecided} undecided)"
     assert undecided < total // 20, f"{undecided} of {total} rows undecidable: the criterion decides nothing"

@@ -1,7 +1,7 @@
 // Stand-alone check + timing of the recurrence's skinny Linear GEMMs (gemm_nt / gemm_nn with a
 // split-K slab): result against a double-precision host product, then the average of 200 launches.
 // RAU_SKINNY_DMA_OFF=1 selects the register-staged tile for an A/B.
-//   usage: linbench [M] [deep]     deep: the 32-deep-stage form (skinny_dma32.hip)
+//   usage: linbench [M] [deep] [bf16]   deep: 32-deep stages;  bf16: operands rounded in registers, bf16 MFMA
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -17,7 +17,8 @@ static float frand(unsigned& s) { s = s * 1664525u + 1013904223u; return ((s >> 
 
 int main(int argc, char** argv) {
   const int M = argc > 1 ? atoi(argv[1]) : 256;
-  if (argc > 2) { rau::skinny_dma_set_deep(1); printf("32-deep stages (skinny_dma32.hip)\n"); }
+  if (argc > 2 && atoi(argv[2])) { rau::skinny_dma_set_deep(1); printf("32-deep stages\n"); }
+  if (argc > 3 && atoi(argv[3])) { rau::skinny_dma_set_bf16(1); printf("bf16 products\n"); }
   struct Shape { int nn, N, K; };
   const Shape shapes[] = {{0, 2048, 512}, {0, 2048, 1024}, {0, 2048, 1536}, {0, 512, 512}, {0, 1024, 512},
                           {1, 512, 2048}, {1, 1024, 2048}, {1, 512, 512}, {1, 1536, 2048}};
