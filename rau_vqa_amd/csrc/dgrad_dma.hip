@@ -77,7 +77,6 @@ struct DgradParams {
   float* C; long c_bs;                 // dZ [b][M][S]
   const float* dj; const float* av;    // [b][M], [b][S]
   const float* Y; float* rs;           // I [b][M][S]; rs [b][M]
-  int stagger;                         // start delay of the first round's second workgroup per CU, 10-ns ticks
 };
 
 template <int DNST>
@@ -93,16 +92,8 @@ __global__ __launch_bounds__(256, 2) void k_dgrad_dma(const DgradParams P) {
   const int tm = id % P.tiles_m, b = id / P.tiles_m;
   const int m0 = tm * DBM;
 
-  // The two workgroups of a CU start together and run the same program: left alone they reach their
-  // epilogues (200 KB of HBM traffic per tile, no MFMA work) together, and the matrix pipes idle while
-  // every CU of the chip waits for memory at once (measured: a launch takes rounds x (K loop + epilogue)).
-  // The workgroups dispatched as the SECOND of their CU in the first round (dispatch deals workgroup i to
-  // XCD i % 8 and fills an XCD's 32 CUs once before it doubles up: i in [256, 512)) start half a K loop
-  // late; their successors inherit the phase, so one tile's epilogue runs under its partner's K loop.
-  if (P.stagger > 0 && (blockIdx.x >> 8) == 1) {
-    const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
-    while (__builtin_amdgcn_s_memrealtime() - t0 < (uint64_t)P.stagger) __builtin_amdgcn_s_sleep(32);
-  }
+  // (A start delay for the first round's second workgroup per CU, so that one tile's epilogue would run
+  // under its partner's K loop, was measured and rejected: only the delay itself shows.  LOG.md, round 4.)
 
   // ---- DMA slots.  Instructions 0..15 of a stage: dS row kr = i (49 pieces, lanes 0..48, to pitch
   // 208); 16..23: Wp rows 2 q, 2 q + 1 (q = i - 16; lane l: row 2 q + (l >> 5), piece l & 31, fetched
@@ -354,8 +345,6 @@ hipError_t dgrad_dma(hipStream_t st, int nB, int M, int K, int S, const float* W
   P.X = X; P.x_bs = x_bs;
   P.C = C; P.c_bs = c_bs;
   P.dj = dj; P.av = av; P.Y = Y; P.rs = rs;
-  static const int stagger_us = [] { const char* e = std::getenv("RAU_DGRAD_STAGGER"); return e ? std::atoi(e) : 0; }();
-  P.stagger = P.tiles_m * nB > 512 ? stagger_us * 100 : 0;   // only where a CU gets more than one round
   static const hipError_t attr_err = [] {   // once per process, thread-safe
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_dgrad_dma<2>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, dgrad_lds_bytes(2));

@@ -144,12 +144,15 @@ bool conv_dz_fused_ok(int S, int M, int bf16) {
 }
 hipError_t conv_att_dgrad_dz(hipStream_t st, int nB, int M, int S, int A, const float* dS,
                              const float* Wp, const float* dj, const float* a, const float* I,
-                             float* dZ, float* rs, int dz16, int bf16, int ds16) {
+                             float* dZ, float* rs, int dz16, int bf16, int ds16, int light) {
   if (bf16 == 1 && dgrad16_ok(M, A, S, M))
     return dgrad16(st, nB, M, A, S, Wp, M, dS, (long)A * S, dZ, (long)M * S, dj, a, I, rs, dz16, ds16);
   if (ds16) return hipErrorInvalidValue;
-  // f32 output on the shapes dgrad_dma.hip takes: per-sample tiles fed by LDS-DMA (round 4)
-  if (!dz16 && dgrad_dma_ok(M, A, S, M))
+  // f32 output on the shapes dgrad_dma.hip takes: per-sample tiles fed by LDS-DMA (round 4).  Two of its
+  // workgroups hold 480 of a SIMD's 512 registers: where the recurrence is the longer path (contexts of up to
+  // 64 samples) its kernels then wait for a bulk tile to retire -- 4.23 / 4.18 vs 4.13 / 4.09 ms on the
+  // 64-sample shard -- so such callers keep the register-staged tile
+  if (!dz16 && !light && dgrad_dma_ok(M, A, S, M))
     return dgrad_dma(st, nB, M, A, S, Wp, M, dS, (long)A * S, dZ, (long)M * S, dj, a, I, rs);
   // one sample per tile (the wide tiling with this epilogue is a concluded negative in the step:
   // DESIGN.md section 8; tools/convbench keeps it for the stand-alone comparison)

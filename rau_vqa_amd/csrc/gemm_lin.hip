@@ -2,6 +2,7 @@
 // forward y = x W^T (gemm_nt), input gradient dx = dy W (gemm_nn) and the
 // deterministic split-K weight gradient dW += dy^T x (gemm_tn_acc).
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 
 #include "gemm_core.h"
@@ -71,6 +72,11 @@ static hipError_t lin_gemm(hipStream_t st, int M, int N, int K, const float* A, 
       return lin_reduce_epilogue(st, M, N, s, o.slab, C, ldc, o);
     }
   }
+#ifdef RAU_DEV_HOOKS
+  if (std::getenv("RAU_LIN_TRACE"))
+    std::fprintf(stderr, "lin_gemm fallback %s M=%d N=%d K=%d lda=%ld ldw=%ld slab=%d\n",
+                 BSRC == SRC_RC ? "nn" : "nt", M, N, K, lda, ldw, o.slab != nullptr);
+#endif
   P.nk = (K + BKS - 1) / BKS;
   const int s = skinny_splits(M, N, K, o);
   if (o.defer_splits) {  // partials stay in the slab; the consumer kernel reduces them
@@ -120,6 +126,11 @@ static hipError_t batched_deferred(hipStream_t st, int nb, int M, int N, int K,
       }
     }
   }
+#ifdef RAU_DEV_HOOKS
+  if (std::getenv("RAU_LIN_TRACE"))
+    std::fprintf(stderr, "batched fallback %s nb=%d M=%d N=%d K=%d slab_floats=%zu\n", BSRC == SRC_RC ? "nn" : "nt",
+                 nb, M, N, K, slab_floats);
+#endif
   LinOpts o;
   o.slab = slab;
   o.slab_floats = slab_floats / nb;
@@ -179,6 +190,10 @@ hipError_t gemm_nt_hetero_deferred(hipStream_t st, int nb, int M, int K, const f
       }
     }
   }
+#ifdef RAU_DEV_HOOKS
+  if (std::getenv("RAU_LIN_TRACE"))
+    std::fprintf(stderr, "hetero fallback nb=%d M=%d K=%d N=%d,%d,%d\n", nb, M, K, N[0], nb > 1 ? N[1] : 0, nb > 2 ? N[2] : 0);
+#endif
   const int nk = (K + BKS - 1) / BKS;
   int s = (160 * nb + tiles - 1) / tiles;     // the merged launch stands for nb launches
   if (s > nk / 2) s = nk / 2;

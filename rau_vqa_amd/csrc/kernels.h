@@ -126,7 +126,9 @@ hipError_t conv_att_dgrad_dz(hipStream_t st, int nB, int M, int S, int A, const 
                              const float* Wp, const float* dj, const float* a, const float* I,
                              float* dZ, float* rs, int dz16 = 0,    // dz16: dZ stored as bf16
                              int bf16 = 0,    // RAU_BF16 mode ...
-                             int ds16 = 0);   // ... and dS points at bf16 elements (dgrad16 only)   // RAU_BF16 mode: bf16-rounded GEMM operands where dgrad16 applies
+                             int ds16 = 0,    // ... and dS points at bf16 elements (dgrad16 only)
+                             int light = 0);  // the caller's recurrence is the longer path: keep the f32 product
+                                              // on the 176-register tile instead of dgrad_dma's 240 (two per CU)
 // RAU_BF16 mode, 14 x 14 maps, M % 128 == 0, K % 32 == 0 (dgrad16.hip): the product above with both GEMM
 // operands rounded to bf16 while staged, f32 accumulate and epilogue; C = dZ as f32 or bf16 elements
 bool dgrad16_ok(int M, int K, int S, long w_rs);

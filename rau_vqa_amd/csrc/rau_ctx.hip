@@ -1736,7 +1736,8 @@ int rau_backward(rau_ctx* ctx, const float* hop_w) {
                                  ctx->att_i.W, ctx->dj + hb * M,
                                  ctx->a + hb * S, ctx->I + hb * M * S,
                                  ctx->xd16 ? (float*)((uint16_t*)ctx->dZ + hb * M * S) : ctx->dZ + hb * M * S,
-                                 ctx->dbi_part + hb * M, ctx->xd16 ? 1 : 0, ctx->bf16, ctx->ds16_step ? 1 : 0));
+                                 ctx->dbi_part + hb * M, ctx->xd16 ? 1 : 0, ctx->bf16, ctx->ds16_step ? 1 : 0,
+                                 chain_bound(ctx) ? 1 : 0));
         else
           RUNS(sb, "conv_att_dgrad", gflop(M, (double)nH * S, A),
                ((double)nH * A * S + 2.0 * nH * M * S) * 4,

@@ -15,6 +15,14 @@ if kind == "bf16":
     run(dict(B=B, T=5, V=60, E=64, Rq=64, D=256, S=196, M=256, A=64, R=64, K=200, H=3), 0.2)
     print("OK")
     sys.exit(0)
+if kind == "bf16ws":
+    # RAU_BF16 mode at the question-LSTM width the persistent encoder takes (enc_ws.hip's rounding form)
+    from tests.test_gpu_bf16 import run
+    dims = dict(B=B, T=6, V=120, E=200, Rq=512, D=64, S=196, M=128, A=64, R=64, K=200, H=2)
+    run(dims, 0.2)
+    run(dims, 0.2, mode="eval")
+    print("OK")
+    sys.exit(0)
 if kind == "ws":
     # the reference's question-LSTM width: the only one the weight-stationary persistent encoder
     # (enc_ws.hip: Rq == 512, B % 16 == 0) takes, so RAU_ENC_WS=0|1 compares two different paths

@@ -11,7 +11,8 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 # (environment, batch, dims of tests/knob_check.py: "" generic, "ws" Rq = 512 (reaches enc_ws.hip),
-#  "wg" A = M = D = 128 (reaches wgrad_dma.hip), "bf16" M = D = 256 (reaches wgrad16.hip / dgrad16.hip))
+#  "wg" A = M = D = 128 (reaches wgrad_dma.hip), "bf16" M = D = 256 (reaches wgrad16.hip / dgrad16.hip),
+#  "bf16ws" bf16 mode at Rq = 512)
 KNOBS = [
     ({}, 72, ""), ({}, 24, ""),                                 # defaults on both sides of the 64-sample switch
     ({"RAU_CONV_WIDE": "0"}, 72, ""),                           # round-2 tilings everywhere
@@ -32,6 +33,11 @@ KNOBS = [
     ({"RAU_SKINNY_DMA_OFF": "1"}, 72, ""),
     ({"BF16": "1"}, 12, "bf16"),                                # bf16 mode, wgrad16.hip on ...
     ({"BF16": "1", "RAU_WGRAD16_OFF": "1"}, 12, "bf16"),        # ... and off (round-2 tile)
+    ({"BF16": "1", "RAU_SKINNY_DMA_OFF": "1"}, 12, "bf16"),     # ... its Linear products on the register-staged tiles (rounded while staged)
+    ({"BF16": "1"}, 32, "bf16ws"),                              # ... and through the persistent encoder's rounding form
+    ({"BF16": "1", "RAU_ENC_WS": "0"}, 32, "bf16ws"),           # ... against the launch-per-step path at the same shape
+    ({"RAU_SEAM": "0"}, 72, ""),                                # head dgrad in the backward, conv gradients behind the hop's last launch
+    ({"RAU_SEAM": "1"}, 72, ""), ({"RAU_SEAM": "2"}, 72, ""),   # ... each half of the default (3) alone
     ({"RAU_ATT_SPLIT": "1", "RAU_ATT_CHUNKS": "4"}, 72, ""),
     ({"RAU_ATT_FUSED": "1"}, 24, ""),
     ({}, 32, "ws"),                                             # persistent encoder selected by shape ...
