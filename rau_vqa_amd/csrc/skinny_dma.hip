@@ -127,11 +127,19 @@ __device__ __forceinline__ auto pack_k(const float (&v)[4 * NH]) {
   }
 }
 
+// What a DMA piece that lies outside its operand fetches instead (RAG kernels): sixteen zero bytes.
+__device__ __attribute__((aligned(16))) float g_zero_piece[4] = {0.f, 0.f, 0.f, 0.f};
+
 // BRC = false: W stored [N][K] (k contiguous);  true: W stored [K][N] (n contiguous)
 // NH: 16-deep halves per stage (1 or 2)
+// RAG: ragged shapes -- K any multiple of 4 (attprob's 196 positions, the 200-wide embedding) and, for
+//      [K][N] weights, N any multiple of 4: the reduction runs over ceil(K / stage) stages (an even number
+//      per split), and every 16-byte piece that starts at k >= K (or at a column >= N) is fetched from
+//      g_zero_piece instead, so the staged image holds zeros there (never a neighbouring row's values,
+//      never bytes behind the operand)
 // BF: both operands rounded to bf16 in registers, bf16 MFMA with f32 accumulation (rau_dtype RAU_BF16: the
 //     recurrence's gate / projection GEMMs, BASELINE.json configs[2]); the staging is the f32 one unchanged
-template <bool BRC, int NH, bool BF>
+template <bool BRC, int NH, bool BF, bool RAG>
 __global__ __launch_bounds__(256, BF ? 4 : 1) void k_skinny_dma(const SkinnyParams P) {
   constexpr int KBK = 16 * NH;          // K-step per stage
   constexpr int KPART = KT * KBK;       // floats per operand per stage (4 / 8 KB)
@@ -156,18 +164,21 @@ __global__ __launch_bounds__(256, BF ? 4 : 1) void k_skinny_dma(const SkinnyPara
   const int PN = P.N[prob];
   const int m0 = tm * KT, n0 = tn * KT;
   if (n0 >= PN) return;                      // narrower problem of a merged launch (whole workgroup)
-  const int nk = P.K / KBK;
+  const int nk = RAG ? (P.K + KBK - 1) / KBK : P.K / KBK;
   const int s0 = split * P.nst;
   int nst = nk - s0;
-  if (nst > P.nst) nst = P.nst;
   if (nst <= 0) return;
+  if (RAG || nst > P.nst) nst = P.nst;      // RAG: always the even count; stages past K stage zeros
 
   // ---- DMA sources: NH 16-byte pieces of each operand per lane and stage (pieces tid + 256 j)
   const char *ga[NH], *gb[NH];
   long stepb;
+  int ka[NH], kb[NH];          // RAG: first reduction index of the piece within its stage
+  bool colok[NH];              // RAG, [K][N] weights: the piece's columns lie inside N
 #pragma unroll
   for (int j = 0; j < NH; ++j) {
     const int p = tid + 256 * j, row = p / PPR, c = (p % PPR) ^ kc_swz<NH>(row);
+    ka[j] = c * 4; kb[j] = c * 4; colok[j] = true;
     int r = m0 + row;
     if (r > P.M - 1) r = P.M - 1;            // rows past M: a duplicate, never stored
     ga[j] = reinterpret_cast<const char*>(P.A[prob] + (long)r * P.lda + (long)s0 * KBK + c * 4);
@@ -180,15 +191,24 @@ __global__ __launch_bounds__(256, BF ? 4 : 1) void k_skinny_dma(const SkinnyPara
       const int k = p >> 4, cc = (p & 15) ^ (((k >> 2) & 1) << 2);
       gb[j] = reinterpret_cast<const char*>(P.B[prob] + ((long)s0 * KBK + k) * P.ldb + n0 + cc * 4);
       stepb = (long)KBK * P.ldb * 4;
+      kb[j] = k; colok[j] = n0 + cc * 4 < PN;
     }
   }
   int issued = 0;
+  const char* const zero_piece = reinterpret_cast<const char*>(g_zero_piece);
   auto issue = [&]() {   // next stage, into ring slot issued % KNST
     float* dst = smem + (issued & (KNST - 1)) * KSTAGE + w * 256;
+    const int kbase = (s0 + issued) * KBK;
 #pragma unroll
     for (int j = 0; j < NH; ++j) {
-      __builtin_amdgcn_global_load_lds((glb_ptr_t)ga[j], (lds_ptr_t)(dst + j * 1024), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((glb_ptr_t)gb[j], (lds_ptr_t)(dst + KPART + j * 1024), 16, 0, 0);
+      const char* sa = ga[j];
+      const char* sb = gb[j];
+      if constexpr (RAG) {
+        if (kbase + ka[j] >= P.K) sa = zero_piece;
+        if (kbase + kb[j] >= P.K || !colok[j]) sb = zero_piece;
+      }
+      __builtin_amdgcn_global_load_lds((glb_ptr_t)sa, (lds_ptr_t)(dst + j * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((glb_ptr_t)sb, (lds_ptr_t)(dst + KPART + j * 1024), 16, 0, 0);
       ga[j] += KBK * 4;
       gb[j] += stepb;
     }
@@ -347,25 +367,48 @@ void lin_set_bf16(int on) { g_bf16 = on; }
 int lin_bf16() { return g_bf16; }
 static int stage_depth(int K) { return (g_deep && K % 64 == 0) ? 32 : 16; }
 
+// Ragged shapes (the RAG kernels): K not a whole even number of stages, or [K][N] weights whose N is not
+// a multiple of the 64-column tile.  RAU_SKINNY_RAGGED_OFF sends them to the register-staged tile as
+// rounds 1-3 did (A/B knob).
+static bool ragged(int K, bool brc, int nprob, const int* N) {
+  if (K % (2 * stage_depth(K)) != 0) return true;
+  if (brc)
+    for (int p = 0; p < nprob; ++p)
+      if (N[p] % KT != 0) return true;
+  return false;
+}
+
 bool skinny_dma_ok(int M, int K, long lda, long ldb, bool brc, int nprob, const int* N,
                    const float* const* A, const float* const* B) {
   static const bool off = std::getenv("RAU_SKINNY_DMA_OFF") != nullptr;   // A/B knob
+  static const bool rag_off = std::getenv("RAU_SKINNY_RAGGED_OFF") != nullptr;
   if (off || M < 1 || nprob < 1 || nprob > 3) return false;
-  if (K % (2 * stage_depth(K)) != 0 || (lda & 3) || (ldb & 3)) return false;
+  if (K < 4 || (K & 3) || (lda & 3) || (ldb & 3)) return false;
+  if (ragged(K, brc, nprob, N)) {
+    if (rag_off) return false;
+    for (int p = 0; p < nprob; ++p)
+      if (brc && (N[p] & 3)) return false;         // pieces are all inside or all outside a row
+  }
   for (int p = 0; p < nprob; ++p) {
     if (N[p] < 1) return false;
-    if (brc && (N[p] % KT) != 0) return false;     // [K][N] rows are read 64 columns at a time
-    if ((reinterpret_cast<uintptr_t>(A[p]) & 15) || (reinterpret_cast<uintptr_t>(B[p]) & 15)) return false;
+    // global_load_lds_dwordx4 takes any dword-aligned global address (checked with tools/linbench: same
+    // results, same speed); the flat parameter vector puts every weight behind attscore's 1 x A + 1 block
+    // one float off a 16-byte boundary, and rounds 1-3 sent all of those GEMMs to the register-staged tile.
+    // RAU_SKINNY_ALIGN16 restores that (A/B knob).
+    static const bool align16 = std::getenv("RAU_SKINNY_ALIGN16") != nullptr;
+    const uintptr_t am = align16 ? 15 : 3;
+    if ((reinterpret_cast<uintptr_t>(A[p]) & am) || (reinterpret_cast<uintptr_t>(B[p]) & am)) return false;
   }
   return true;
 }
 
 // K splits: about one workgroup per CU (256), an even number of K-steps per split
 int skinny_dma_splits(int M, int K, int tiles_all, size_t cols_all, size_t slab_floats) {
-  const int nk = K / stage_depth(K);
+  const int depth = stage_depth(K);
+  const int nk = (K + depth - 1) / depth;
   int s = (256 + tiles_all / 2) / tiles_all;   // 160 .. 512 measured equal in the step
-  if (s < 1) s = 1;
   if (s > nk / 2) s = nk / 2;
+  if (s < 1) s = 1;
   while (s > 1 && (size_t)s * M * cols_all > slab_floats) --s;
   int per = (nk + s - 1) / s;
   per += per & 1;
@@ -376,10 +419,11 @@ hipError_t skinny_dma(hipStream_t st, bool brc, int nprob, int M, int K, const f
                       long lda, const float* const* B, long ldb, const int* N, float* slab,
                       const long* off, int splits) {
   const int depth = stage_depth(K);
-  if (splits < 1 || nprob < 1 || nprob > 3 || K % (2 * depth) != 0) return hipErrorInvalidValue;
+  const bool rag = ragged(K, brc, nprob, N);
+  if (splits < 1 || nprob < 1 || nprob > 3 || (K & 3)) return hipErrorInvalidValue;
   SkinnyParams P{};
   P.M = M; P.K = K; P.nprob = nprob; P.splits = splits;
-  const int nk = K / depth;
+  const int nk = (K + depth - 1) / depth;
   int per = (nk + splits - 1) / splits;
   per += per & 1;
   P.nst = per;
@@ -394,8 +438,12 @@ hipError_t skinny_dma(hipStream_t st, bool brc, int nprob, int M, int K, const f
   P.lda = lda; P.ldb = ldb; P.slab = slab;
   const dim3 grid(nprob * splits * P.tiles_m * P.tiles_n), block(256);
   auto go = [&](auto brc_t, auto nh_t, auto bf_t) {
-    hipLaunchKernelGGL((k_skinny_dma<decltype(brc_t)::value, decltype(nh_t)::value, decltype(bf_t)::value>),
-                       grid, block, 0, st, P);
+    if (rag)
+      hipLaunchKernelGGL((k_skinny_dma<decltype(brc_t)::value, decltype(nh_t)::value, decltype(bf_t)::value, true>),
+                         grid, block, 0, st, P);
+    else
+      hipLaunchKernelGGL((k_skinny_dma<decltype(brc_t)::value, decltype(nh_t)::value, decltype(bf_t)::value, false>),
+                         grid, block, 0, st, P);
   };
   auto by_bf = [&](auto brc_t, auto nh_t) {
     if (g_bf16) go(brc_t, nh_t, std::true_type{});

@@ -31,6 +31,9 @@ KNOBS = [
     ({"RAU_WGRAD_GROUPS": "1"}, 72, "wg"),                      # conv weight gradients: four-wave workgroups for both ...
     ({"RAU_WGRAD_GROUPS": "2"}, 72, "wg"),                      # ... and the eight-wave (two K groups) form for both
     ({"RAU_SKINNY_DMA_OFF": "1"}, 72, ""),
+    ({"RAU_SKINNY_ALIGN16": "1"}, 72, ""),                      # weights off a 16-byte boundary back on the register-staged tile
+    ({"RAU_SKINNY_RAGGED_OFF": "1"}, 72, ""),                   # ... and the K = 196 / N = 196 products (skinny_dma.hip RAG)
+    ({"RAU_SKINNY_RAGGED_OFF": "1"}, 24, ""),
     ({"BF16": "1"}, 12, "bf16"),                                # bf16 mode, wgrad16.hip on ...
     ({"BF16": "1", "RAU_WGRAD16_OFF": "1"}, 12, "bf16"),        # ... and off (round-2 tile)
     ({"BF16": "1", "RAU_SKINNY_DMA_OFF": "1"}, 12, "bf16"),     # ... its Linear products on the register-staged tiles (rounded while staged)

@@ -1,7 +1,8 @@
 // Stand-alone check + timing of the recurrence's skinny Linear GEMMs (gemm_nt / gemm_nn with a
 // split-K slab): result against a double-precision host product, then the average of 200 launches.
 // RAU_SKINNY_DMA_OFF=1 selects the register-staged tile for an A/B.
-//   usage: linbench [M] [deep] [bf16]   deep: 32-deep stages;  bf16: operands rounded in registers, bf16 MFMA
+//   usage: linbench [M] [deep] [bf16] [woff]   deep: 32-deep stages;  bf16: operands rounded in registers, bf16 MFMA;
+//          woff: the weights start that many floats behind a 16-byte boundary (the flat parameter vector does that)
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -18,10 +19,14 @@ static float frand(unsigned& s) { s = s * 1664525u + 1013904223u; return ((s >> 
 int main(int argc, char** argv) {
   const int M = argc > 1 ? atoi(argv[1]) : 256;
   if (argc > 2 && atoi(argv[2])) { rau::skinny_dma_set_deep(1); printf("32-deep stages\n"); }
-  if (argc > 3 && atoi(argv[3])) { rau::skinny_dma_set_bf16(1); printf("bf16 products\n"); }
+  if (argc > 3 && atoi(argv[3])) { rau::lin_set_bf16(1); printf("bf16 products\n"); }
+  const int woff = argc > 4 ? atoi(argv[4]) : 0;   // W starts `woff` floats behind a 16-byte boundary
+  if (woff) printf("W offset by %d floats\n", woff);
   struct Shape { int nn, N, K; };
   const Shape shapes[] = {{0, 2048, 512}, {0, 2048, 1024}, {0, 2048, 1536}, {0, 512, 512}, {0, 1024, 512},
-                          {1, 512, 2048}, {1, 1024, 2048}, {1, 512, 512}, {1, 1536, 2048}};
+                          {1, 512, 2048}, {1, 1024, 2048}, {1, 512, 512}, {1, 1536, 2048},
+                          // ragged: attprob's 196 positions as K (forward, dgrad) and as N, the 200-wide embedding
+                          {0, 512, 196}, {1, 512, 196}, {1, 196, 512}, {0, 2048, 200}, {1, 200, 2048}};
   hipStream_t st;
   CK(hipStreamCreate(&st));
   const size_t slab_floats = (size_t)16 << 20;
@@ -34,8 +39,9 @@ int main(int argc, char** argv) {
     for (auto& v : hA) v = frand(seed);
     for (auto& v : hW) v = frand(seed) * 0.1f;
     for (auto& v : hb) v = frand(seed);
-    float *A, *W, *b, *C;
-    CK(hipMalloc(&A, hA.size() * 4)); CK(hipMalloc(&W, hW.size() * 4));
+    float *A, *W, *b, *C, *Wbase;
+    CK(hipMalloc(&A, hA.size() * 4)); CK(hipMalloc(&Wbase, (hW.size() + 8) * 4));
+    W = Wbase + woff;
     CK(hipMalloc(&b, hb.size() * 4)); CK(hipMalloc(&C, hC.size() * 4));
     CK(hipMemcpy(A, hA.data(), hA.size() * 4, hipMemcpyHostToDevice));
     CK(hipMemcpy(W, hW.data(), hW.size() * 4, hipMemcpyHostToDevice));
@@ -72,7 +78,7 @@ int main(int argc, char** argv) {
     const double us = ms * 1000.0 / 200;
     printf("%s M=%d N=%d K=%d  max|err|=%.2e  %.1f us/GEMM(+reduce)  %.1f TFLOP/s\n", sh.nn ? "nn" : "nt", M, N, K,
            maxerr, us, 2.0 * M * N * K / us * 1e-6);
-    hipFree(A); hipFree(W); hipFree(b); hipFree(C);
+    hipFree(A); hipFree(Wbase); hipFree(b); hipFree(C);
   }
   return 0;
 }
