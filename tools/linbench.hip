@@ -24,7 +24,7 @@ int main(int argc, char** argv) {
   if (woff) printf("W offset by %d floats\n", woff);
   struct Shape { int nn, N, K; };
   const Shape shapes[] = {{0, 2048, 512}, {0, 2048, 1024}, {0, 2048, 1536}, {0, 512, 512}, {0, 1024, 512},
-                          {1, 512, 2048}, {1, 1024, 2048}, {1, 512, 512}, {1, 1536, 2048},
+                          {1, 512, 2048}, {1, 1024, 2048}, {1, 512, 512}, {1, 1536, 2048}, {0, 512, 2048},
                           // ragged: attprob's 196 positions as K (forward, dgrad) and as N, the 200-wide embedding
                           {0, 512, 196}, {1, 512, 196}, {1, 196, 512}, {0, 2048, 200}, {1, 200, 2048}};
   hipStream_t st;
