@@ -70,7 +70,7 @@ for cls, rr in by_cls.items():
                "note": "hbm_bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (gfx950 FETCH_SIZE correction, "
                        "MI355X_MICROARCH.md); operands counted at their stored width"},
               open(os.path.join(OUT, f"{tag}_bf16_pmc_{cls}.json"), "w"), indent=1)
-lines = [f"# {tag} bf16 mode (BASELINE.json configs[2]: Ours_ResNet, B=256, D=2048, bf16 conv operands)", ""]
+lines = [f"# {tag} bf16 mode (BASELINE.json configs[2]: Ours_ResNet, B=256, D=2048, bf16-rounded operands in every conv and Linear GEMM)", ""]
 bl = os.path.join(src, "b16_bench_line.json")
 for l in open(bl):
     if l.startswith("{"):
