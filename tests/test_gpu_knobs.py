@@ -38,7 +38,6 @@ KNOBS = [
     ({"BF16": "1", "RAU_WGRAD16_OFF": "1"}, 12, "bf16"),        # ... and off (round-2 tile)
     ({"BF16": "1", "RAU_SKINNY_DMA_OFF": "1"}, 12, "bf16"),     # ... its Linear products on the register-staged tiles (rounded while staged)
     ({"BF16": "1"}, 32, "bf16ws"),                              # ... and through the persistent encoder's rounding form
-    ({"BF16": "1", "RAU_ENC_WS": "0"}, 32, "bf16ws"),           # ... against the launch-per-step path at the same shape
     ({"RAU_SEAM": "0"}, 72, ""),                                # head dgrad in the backward, conv gradients behind the hop's last launch
     ({"RAU_SEAM": "1"}, 72, ""), ({"RAU_SEAM": "2"}, 72, ""),   # ... each half of the default (3) alone
     ({"RAU_ATT_SPLIT": "1", "RAU_ATT_CHUNKS": "4"}, 72, ""),
