@@ -233,25 +233,6 @@ struct LstmFwdCell {
 };
 struct LstmFwdCells { int n; LstmFwdCell c[2]; };
 hipError_t lstm_fwd_multi(hipStream_t st, int order, int nB, int R, const LstmFwdCells& cells);
-// One LSTM cell step as ONE launch (lstm_fused.hip): recurrent gate GEMM on f32 MFMA with the
-// cell's pointwise half as its epilogue.  Up to two independent cells per launch (the encoder's
-// layer wavefront).  Per cell: pre-activation = `pre` rows [B,4R] (or b1 + b2 when pre is null)
-// + sum over nsrc (0..2) sources of A_k [B,K_k] W_k[4R,K_k]^T; gates is written in place of pre
-// when they are the same buffer.
-struct LstmStepSide {
-  int nsrc; int K[2];
-  const float* A[2]; const float* W[2];
-  const float* pre; const float* b1; const float* b2;
-  float* gates; const float* c_prev; float* c; float* h; float* tanhc;
-  float* drop_out; const uint32_t* mask; size_t mask_e0; float mscale;
-};
-struct LstmStepParams { int n, B, R; LstmStepSide s[2]; int bf16 = 0; /* operands of the gate products rounded to bf16 */ };
-hipError_t lstm_step_fused(hipStream_t st, int order, const LstmStepParams& P);
-// The 2-layer encoder's whole wavefront (TL + 1 steps of the same tiles) in one persistent launch with
-// a grid barrier per step (lstm_fused.hip).  Tensors are time-major [t][B][..]; slot 0 of h1/c1/h2/c2
-// holds the zero initial state; G1 holds layer 1's input projection (+ both biases) and receives the
-// activated gates.  flags: >= enc_persist_workgroups(B, R) + 1 words (one per workgroup + the published epoch), zeroed once; epoch0: a number that
-// grows by at least TL + 1 from launch to launch; *err is set if a barrier timed out.
 // Weight-stationary persistent encoder forward (enc_ws.hip, round 3): all T token steps of both
 // layers in one launch, recurrent weights held in registers, per-(layer, sample half) counters
 // instead of a grid barrier.  cnt: 16 words (zeroed by the launcher), err: device error word.

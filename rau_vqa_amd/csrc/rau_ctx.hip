@@ -1344,42 +1344,6 @@ int rau_forward(rau_ctx* ctx) {
       RUN("enc_ws", (double)TL * 3 * gflop(B, 4 * Rq, Rq), 0, enc_ws_forward(st, GATES_DEEP, q));
       HIPC(hipMemcpyAsync(ctx->perr_h, ctx->perr_d, sizeof(int), hipMemcpyDeviceToHost, st));
       ctx->persist_used = true;
-    } else if (ctx->mode == RAU_MODE_EVAL) {
-      // one launch per wavefront step: gate GEMM + cell fused (lstm_fused.hip)
-      for (int s = 1; s <= TL + 1; ++s) {
-        if (s == t_head + 1 && t_head < TL) HIPC(hipStreamWaitEvent(st, ctx->evG, 0));   // G1 rows of token s
-        LstmStepParams sp{};
-        sp.B = B; sp.R = Rq; sp.bf16 = ctx->bf16 == 1;
-        double fl = 0;
-        if (s <= TL) {  // layer-1 cell t = s: G1[t] + h1[t-1] W_h2h1^T
-          LstmStepSide& C1 = sp.s[sp.n++];
-          C1.nsrc = s >= 2 ? 1 : 0;           // h1[0] = 0
-          C1.A[0] = ctx->h1 + (size_t)(s - 1) * BRq; C1.W[0] = ctx->h2h[0].W; C1.K[0] = Rq;
-          C1.pre = ctx->G1 + (size_t)(s - 1) * G4;
-          C1.gates = ctx->G1 + (size_t)(s - 1) * G4;
-          C1.c_prev = ctx->c1 + (size_t)(s - 1) * BRq;
-          C1.c = ctx->c1 + (size_t)s * BRq; C1.h = ctx->h1 + (size_t)s * BRq;
-          C1.tanhc = ctx->tc1 + (size_t)(s - 1) * BRq;
-          C1.drop_out = ctx->x2 + (size_t)(s - 1) * BRq;   // layer-2 input, DeepLSTM.lua:39
-          C1.mask = m_rnn; C1.mask_e0 = (size_t)(s - 1) * BRq; C1.mscale = sc(RAU_MASK_RNN);
-          fl += C1.nsrc * gflop(B, 4 * Rq, Rq);
-        }
-        if (s >= 2) {  // layer-2 cell t = s - 1: b + x2[t] W_i2h2^T + h2[t-1] W_h2h2^T
-          const int t = s - 1;
-          LstmStepSide& C2 = sp.s[sp.n++];
-          C2.nsrc = s >= 3 ? 2 : 1;           // h2[0] = 0
-          C2.A[0] = ctx->x2 + (size_t)(t - 1) * BRq; C2.W[0] = ctx->i2h[1].W; C2.K[0] = Rq;
-          C2.A[1] = ctx->h2 + (size_t)(t - 1) * BRq; C2.W[1] = ctx->h2h[1].W; C2.K[1] = Rq;
-          C2.pre = nullptr; C2.b1 = ctx->i2h[1].b; C2.b2 = ctx->h2h[1].b;
-          C2.gates = ctx->G2 + (size_t)(t - 1) * G4;
-          C2.c_prev = ctx->c2 + (size_t)(t - 1) * BRq;
-          C2.c = ctx->c2 + (size_t)t * BRq; C2.h = ctx->h2 + (size_t)t * BRq;
-          C2.tanhc = ctx->tc2 + (size_t)(t - 1) * BRq;
-          C2.drop_out = nullptr; C2.mask = nullptr; C2.mask_e0 = 0; C2.mscale = 1.f;
-          fl += C2.nsrc * gflop(B, 4 * Rq, Rq);
-        }
-        RUN("enc_step_fused", fl, 0, lstm_step_fused(st, GATES_DEEP, sp));
-      }
     } else
     for (int s = 1; s <= TL + 1; ++s) {
       if (s == t_head + 1 && t_head < TL) HIPC(hipStreamWaitEvent(st, ctx->evG, 0));   // G1 rows of token s
