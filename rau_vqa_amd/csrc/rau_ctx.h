@@ -20,6 +20,10 @@ using namespace rau;
 
 // LinOpts pre-wired with the ctx's split-K workspace
 constexpr int kEncHeadTokens = 4;   // tokens whose layer-1 input projection stays on the chain stream
+constexpr int kEncSideChunks = 4;   // the other tokens' projection: that many launches on the third stream, each with
+                                    // its own event -- the recurrence waits for the chunk it is about to read, not
+                                    // for all of them (one launch of 22 x 256 rows took 0.3-0.45 ms beside the bulk
+                                    // tiles and held the encoder at token 5)
 #define LINOPTS(name) LinOpts name; name.slab = ctx->slab; name.slab_floats = ctx->slab_floats
 
 // ------------------------------------------------------------------ errors
@@ -97,6 +101,8 @@ struct rau_ctx {
   hipEvent_t evA = nullptr, evD = nullptr, evW = nullptr, evE = nullptr, evW3 = nullptr,
              evM3 = nullptr, evEnd = nullptr, evE1 = nullptr, evHd = nullptr,
              evG0 = nullptr, evG = nullptr, evQ0 = nullptr, evQ = nullptr, evDq = nullptr;   // side-stream forks / joins
+  hipEvent_t evGc[kEncSideChunks] = {};   // layer-1 input projection, chunk c done on the third stream
+  int enc_chunk_tok[kEncSideChunks + 1] = {};   // first token of chunk c (last entry: TL) in the current forward
   std::vector<hipEvent_t> evH;       // per hop: forward chain done (the head stream waits on it)
   std::vector<hipEvent_t> evF, evK;  // per hop group: forward bulk done / backward chain done
   // hops per bulk launch (pipelines the bulk GEMMs with the hop loops): gsize[h] = n if hops

@@ -199,6 +199,7 @@ int rau_create(const rau_config* cfg, rau_ctx** out) {
   for (hipEvent_t* e : {&ctx->evA, &ctx->evD, &ctx->evW, &ctx->evE, &ctx->evW3, &ctx->evM3, &ctx->evEnd, &ctx->evE1,
                         &ctx->evG0, &ctx->evG, &ctx->evQ0, &ctx->evQ, &ctx->evDq})
     hipEventCreateWithFlags(e, evflags);
+  for (hipEvent_t& e : ctx->evGc) hipEventCreateWithFlags(&e, evflags);
   {
     int plo = 0, phi = 0;
     hipDeviceGetStreamPriorityRange(&plo, &phi);
@@ -546,6 +547,8 @@ void rau_destroy(rau_ctx* ctx) {
   if (ctx->ev1) hipEventDestroy(ctx->ev1);
   for (hipEvent_t e : {ctx->evA, ctx->evD, ctx->evW, ctx->evE, ctx->evW3, ctx->evM3, ctx->evEnd, ctx->evE1,
                        ctx->evG0, ctx->evG, ctx->evQ0, ctx->evQ, ctx->evDq})
+    if (e) hipEventDestroy(e);
+  for (hipEvent_t e : ctx->evGc)
     if (e) hipEventDestroy(e);
   if (ctx->st3) hipStreamDestroy(ctx->st3);
   if (ctx->perr_h) hipHostFree(ctx->perr_h);
@@ -1325,12 +1328,29 @@ int rau_forward(rau_ctx* ctx) {
       o.slab = ctx->slab3; o.slab_floats = ctx->slab3_floats;
       o.bias = ctx->i2h[0].b;
       o.bias2 = ctx->h2h[0].b;
-      const int r1 = (TL - t_head) * B;
-      RUNS(ctx->st3, "enc_i2h_gemm", gflop(r1, 4 * Rq, E), 0,
-           gemm_nt(ctx->st3, r1, 4 * Rq, E, ctx->we + (size_t)t_head * B * E, E, ctx->i2h[0].W, E,
-                   ctx->G1 + (size_t)t_head * G4, 4 * Rq, o));
-      HIPC(hipEventRecord(ctx->evG, ctx->st3));
+      // in chunks, so that the recurrence only ever waits for the rows it is about to read
+      static const int nchunk_env = [] { const char* e = std::getenv("RAU_ENC_CHUNKS"); return e ? std::atoi(e) : 0; }();
+      const int nchunk = std::max(1, std::min(nchunk_env > 0 ? nchunk_env : kEncSideChunks,
+                                              std::min(kEncSideChunks, TL - t_head)));
+      const int per = (TL - t_head + nchunk - 1) / nchunk;
+      for (int cch = 0; cch <= kEncSideChunks; ++cch) ctx->enc_chunk_tok[cch] = TL;
+      for (int cch = 0, t0 = t_head; t0 < TL; ++cch, t0 += per) {
+        const int nt = std::min(per, TL - t0), r1 = nt * B;
+        ctx->enc_chunk_tok[cch] = t0;
+        RUNS(ctx->st3, "enc_i2h_gemm", gflop(r1, 4 * Rq, E), 0,
+             gemm_nt(ctx->st3, r1, 4 * Rq, E, ctx->we + (size_t)t0 * B * E, E, ctx->i2h[0].W, E,
+                     ctx->G1 + (size_t)t0 * G4, 4 * Rq, o));
+        HIPC(hipEventRecord(ctx->evGc[cch], ctx->st3));
+      }
     }
+    // the recurrence's wait in front of wavefront step s (layer-1 cell of token s, 1-based): the chunk that
+    // starts with that token
+    auto wait_i2h_rows = [&](int s) -> int {
+      if (t_head >= TL) return 0;
+      for (int cch = 0; cch < kEncSideChunks; ++cch)
+        if (ctx->enc_chunk_tok[cch] == s - 1 && s - 1 < TL) HIPC(hipStreamWaitEvent(st, ctx->evGc[cch], 0));
+      return 0;
+    };
     if (ws_path) {
       // both layers, all tokens: one launch, weights resident in registers (enc_ws.hip)
       EncWsParams q{};
@@ -1346,7 +1366,7 @@ int rau_forward(rau_ctx* ctx) {
       ctx->persist_used = true;
     } else
     for (int s = 1; s <= TL + 1; ++s) {
-      if (s == t_head + 1 && t_head < TL) HIPC(hipStreamWaitEvent(st, ctx->evG, 0));   // G1 rows of token s
+      if (int rc = wait_i2h_rows(s)) return rc;   // G1 rows of token s
       const float* Ap[3];
       const float* Wp[3];
       int nb = 0, i0 = -1, i1 = -1, i2 = -1;

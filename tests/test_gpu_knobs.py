@@ -49,6 +49,7 @@ KNOBS = [
     ({"RAU_SKINNY_DEEP": "0"}, 24, ""),                         # ... and 16-deep where 32 would be chosen
     ({"RAU_SIDE_SPLIT": "1"}, 72, ""),                          # the chain's non-recurrent GEMMs on the side stream
     ({"RAU_SIDE_SPLIT": "0"}, 24, ""),                          # ... and kept on the chain where they would be split
+    ({"RAU_ENC_CHUNKS": "1"}, 24, ""),                          # the side stream's layer-1 input projection as one launch (default: four chunks)
 ]
 
 
