@@ -270,7 +270,8 @@ hipError_t lstm_bwd_multi(hipStream_t st, int order, int nB, int R, const LstmBw
 // SL: logical number of positions when the tensors' pitch S is padded (7x7 maps); positions
 // [SL, S) get zero attention.
 // u_out: where to keep the finished u rows [nB][A] when T is not stored (T == nullptr).
-struct AttPartials { int u_ns = 0; const float* u_bias = nullptr; int z_ns = 0; const float* z_bias = nullptr; int SL = 0; float* u_out = nullptr; };
+// waves: the caller's choice of waves per sample for the forward kernel (8 | 16; 0 = the default, 8)
+struct AttPartials { int u_ns = 0; const float* u_bias = nullptr; int z_ns = 0; const float* z_bias = nullptr; int SL = 0; float* u_out = nullptr; int waves = 0; };
 hipError_t att_fwd_fused(hipStream_t st, int nB, int M, int A, int S, const float* P,
                          const float* u, const float* ws, const float* bs, const float* zm,
                          const float* I, const float* qf, float* T, float* a, float* jv,

@@ -712,7 +712,7 @@ hipError_t att_fwd_fused(hipStream_t st, int nB, int M, int A, int S, const floa
   if (!split_span_ok(u, ap.u_ns, (size_t)nB * A) ||
       !split_span_ok(zm, ap.z_ns, (size_t)nB * (ap.SL ? ap.SL : S)))
     return kSplitStateError;
-  const int nw = att_waves(false);
+  const int nw = att_waves(false, ap.waves);
   // 14 x 14 (and any S % 4 == 0, S <= 256) maps on the step path (tanh(P + u) not kept): the LDS-DMA kernel
   static const bool dma_off = std::getenv("RAU_ATT_DMA_OFF") != nullptr;   // A/B knob
   if (!dma_off && !T && S % 4 == 0 && S <= 256 && A <= 64 * 8 && M <= 64 * 8 && (nw == 8 || nw == 16)) {
