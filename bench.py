@@ -496,7 +496,7 @@ def main():
             extra["inference"] = {"qa_per_s": cfg.B / inf_s, "batch": cfg.B, "ms_per_batch": inf_s * 1e3,
                                   "roofline": inference_roofline(cfg, inf_s),
                                   "note": "whole evaluate-mode forward, wall time over 10 batches; at this batch the "
-                                          "27 encoder steps and 8 hops (~90 dependent launches) bound it"}
+                                          "27 encoder steps of two launches and 8 hops of seven (~120 dependent launches) bound it"}
             m.training()
             # the same forward at a serving batch (the recurrences' launch chain does not grow with the batch)
             if world == 1 and args.dtype == "f32" and not args.graph and args.batch == 256:
