@@ -372,6 +372,8 @@ struct HopGrad {
   int* dh_part_ns_out;
   hipEvent_t ev_conv_ready;  // non-null: recorded on the chain stream right behind att_bwd -- everything the
                              // bulk stream's conv gradients of this hop read (dS, dj) exists from there on
+  bool dh_prev_dead;      // the gradient at prev_h has no consumer (step-level hop 0: the initial state is a
+                          // constant): its three products are not formed
 };
 __attribute__((visibility("hidden"))) int hop_forward(rau_ctx* ctx, int h, const float* cp,
     const float* hp, float* c_out, float* h_out, const float* Ih, const float* Pin,

@@ -257,10 +257,12 @@ int rau_create(const rau_config* cfg, rau_ctx** out) {
   }
   ctx->evF.resize(c.H);
   ctx->evK.resize(c.H);
+
   ctx->evH.resize(c.H);
   for (int i = 0; i < c.H; ++i) {
     hipEventCreateWithFlags(&ctx->evF[i], evflags);
     hipEventCreateWithFlags(&ctx->evK[i], evflags);
+
     hipEventCreateWithFlags(&ctx->evH[i], evflags);
   }
   hipEventCreateWithFlags(&ctx->evHd, evflags);
@@ -561,6 +563,7 @@ void rau_destroy(rau_ctx* ctx) {
   for (hipEvent_t e : ctx->hopw_ev) if (e) hipEventDestroy(e);
   for (hipEvent_t e : ctx->evF) hipEventDestroy(e);
   for (hipEvent_t e : ctx->evK) hipEventDestroy(e);
+
   for (hipEvent_t e : ctx->evH) hipEventDestroy(e);
   if (ctx->evHd) hipEventDestroy(ctx->evHd);
   if (ctx->st2) hipStreamDestroy(ctx->st2);
@@ -1173,13 +1176,20 @@ int hop_backward(rau_ctx* ctx, int h, const float* cp, const float* Ih, const Ho
   // dj partials = dg Wx ; dh_prev partials #1 = dg Wr
   int ns_j = 0, ns_h = 0;
   float* dhp = nullptr;      // start of this hop's dh_prev partials [ns_h][B][R]
-  if (M == R) {
+  const bool dead = g.dh_prev_dead;
+  if (M == R && !dead) {
     const float* Ap[2] = {dg4, dg4};
     const float* Wp[2] = {ctx->lstm_i2h.W, ctx->lstm_h2h.W};
     RUN("small_gemm", 2 * gflop(B, M, 4 * R), 0,
         gemm_nn_batched_deferred(st, 2, B, M, 4 * R, Ap, 4 * R, Wp, M, X, Xcap / 2, &ns_j));
     dhp = X + (size_t)ns_j * BM_;
     ns_h = ns_j;
+  } else if (dead) {
+    LinOpts o1;
+    o1.slab = X; o1.slab_floats = Xcap / 4; o1.defer_splits = &ns_j;
+    RUN("small_gemm", gflop(B, M, 4 * R), 0,
+        gemm_nn(st, B, M, 4 * R, dg4, 4 * R, ctx->lstm_i2h.W, M, djh, M, o1));
+    dhp = X + (size_t)ns_j * BM_;
   } else {
     LinOpts o1;
     o1.slab = X; o1.slab_floats = Xcap / 4; o1.defer_splits = &ns_j;
@@ -1219,7 +1229,7 @@ int hop_backward(rau_ctx* ctx, int h, const float* cp, const float* Ih, const Ho
                       ctx->u + (size_t)h * B * A, ctx->att_part, ns_a, SL, g.da_out));
   if (g.ev_conv_ready) HIPC(hipEventRecord(g.ev_conv_ready, st));
   const size_t used = (size_t)(dhp - X);
-  {  // dh_prev partials #2 = dz Wm
+  if (!dead) {  // dh_prev partials #2 = dz Wm
     int ns = 0;
     LinOpts o;
     o.slab = dhp + (size_t)ns_h * BR_;
@@ -1237,7 +1247,7 @@ int hop_backward(rau_ctx* ctx, int h, const float* cp, const float* Ih, const Ho
     o.y_rs = M;
     RUN("small_gemm", gflop(B, M, A), 0, gemm_nn(st, B, M, A, duh, A, ctx->att_q.W, M, dqt, M, o));
   }
-  {  // dh_prev partials #3 = dq~ Wh
+  if (!dead) {  // dh_prev partials #3 = dq~ Wh
     int ns = 0;
     LinOpts o;
     o.slab = dhp + (size_t)ns_h * BR_;
@@ -1247,8 +1257,8 @@ int hop_backward(rau_ctx* ctx, int h, const float* cp, const float* Ih, const Ho
     ns_h += ns;
   }
   if (g.dh_part_out) {   // the next hop_backward's lstm_bwd sums them
-    *g.dh_part_out = dhp;
-    *g.dh_part_ns_out = ns_h;
+    *g.dh_part_out = dead ? nullptr : dhp;
+    *g.dh_part_ns_out = dead ? 0 : ns_h;
   } else {               // module-level callers want dh_prev itself
     LinOpts o;
     RUN("lin_reduce", 0, 0, lin_reduce_epilogue(st, B, R, ns_h, dhp, g.dh_out, R, o));
@@ -1677,6 +1687,7 @@ int rau_backward(rau_ctx* ctx, const float* hop_w) {
       // h is the first hop of its launch group: its conv gradients may start behind att_bwd, three launches
       // before the hop's backward is over (it matters for the first group: the forward / backward seam)
       g.ev_conv_ready = (gsz[h] && (seam_mask() & 2)) ? ctx->evK[h] : nullptr;
+      g.dh_prev_dead = h == 0;   // hop 0's prev_h is the constant initial state: nothing reads its gradient
       if (int rc = hop_backward(ctx, h, ctx->cc + (size_t)h * BR_,
                                 ctx->I + (ctx->I_shared ? 0 : (size_t)h * BM_ * S), g))
         return rc;
